@@ -1,0 +1,217 @@
+/*
+ * kicp.h -- C-ABI of the MI355X-native KISS-ICP registration hot path (libkicp.so).
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++/torch types.
+ * Every entry point names the reference interface it replaces (file:line under
+ * PRBonn/kiss-icp v1.2.3).  The reference's C++ classes (kiss_icp::Registration,
+ * kiss_icp::VoxelHashMap, kiss_icp::pipeline::KissICP) and its pybind module are re-hosted on
+ * top of these calls (kiss-icp_amd/cpp/, kiss-icp_amd/python/); INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - points: row-major N x 3 float64, i.e. std::vector<Eigen::Vector3d>::data().
+ *   - SE(3): row-major 4 x 4 float64 (numpy's natural layout; Eigen::Matrix4d transposed).
+ *   - every function returns a kicp_status; nothing throws or aborts across the boundary.
+ *   - the caller owns every buffer it passes; the library keeps no pointer past the call.
+ *   - handles are single-threaded objects (like the reference's classes); distinct handles may
+ *     be used from distinct threads / on distinct GPUs concurrently.
+ *   - there is NO CPU fallback: with no gfx950 device every create call fails with
+ *     KICP_ERR_NO_DEVICE.
+ *   - voxel coordinates must satisfy |floor(p / voxel_size)| < 2^20 on every axis (the
+ *     device hash packs a voxel into one 64-bit word); KICP_ERR_RANGE otherwise.
+ */
+#ifndef KICP_H
+#define KICP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KICP_VERSION_MAJOR 0
+#define KICP_VERSION_MINOR 1
+
+typedef enum kicp_status {
+    KICP_OK = 0,
+    KICP_ERR_INVALID_ARG = 1, /* null pointer, bad shape, non-orthonormal pose (SOPHUS_ENSURE) */
+    KICP_ERR_HIP = 2,         /* a HIP runtime call failed; see kicp_last_error() */
+    KICP_ERR_OOM = 3,         /* device or host allocation failed */
+    KICP_ERR_CAPACITY = 4,    /* a device table could not grow any further */
+    KICP_ERR_RANGE = 5,       /* voxel coordinate outside +-2^20 */
+    KICP_ERR_TIMEOUT = 6,     /* a bounded in-kernel wait gave up (never hangs the GPU) */
+    KICP_ERR_NO_DEVICE = 7,   /* no usable gfx950 GPU */
+    KICP_ERR_TIMESTAMPS = 8   /* 0 < n_timestamps < n_points (std::vector::at would throw,
+                                 core/Preprocessing.cpp:76-77) */
+} kicp_status;
+
+const char *kicp_status_string(int status);
+/* message of the last failing call on this thread ("" if none) */
+const char *kicp_last_error(void);
+int kicp_version(int *major, int *minor);
+int kicp_device_count(int *count);
+/* name and gcnArchName of a device, for logs */
+int kicp_device_name(int device_id, char *buf, size_t buf_len);
+
+/* ------------------------------------------------------------------------------------------
+ * VoxelHashMap  -- replaces kiss_icp::VoxelHashMap (core/VoxelHashMap.hpp:38-57,
+ * core/VoxelHashMap.cpp:35-132) / pybind _VoxelHashMap (pybind/kiss_icp_pybind.cpp:54-74).
+ * The map lives in HBM: an open-addressed hash of packed voxel keys over a pool of
+ * fixed-stride voxel blocks.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct kicp_map kicp_map;
+
+/* VoxelHashMap(voxel_size, max_distance, max_points_per_voxel)  VoxelHashMap.hpp:39-42 */
+int kicp_map_create(double voxel_size, double max_distance, unsigned max_points_per_voxel,
+                    int device_id, kicp_map **out);
+int kicp_map_destroy(kicp_map *map);
+int kicp_map_clear(kicp_map *map);                          /* Clear()   VoxelHashMap.hpp:44 */
+int kicp_map_empty(const kicp_map *map, int *empty);        /* Empty()   VoxelHashMap.hpp:45 */
+int kicp_map_size(const kicp_map *map, size_t *n_voxels, size_t *n_points);
+/* AddPoints(points)  VoxelHashMap.cpp:97-119 */
+int kicp_map_add_points(kicp_map *map, const double *xyz, size_t n);
+/* RemovePointsFarFromLocation(origin)  VoxelHashMap.cpp:121-132 */
+int kicp_map_remove_far(kicp_map *map, const double origin[3]);
+/* Update(points, origin)  VoxelHashMap.cpp:83-87 */
+int kicp_map_update_origin(kicp_map *map, const double *xyz, size_t n, const double origin[3]);
+/* Update(points, pose)  VoxelHashMap.cpp:89-95 (pose: row-major 4x4) */
+int kicp_map_update_pose(kicp_map *map, const double *xyz, size_t n, const double pose[16]);
+/* Pointcloud()  VoxelHashMap.cpp:72-81.  Writes at most cap points, *n = total points.
+ * Order: pool order (the reference's is hash-bucket order; both unspecified). */
+int kicp_map_pointcloud(const kicp_map *map, double *out_xyz, size_t cap, size_t *n);
+/* GetClosestNeighbor(query)  VoxelHashMap.cpp:46-70, batched over nq queries.
+ * nn_xyz[i] = (0,0,0) and dist[i] = DBL_MAX when the 27-neighbourhood is empty. */
+int kicp_map_closest_neighbor(const kicp_map *map, const double *query_xyz, size_t nq,
+                              double *nn_xyz, double *dist);
+
+/* ------------------------------------------------------------------------------------------
+ * Registration -- replaces kiss_icp::Registration (core/Registration.hpp:33-45,
+ * core/Registration.cpp:55-167) / pybind _Registration (kiss_icp_pybind.cpp:90-106).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct kicp_registration kicp_registration;
+
+typedef struct kicp_icp_stats {
+    int32_t iterations;       /* ICP iterations executed (0 when the map was empty) */
+    int32_t converged;        /* dx.norm() < convergence_criterion ended the loop */
+    uint64_t n_source;        /* N_src */
+    uint64_t n_corr_last;     /* correspondences in the last iteration */
+    uint64_t points_examined; /* E: map points examined, summed over iterations */
+    uint64_t n_corr_total;    /* correspondences summed over iterations */
+    double kernel_ms;         /* device time of the ICP kernel (hipEvent), 0 if not timed */
+} kicp_icp_stats;
+
+/* Registration(max_num_iteration, convergence_criterion, max_num_threads)
+ * Registration.cpp:126-136.  max_num_threads is accepted for signature compatibility and
+ * ignored (the device schedules its own parallelism). */
+int kicp_registration_create(int max_num_iterations, double convergence_criterion,
+                             int max_num_threads, int device_id, kicp_registration **out);
+int kicp_registration_destroy(kicp_registration *reg);
+/* AlignPointsToMap(frame, voxel_map, initial_guess, max_correspondence_distance,
+ * kernel_scale)  Registration.cpp:138-167.  map must live on the same device.  stats may be
+ * NULL. */
+int kicp_align_points_to_map(kicp_registration *reg, const double *frame_xyz, size_t n,
+                             const kicp_map *map, const double initial_guess[16],
+                             double max_correspondence_distance, double kernel_scale,
+                             double T_out[16], kicp_icp_stats *stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Free functions of the stages either side of the path ("next" rows of SURVEY.md section 8f)
+ * ---------------------------------------------------------------------------------------- */
+/* VoxelDownsample(frame, voxel_size)  core/VoxelUtils.cpp:7-21 / pybind _voxel_down_sample.
+ * Keeps the first point per voxel; output order = ascending original index (the reference's
+ * is robin_map bucket order, unspecified).  out_xyz must hold n points. */
+int kicp_voxel_downsample(const double *xyz, size_t n, double voxel_size, int device_id,
+                          double *out_xyz, size_t *n_out);
+/* Preprocessor(max_range, min_range, deskew, max_num_threads).Preprocess(frame, timestamps,
+ * relative_motion)  core/Preprocessing.cpp:40-95 / pybind _Preprocessor._preprocess.
+ * out_xyz must hold n points. */
+int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_t n_timestamps,
+                    const double relative_motion[16], double max_range, double min_range,
+                    int deskew, int device_id, double *out_xyz, size_t *n_out);
+
+/* ------------------------------------------------------------------------------------------
+ * pipeline::KissICP -- replaces kiss_icp::pipeline::KissICP (pipeline/KissICP.hpp:36-96,
+ * pipeline/KissICP.cpp:35-75).  All per-frame state (poses, adaptive threshold, local map,
+ * intermediate clouds) stays in HBM; only the raw scan goes in and the pose comes out.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct kicp_config { /* KISSConfig  pipeline/KissICP.hpp:36-54, same defaults */
+    double voxel_size;           /* 1.0   */
+    double max_range;            /* 100.0 */
+    double min_range;            /* 0.0   */
+    int max_points_per_voxel;    /* 20    */
+    double min_motion_th;        /* 0.1   */
+    double initial_threshold;    /* 2.0   */
+    int max_num_iterations;      /* 500   */
+    double convergence_criterion;/* 1e-4  */
+    int max_num_threads;         /* 0 (ignored) */
+    int deskew;                  /* 1     */
+} kicp_config;
+int kicp_config_default(kicp_config *cfg);
+
+typedef struct kicp_pipeline kicp_pipeline;
+
+typedef struct kicp_frame_stats {
+    uint64_t n_raw, n_preprocessed, n_frame_downsample, n_source;
+    uint64_t map_voxels;
+    double sigma;             /* adaptive threshold used for this frame */
+    kicp_icp_stats icp;
+} kicp_frame_stats;
+
+enum { /* kicp_pipeline_output: which cloud of the last frame */
+    KICP_OUT_PREPROCESSED = 0, /* RegisterFrame's first return value  (KissICP.cpp:67) */
+    KICP_OUT_SOURCE = 1,       /* RegisterFrame's second return value (KissICP.cpp:67) */
+    KICP_OUT_FRAME_DOWNSAMPLE = 2
+};
+
+int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **out);
+int kicp_pipeline_destroy(kicp_pipeline *p);
+/* RegisterFrame(frame, timestamps)  KissICP.cpp:35-68, host buffers (copied H2D). Blocks until
+ * the frame's pose is available.  timestamps may be NULL / n_timestamps 0. */
+int kicp_pipeline_register_frame(kicp_pipeline *p, const double *xyz, size_t n,
+                                 const double *timestamps, size_t n_timestamps);
+/* Same, with the scan (and timestamps) already resident in this device's HBM.  Enqueues the
+ * frame on the pipeline's stream and returns without waiting; frames may be queued
+ * back-to-back (frame k+1 consumes frame k's pose on the device).  The buffers must stay
+ * valid until kicp_pipeline_sync(). */
+int kicp_pipeline_register_frame_device(kicp_pipeline *p, const double *d_xyz, size_t n,
+                                        const double *d_timestamps, size_t n_timestamps);
+int kicp_pipeline_sync(kicp_pipeline *p);
+/* poses (row-major 4x4 each) of the frames completed by the most recent kicp_pipeline_sync /
+ * kicp_pipeline_register_frame, oldest first; *n_frames = how many there are */
+int kicp_pipeline_synced_poses(kicp_pipeline *p, double *T_out, size_t cap_frames,
+                               size_t *n_frames);
+/* pose() / delta()  KissICP.hpp:80-84 (getters and setters for the mutable refs) */
+int kicp_pipeline_pose(kicp_pipeline *p, double T[16]);
+int kicp_pipeline_delta(kicp_pipeline *p, double T[16]);
+int kicp_pipeline_set_pose(kicp_pipeline *p, const double T[16]);
+int kicp_pipeline_set_delta(kicp_pipeline *p, const double T[16]);
+/* VoxelMap()  KissICP.hpp:77-78: borrowed handle, owned by the pipeline */
+int kicp_pipeline_map(kicp_pipeline *p, kicp_map **map);
+/* LocalMap()  KissICP.hpp:75 == kicp_map_pointcloud(kicp_pipeline_map()) */
+/* clouds of the last registered frame */
+int kicp_pipeline_output_size(kicp_pipeline *p, int which, size_t *n);
+int kicp_pipeline_output(kicp_pipeline *p, int which, double *out_xyz, size_t cap, size_t *n);
+/* Voxelize(frame)  KissICP.cpp:70-75: (source, frame_downsample) of an arbitrary cloud */
+int kicp_pipeline_voxelize(kicp_pipeline *p, const double *xyz, size_t n, double *source_xyz,
+                           size_t *n_source, double *frame_downsample_xyz,
+                           size_t *n_frame_downsample);
+int kicp_pipeline_last_stats(kicp_pipeline *p, kicp_frame_stats *stats);
+/* device time (ms, hipEvents on the pipeline's stream) of the ICP kernel over all frames since
+ * the last reset, its launch count and iteration count -- for roofline accounting */
+int kicp_pipeline_icp_timing(kicp_pipeline *p, double *total_ms, uint64_t *launches,
+                             uint64_t *iterations, uint64_t *algorithmic_bytes, int reset);
+/* the HIP stream (hipStream_t) the pipeline launches on, as an opaque pointer */
+int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tuning knobs (process-wide; read when a handle is created).  Unknown names are an error.
+ *   "icp_blocks"      workgroups of the persistent ICP kernel (0 = choose from N_src)
+ *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
+ * ---------------------------------------------------------------------------------------- */
+int kicp_set_option(const char *name, long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KICP_H */

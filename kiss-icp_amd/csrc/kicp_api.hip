@@ -1,0 +1,1223 @@
+// kicp_api.hip -- the C-ABI of libkicp (include/kicp.h): handle management, HBM buffers, launch
+// sequencing on one HIP stream per handle.  No CPU fallback exists: without a gfx950 device
+// every create call fails loudly with KICP_ERR_NO_DEVICE.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kicp_launch.hpp"
+
+namespace kicp {
+
+// ---- errors / options ------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+Options &options() {
+    static Options o;
+    return o;
+}
+
+int DevBuf::reserve(size_t need, bool keep, hipStream_t s) {
+    if (need <= bytes && p) return KICP_OK;
+    size_t nb = need < 256 ? 256 : need;
+    if (keep && bytes) nb = nb < bytes * 2 ? bytes * 2 : nb;
+    void *np = nullptr;
+    KICP_HIP(hipMalloc(&np, nb));
+    if (keep && p && bytes) {
+        KICP_HIP(hipMemcpyAsync(np, p, bytes, hipMemcpyDeviceToDevice, s));
+        KICP_HIP(hipStreamSynchronize(s));
+    }
+    if (p) KICP_HIP(hipFree(p));
+    p = np;
+    bytes = nb;
+    return KICP_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+int check_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s); libkicp has no CPU fallback",
+                  e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return KICP_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        set_error("device_id %d out of range (have %d)", device_id, n);
+        return KICP_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    KICP_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libkicp is built for gfx950 (MI355X) only", device_id,
+                  prop.gcnArchName);
+        return KICP_ERR_NO_DEVICE;
+    }
+    KICP_HIP(hipSetDevice(device_id));
+    return KICP_OK;
+}
+
+static uint32_t next_pow2(size_t v) {
+    uint32_t c = 1024;
+    while (c < v && c < (1u << 30)) c <<= 1;
+    return c;
+}
+
+static int err_bits_to_status(int bits) {
+    if (!bits) return KICP_OK;
+    if (bits & E_TIMEOUT) {
+        set_error("a bounded in-kernel wait gave up (ICP workgroups not co-resident?)");
+        return KICP_ERR_TIMEOUT;
+    }
+    if (bits & E_RANGE) {
+        set_error("voxel coordinate outside +-2^20 (point too far from the origin for this voxel size)");
+        return KICP_ERR_RANGE;
+    }
+    set_error("device table full (bits 0x%x)", bits);
+    return KICP_ERR_CAPACITY;
+}
+
+static int choose_icp_blocks(long n_hint) {
+    long g = options().icp_blocks;
+    if (g <= 0) {
+        // two rounds of 8 points per workgroup and iteration
+        g = (n_hint + 2 * kIcpGroupsPerBlock - 1) / (2 * kIcpGroupsPerBlock);
+    }
+    if (g < 1) g = 1;
+    if (g > kIcpMaxBlocks) g = kIcpMaxBlocks;
+    return (int)g;
+}
+
+}  // namespace kicp
+
+using namespace kicp;
+
+// ==============================================================================================
+// kicp_map
+// ==============================================================================================
+MapView kicp_map::view() const {
+    MapView v;
+    v.slots = slots.as<Slot>();
+    v.mask = slot_cap - 1;
+    v.blocks = blocks.as<char>();
+    v.stride = stride;
+    v.max_points = (int)max_points;
+    v.blocks_cap = blocks_cap;
+    v.ctr = ctr.as<int>();
+    v.free_ids = free_ids.as<int>();
+    v.voxel_size = voxel_size;
+    v.max_distance = max_distance;
+    v.map_resolution = sqrt(voxel_size * voxel_size / (double)max_points);
+    return v;
+}
+
+int kicp_map::refresh_counters() {
+    KICP_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
+    KICP_HIP(hipStreamSynchronize(stream));
+    used_ub = h_ctr[C_USED];
+    bump_ub = h_ctr[C_BUMP] < blocks_cap ? h_ctr[C_BUMP] : blocks_cap;
+    return KICP_OK;
+}
+
+int kicp_map::check_errors() {
+    KICP_TRY(refresh_counters());
+    if (h_ctr[C_ERR]) {
+        const int bits = h_ctr[C_ERR];
+        int zero = 0;
+        KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_ERR, &zero, sizeof zero, hipMemcpyHostToDevice, stream));
+        KICP_HIP(hipStreamSynchronize(stream));
+        return err_bits_to_status(bits);
+    }
+    return KICP_OK;
+}
+
+static int map_rehash(kicp_map *m, uint32_t new_cap) {
+    // (re)build the slot array from the live blocks; drops tombstones
+    if (new_cap != m->slot_cap) {
+        DevBuf ns;
+        KICP_TRY(ns.reserve((size_t)new_cap * sizeof(Slot)));
+        KICP_HIP(hipStreamSynchronize(m->stream));
+        m->slots.release();
+        m->slots = ns;
+        m->slot_cap = new_cap;
+    }
+    KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
+    launch_map_rehash(m->view(), m->bump_ub, m->stream);
+    KICP_HIP(hipGetLastError());
+    KICP_TRY(m->refresh_counters());
+    return KICP_OK;
+}
+
+int kicp_map::ensure_capacity(size_t incoming) {
+    // Every incoming point may open a new voxel.  Keep the load factor (live + tombstones) <= 1/2
+    // and one block per possible new voxel.  The host only knows upper bounds of the device
+    // counters between refreshes; refresh (one small D2H) before deciding to grow.
+    const size_t need_slots = 2 * ((size_t)used_ub + incoming);
+    const size_t need_blocks = (size_t)bump_ub + incoming;
+    if (need_slots <= slot_cap && need_blocks <= (size_t)blocks_cap) return KICP_OK;
+    KICP_TRY(refresh_counters());
+    const size_t live = (size_t)h_ctr[C_LIVE], tomb = (size_t)h_ctr[C_TOMB];
+    if (2 * ((size_t)used_ub + incoming) > slot_cap) {
+        const size_t want = 2 * (live + incoming);
+        uint32_t cap = slot_cap;
+        if (want > cap) cap = next_pow2(want * 2);
+        if (cap != slot_cap || tomb > 0) KICP_TRY(map_rehash(this, cap));
+        if (2 * ((size_t)used_ub + incoming) > slot_cap) {
+            set_error("voxel hash cannot grow to %zu slots", want);
+            return KICP_ERR_CAPACITY;
+        }
+    }
+    if ((size_t)bump_ub + incoming > (size_t)blocks_cap) {
+        size_t want = ((size_t)bump_ub + incoming) * 2;
+        if (want > (size_t)0x7FFFFFF0) want = (size_t)0x7FFFFFF0;
+        if (want < (size_t)bump_ub + incoming) {
+            set_error("voxel pool cannot grow beyond %d blocks", blocks_cap);
+            return KICP_ERR_CAPACITY;
+        }
+        const size_t old_bytes = (size_t)blocks_cap * stride;
+        KICP_TRY(blocks.reserve(want * stride + 64, true, stream));
+        KICP_HIP(hipMemsetAsync(blocks.as<char>() + old_bytes, 0, want * stride + 64 - old_bytes, stream));
+        KICP_TRY(free_ids.reserve(want * sizeof(int), true, stream));
+        blocks_cap = (int)want;
+    }
+    return KICP_OK;
+}
+
+static int map_alloc(kicp_map *m) {
+    m->stride = ((kBlockHeader + 24 * (int)m->max_points + 127) / 128) * 128;
+    m->slot_cap = 1u << 16;
+    m->blocks_cap = 1 << 14;
+    KICP_TRY(m->slots.reserve((size_t)m->slot_cap * sizeof(Slot)));
+    KICP_TRY(m->blocks.reserve((size_t)m->blocks_cap * m->stride + 64));
+    KICP_TRY(m->free_ids.reserve((size_t)m->blocks_cap * sizeof(int)));
+    KICP_TRY(m->ctr.reserve(sizeof(int) * C_COUNT + sizeof(PipeState)));
+    KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
+    KICP_HIP(hipMemsetAsync(m->blocks.p, 0, m->blocks.bytes, m->stream));
+    KICP_HIP(hipMemsetAsync(m->ctr.p, 0, m->ctr.bytes, m->stream));
+    KICP_HIP(hipStreamSynchronize(m->stream));
+    m->used_ub = m->bump_ub = 0;
+    return KICP_OK;
+}
+
+// the small PipeState that carries a pose into k_map_link for the standalone map calls
+static PipeState *map_mini_state(kicp_map *m) {
+    return reinterpret_cast<PipeState *>(m->ctr.as<char>() + sizeof(int) * C_COUNT);
+}
+
+static int map_create_on_stream(double voxel_size, double max_distance, unsigned max_points,
+                                int device_id, hipStream_t stream, kicp_map **out) {
+    if (!out) return KICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!(voxel_size > 0.0) || max_points == 0 || max_points > 4096) {
+        set_error("invalid map parameters (voxel_size %g, max_points_per_voxel %u)", voxel_size, max_points);
+        return KICP_ERR_INVALID_ARG;
+    }
+    KICP_TRY(check_device(device_id));
+    kicp_map *m = new (std::nothrow) kicp_map();
+    if (!m) return KICP_ERR_OOM;
+    m->device = device_id;
+    m->voxel_size = voxel_size;
+    m->max_distance = max_distance;
+    m->max_points = max_points;
+    if (stream) {
+        m->stream = stream;
+        m->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete m;
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return KICP_ERR_HIP;
+        }
+    }
+    int s = map_alloc(m);
+    if (s != KICP_OK) {
+        kicp_map_destroy(m);
+        return s;
+    }
+    *out = m;
+    return KICP_OK;
+}
+
+extern "C" {
+
+int kicp_map_create(double voxel_size, double max_distance, unsigned max_points_per_voxel,
+                    int device_id, kicp_map **out) {
+    return map_create_on_stream(voxel_size, max_distance, max_points_per_voxel, device_id, nullptr, out);
+}
+
+int kicp_map_destroy(kicp_map *m) {
+    if (!m) return KICP_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    m->slots.release();
+    m->blocks.release();
+    m->free_ids.release();
+    m->ctr.release();
+    m->pts_in.release();
+    m->world.release();
+    m->slot_of.release();
+    m->next.release();
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return KICP_OK;
+}
+
+int kicp_map_clear(kicp_map *m) {
+    if (!m) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(m->refresh_counters());
+    KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
+    KICP_HIP(hipMemsetAsync(m->blocks.p, 0, (size_t)m->bump_ub * m->stride, m->stream));
+    KICP_HIP(hipMemsetAsync(m->ctr.p, 0, sizeof(int) * C_COUNT, m->stream));
+    KICP_HIP(hipStreamSynchronize(m->stream));
+    m->used_ub = m->bump_ub = 0;
+    return KICP_OK;
+}
+
+int kicp_map_empty(const kicp_map *cm, int *empty) {
+    kicp_map *m = const_cast<kicp_map *>(cm);
+    if (!m || !empty) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(m->refresh_counters());
+    *empty = (m->h_ctr[C_LIVE] == 0);
+    return KICP_OK;
+}
+
+int kicp_map_size(const kicp_map *cm, size_t *n_voxels, size_t *n_points) {
+    kicp_map *m = const_cast<kicp_map *>(cm);
+    if (!m) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(m->refresh_counters());
+    if (n_points) {
+        KICP_HIP(hipMemsetAsync(m->ctr.as<int>() + C_NPTS, 0, sizeof(int), m->stream));
+        launch_map_count_points(m->view(), m->bump_ub, m->stream);
+        KICP_HIP(hipGetLastError());
+        KICP_TRY(m->refresh_counters());
+        *n_points = (size_t)m->h_ctr[C_NPTS];
+    }
+    if (n_voxels) *n_voxels = (size_t)m->h_ctr[C_LIVE];
+    return KICP_OK;
+}
+
+static int map_insert_device(kicp_map *m, const double *d_in, const int *n_ptr, int n_imm,
+                             size_t n_max, const PipeState *state, int use_pose) {
+    // AddPoints on points already in HBM (shared by the standalone calls and the pipeline)
+    if (n_max == 0) return KICP_OK;
+    KICP_TRY(m->ensure_capacity(n_max));
+    KICP_TRY(m->world.reserve(n_max * 3 * sizeof(double)));
+    KICP_TRY(m->slot_of.reserve(n_max * sizeof(int)));
+    KICP_TRY(m->next.reserve(n_max * sizeof(int)));
+    const MapView v = m->view();
+    launch_map_link(v, d_in, n_ptr, n_imm, (int)n_max, state, use_pose, m->world.as<double>(),
+                    m->slot_of.as<int>(), m->next.as<int>(), m->stream);
+    launch_map_apply(v, n_ptr, n_imm, (int)n_max, m->world.as<double>(), m->slot_of.as<int>(),
+                     m->next.as<int>(), m->stream);
+    KICP_HIP(hipGetLastError());
+    m->used_ub += (long)n_max;
+    m->bump_ub += (long)n_max;
+    if (m->bump_ub > m->blocks_cap) m->bump_ub = m->blocks_cap;
+    return KICP_OK;
+}
+
+static int map_upload(kicp_map *m, const double *xyz, size_t n) {
+    if (n > (size_t)0x7FFFFFF0 / 3) {
+        set_error("too many points (%zu)", n);
+        return KICP_ERR_INVALID_ARG;
+    }
+    KICP_TRY(m->pts_in.reserve((n ? n : 1) * 3 * sizeof(double)));
+    if (n) KICP_HIP(hipMemcpyAsync(m->pts_in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    return KICP_OK;
+}
+
+int kicp_map_add_points(kicp_map *m, const double *xyz, size_t n) {
+    if (!m || (!xyz && n)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(map_upload(m, xyz, n));
+    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, nullptr, 0));
+    return m->check_errors();
+}
+
+int kicp_map_remove_far(kicp_map *m, const double origin[3]) {
+    if (!m || !origin) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, m->stream);
+    KICP_HIP(hipGetLastError());
+    return m->check_errors();
+}
+
+int kicp_map_update_origin(kicp_map *m, const double *xyz, size_t n, const double origin[3]) {
+    if (!m || (!xyz && n) || !origin) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(map_upload(m, xyz, n));
+    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, nullptr, 0));
+    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, m->stream);
+    KICP_HIP(hipGetLastError());
+    return m->check_errors();
+}
+
+int kicp_map_update_pose(kicp_map *m, const double *xyz, size_t n, const double pose[16]) {
+    if (!m || (!xyz && n) || !pose) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    SE3 T;
+    if (!se3_from_matrix(pose, T)) {
+        set_error("pose is not a rigid transform (SOPHUS_ENSURE: R not orthogonal or det <= 0)");
+        return KICP_ERR_INVALID_ARG;
+    }
+    PipeState *ms = map_mini_state(m);
+    KICP_HIP(hipMemcpyAsync(&ms->new_pose, &T, sizeof T, hipMemcpyHostToDevice, m->stream));
+    KICP_TRY(map_upload(m, xyz, n));
+    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, ms, 1));
+    launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, m->stream);
+    KICP_HIP(hipGetLastError());
+    return m->check_errors();
+}
+
+int kicp_map_pointcloud(const kicp_map *cm, double *out_xyz, size_t cap, size_t *n_out) {
+    kicp_map *m = const_cast<kicp_map *>(cm);
+    if (!m || !n_out || (!out_xyz && cap)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(m->refresh_counters());
+    const size_t nb = (size_t)m->bump_ub;
+    std::vector<char> host(nb * m->stride);
+    if (nb) {
+        KICP_HIP(hipMemcpyAsync(host.data(), m->blocks.p, nb * m->stride, hipMemcpyDeviceToHost, m->stream));
+        KICP_HIP(hipStreamSynchronize(m->stream));
+    }
+    size_t k = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        const BlockHdr *h = reinterpret_cast<const BlockHdr *>(host.data() + b * m->stride);
+        const double *pts = reinterpret_cast<const double *>(host.data() + b * m->stride + kBlockHeader);
+        for (int i = 0; i < h->count; ++i, ++k)
+            if (k < cap) memcpy(out_xyz + 3 * k, pts + 3 * i, 3 * sizeof(double));
+    }
+    *n_out = k;
+    return KICP_OK;
+}
+
+int kicp_map_closest_neighbor(const kicp_map *cm, const double *q, size_t nq, double *nn, double *dist) {
+    kicp_map *m = const_cast<kicp_map *>(cm);
+    if (!m || ((!q || !nn || !dist) && nq)) return KICP_ERR_INVALID_ARG;
+    if (nq == 0) return KICP_OK;
+    KICP_HIP(hipSetDevice(m->device));
+    KICP_TRY(map_upload(m, q, nq));
+    KICP_TRY(m->world.reserve(nq * 4 * sizeof(double)));
+    double *d_nn = m->world.as<double>();
+    double *d_dist = d_nn + 3 * nq;
+    launch_closest_neighbor(m->view(), m->pts_in.as<double>(), (int)nq, d_nn, d_dist, m->stream);
+    KICP_HIP(hipGetLastError());
+    KICP_HIP(hipMemcpyAsync(nn, d_nn, nq * 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    KICP_HIP(hipMemcpyAsync(dist, d_dist, nq * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    KICP_HIP(hipStreamSynchronize(m->stream));
+    return KICP_OK;
+}
+
+}  // extern "C"
+
+// ==============================================================================================
+// Registration
+// ==============================================================================================
+static void init_state(PipeState &s, double initial_threshold) {
+    memset(&s, 0, sizeof s);
+    s.last_pose = se3_identity();
+    s.last_delta = se3_identity();
+    s.new_pose = se3_identity();
+    s.guess = se3_identity();
+    s.model_sse = initial_threshold * initial_threshold;  // Threshold.cpp:35
+    s.num_samples = 1;
+    s.epoch_base = 1;
+    s.tmin_bits = ~0ull;
+    s.tmax_bits = 0ull;
+}
+
+static constexpr unsigned kSpinLimit = 1u << 21;
+
+extern "C" {
+
+int kicp_registration_create(int max_num_iterations, double convergence_criterion, int max_num_threads,
+                             int device_id, kicp_registration **out) {
+    (void)max_num_threads;
+    if (!out) return KICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    KICP_TRY(check_device(device_id));
+    kicp_registration *r = new (std::nothrow) kicp_registration();
+    if (!r) return KICP_ERR_OOM;
+    r->device = device_id;
+    r->max_iters = max_num_iterations;
+    r->conv = convergence_criterion;
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) {
+        set_error("stream/event creation failed");
+        kicp_registration_destroy(r);
+        return KICP_ERR_HIP;
+    }
+    int s = r->state.reserve(sizeof(PipeState));
+    if (s == KICP_OK) s = r->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
+    if (s != KICP_OK) {
+        kicp_registration_destroy(r);
+        return s;
+    }
+    PipeState st;
+    init_state(st, 0.0);
+    KICP_HIP(hipMemcpyAsync(r->state.p, &st, sizeof st, hipMemcpyHostToDevice, r->stream));
+    KICP_HIP(hipMemsetAsync(r->granules.p, 0, r->granules.bytes, r->stream));
+    KICP_HIP(hipStreamSynchronize(r->stream));
+    *out = r;
+    return KICP_OK;
+}
+
+int kicp_registration_destroy(kicp_registration *r) {
+    if (!r) return KICP_OK;
+    (void)hipSetDevice(r->device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    r->frame.release();
+    r->work.release();
+    r->granules.release();
+    r->state.release();
+    if (r->ev0) (void)hipEventDestroy(r->ev0);
+    if (r->ev1) (void)hipEventDestroy(r->ev1);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+    return KICP_OK;
+}
+
+int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size_t n,
+                             const kicp_map *cmap, const double initial_guess[16],
+                             double max_correspondence_distance, double kernel_scale,
+                             double T_out[16], kicp_icp_stats *stats) {
+    kicp_map *map = const_cast<kicp_map *>(cmap);
+    if (!r || !map || !initial_guess || !T_out || (!frame_xyz && n)) return KICP_ERR_INVALID_ARG;
+    if (map->device != r->device) {
+        set_error("map lives on device %d, registration on device %d", map->device, r->device);
+        return KICP_ERR_INVALID_ARG;
+    }
+    if (n > (size_t)0x7FFFFFF0 / 3) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(r->device));
+    SE3 guess;
+    if (!se3_from_matrix(initial_guess, guess)) {
+        set_error("initial_guess is not a rigid transform (SOPHUS_ENSURE)");
+        return KICP_ERR_INVALID_ARG;
+    }
+    KICP_HIP(hipStreamSynchronize(map->stream));  // the map's own work is done before we read it
+    KICP_TRY(r->frame.reserve((n ? n : 1) * 3 * sizeof(double)));
+    KICP_TRY(r->work.reserve((n ? n : 1) * 3 * sizeof(double)));
+    if (n) KICP_HIP(hipMemcpyAsync(r->frame.p, frame_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, r->stream));
+    PipeState *st = r->state.as<PipeState>();
+    KICP_HIP(hipMemcpyAsync(&st->guess, &guess, sizeof guess, hipMemcpyHostToDevice, r->stream));
+    const int G = choose_icp_blocks((long)n);
+    IcpParams P;
+    memset(&P, 0, sizeof P);
+    P.frame = r->frame.as<double>();
+    P.work = r->work.as<double>();
+    P.n_ptr = nullptr;
+    P.n_imm = (int)n;
+    P.map = map->view();
+    P.state = st;
+    P.pipeline_mode = 0;
+    P.max_dist = max_correspondence_distance;
+    P.kernel_scale = kernel_scale;
+    P.max_iters = r->max_iters;
+    P.conv = r->conv;
+    P.granules = r->granules.as<unsigned long long>();
+    P.spin_limit = kSpinLimit;
+    KICP_HIP(hipEventRecord(r->ev0, r->stream));
+    launch_icp(P, G, r->stream);
+    KICP_HIP(hipGetLastError());
+    KICP_HIP(hipEventRecord(r->ev1, r->stream));
+    PipeState h;
+    KICP_HIP(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, r->stream));
+    KICP_HIP(hipStreamSynchronize(r->stream));
+    if (h.err) {
+        int zero = 0;
+        KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+        return err_bits_to_status(h.err);
+    }
+    se3_matrix(h.new_pose, T_out);
+    if (stats) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r->ev0, r->ev1);
+        stats->iterations = h.icp_iterations;
+        stats->converged = h.icp_converged;
+        stats->n_source = n;
+        stats->n_corr_last = h.icp_ncorr_last;
+        stats->points_examined = h.icp_examined;
+        stats->n_corr_total = h.icp_ncorr_total;
+        stats->kernel_ms = ms;
+    }
+    return KICP_OK;
+}
+
+}  // extern "C"
+
+// ==============================================================================================
+// VoxelDownsample / Preprocess as free functions (temporary HBM buffers per call)
+// ==============================================================================================
+struct ScopedStream {
+    hipStream_t s = nullptr;
+    ~ScopedStream() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+struct ScopedBufs {
+    std::vector<DevBuf *> v;
+    ~ScopedBufs() {
+        for (auto *b : v) b->release();
+    }
+};
+
+static int downsample_device(const double *d_in, const int *n_ptr, int n_imm, int n_max, double voxel,
+                             DevBuf &tab, uint32_t tab_cap, int *slot_of, int *blk_counts, double *d_out,
+                             int *d_nout, int *d_err, bool claim, hipStream_t s) {
+    DsParams P;
+    memset(&P, 0, sizeof P);
+    P.in = d_in;
+    P.n_ptr = n_ptr;
+    P.n_imm = n_imm;
+    P.n_max = n_max;
+    P.voxel = voxel;
+    P.tab = tab.as<DsSlot>();
+    P.mask = tab_cap - 1;
+    P.slot_of = slot_of;
+    P.blk_counts = blk_counts;
+    P.out = d_out;
+    P.n_out = d_nout;
+    P.err = d_err;
+    if (claim) launch_ds_claim(P, s);
+    launch_ds_flags(P, s);
+    launch_ds_scatter(P, s);
+    KICP_HIP(hipGetLastError());
+    return KICP_OK;
+}
+
+static int init_ds_table(DevBuf &tab, uint32_t cap, hipStream_t s) {
+    // key = EMPTY (all ones), minidx = INT_MAX: fill with 0xFF then fix minidx by a pattern fill
+    KICP_TRY(tab.reserve((size_t)cap * sizeof(DsSlot)));
+    std::vector<DsSlot> h(cap);
+    for (auto &e : h) {
+        e.key = kKeyEmpty;
+        e.minidx = 0x7FFFFFFF;
+        e.pad = 0;
+    }
+    KICP_HIP(hipMemcpyAsync(tab.p, h.data(), (size_t)cap * sizeof(DsSlot), hipMemcpyHostToDevice, s));
+    KICP_HIP(hipStreamSynchronize(s));
+    return KICP_OK;
+}
+
+extern "C" {
+
+int kicp_voxel_downsample(const double *xyz, size_t n, double voxel_size, int device_id, double *out_xyz,
+                          size_t *n_out) {
+    if ((!xyz || !out_xyz) && n) return KICP_ERR_INVALID_ARG;
+    if (!n_out || !(voxel_size > 0.0) || n > (size_t)0x7FFFFFF0 / 3) return KICP_ERR_INVALID_ARG;
+    KICP_TRY(check_device(device_id));
+    *n_out = 0;
+    if (n == 0) return KICP_OK;
+    ScopedStream ss;
+    KICP_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    DevBuf in, out, tab, slot_of, counts, misc;
+    ScopedBufs sb;
+    sb.v = {&in, &out, &tab, &slot_of, &counts, &misc};
+    KICP_TRY(in.reserve(n * 3 * sizeof(double)));
+    KICP_TRY(out.reserve(n * 3 * sizeof(double)));
+    KICP_TRY(slot_of.reserve(n * sizeof(int)));
+    KICP_TRY(counts.reserve(((n + 1023) / 1024 + 1) * sizeof(int)));
+    KICP_TRY(misc.reserve(2 * sizeof(int)));
+    const uint32_t cap = next_pow2(2 * n);
+    KICP_TRY(init_ds_table(tab, cap, ss.s));
+    KICP_HIP(hipMemsetAsync(misc.p, 0, 2 * sizeof(int), ss.s));
+    KICP_HIP(hipMemcpyAsync(in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ss.s));
+    KICP_TRY(downsample_device(in.as<double>(), nullptr, (int)n, (int)n, voxel_size, tab, cap, slot_of.as<int>(),
+                               counts.as<int>(), out.as<double>(), misc.as<int>(), misc.as<int>() + 1, true, ss.s));
+    int h[2];
+    KICP_HIP(hipMemcpyAsync(h, misc.p, sizeof h, hipMemcpyDeviceToHost, ss.s));
+    KICP_HIP(hipStreamSynchronize(ss.s));
+    if (h[1]) return err_bits_to_status(h[1]);
+    KICP_HIP(hipMemcpy(out_xyz, out.p, (size_t)h[0] * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    *n_out = (size_t)h[0];
+    return KICP_OK;
+}
+
+int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_t n_ts,
+                    const double relative_motion[16], double max_range, double min_range, int deskew,
+                    int device_id, double *out_xyz, size_t *n_out) {
+    if ((!xyz || !out_xyz) && n) return KICP_ERR_INVALID_ARG;
+    if (!n_out || !relative_motion || n > (size_t)0x7FFFFFF0 / 3) return KICP_ERR_INVALID_ARG;
+    KICP_TRY(check_device(device_id));
+    *n_out = 0;
+    SE3 motion;
+    if (!se3_from_matrix(relative_motion, motion)) {
+        set_error("relative_motion is not a rigid transform (SOPHUS_ENSURE)");
+        return KICP_ERR_INVALID_ARG;
+    }
+    const bool do_deskew = deskew && n_ts > 0 && timestamps;
+    if (do_deskew && n_ts < n) {
+        set_error("timestamps (%zu) shorter than frame (%zu)", n_ts, n);
+        return KICP_ERR_TIMESTAMPS;
+    }
+    if (n == 0) return KICP_OK;
+    ScopedStream ss;
+    KICP_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    DevBuf in, ts, tmp, out, counts, st;
+    ScopedBufs sb;
+    sb.v = {&in, &ts, &tmp, &out, &counts, &st};
+    KICP_TRY(in.reserve(n * 3 * sizeof(double)));
+    KICP_TRY(tmp.reserve(n * 3 * sizeof(double)));
+    KICP_TRY(out.reserve(n * 3 * sizeof(double)));
+    KICP_TRY(counts.reserve(((n + 1023) / 1024 + 1) * sizeof(int)));
+    KICP_TRY(st.reserve(sizeof(PipeState)));
+    PipeState hs;
+    init_state(hs, 0.0);
+    KICP_HIP(hipMemcpyAsync(st.p, &hs, sizeof hs, hipMemcpyHostToDevice, ss.s));
+    KICP_HIP(hipMemcpyAsync(in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ss.s));
+    if (do_deskew) {
+        KICP_TRY(ts.reserve(n_ts * sizeof(double)));
+        KICP_HIP(hipMemcpyAsync(ts.p, timestamps, n_ts * sizeof(double), hipMemcpyHostToDevice, ss.s));
+        launch_ts_minmax(ts.as<double>(), (int)n_ts, st.as<PipeState>(), ss.s);
+    }
+    PreParams P;
+    memset(&P, 0, sizeof P);
+    P.xyz = in.as<double>();
+    P.ts = do_deskew ? ts.as<double>() : nullptr;
+    P.n = (int)n;
+    P.deskew = do_deskew ? 1 : 0;
+    P.use_state_motion = 0;
+    P.motion = motion;
+    P.state = st.as<PipeState>();
+    P.max_range = max_range;
+    P.min_range = min_range;
+    P.tmp = tmp.as<double>();
+    P.blk_counts = counts.as<int>();
+    P.out = out.as<double>();
+    P.n_out = &st.as<PipeState>()->n_pre;
+    P.ds_tab = nullptr;
+    P.err = &st.as<PipeState>()->err;
+    launch_pre_flags(P, ss.s);
+    launch_pre_scatter(P, ss.s);
+    KICP_HIP(hipGetLastError());
+    KICP_HIP(hipMemcpyAsync(&hs, st.p, sizeof hs, hipMemcpyDeviceToHost, ss.s));
+    KICP_HIP(hipStreamSynchronize(ss.s));
+    KICP_HIP(hipMemcpy(out_xyz, out.p, (size_t)hs.n_pre * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    *n_out = (size_t)hs.n_pre;
+    return KICP_OK;
+}
+
+}  // extern "C"
+
+// ==============================================================================================
+// pipeline::KissICP
+// ==============================================================================================
+struct FrameRecord {
+    PipeState st;
+    int map_ctr[C_COUNT];
+    uint64_t n_raw;
+};
+
+struct kicp_pipeline {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    kicp_config cfg;
+    kicp_map *map = nullptr;
+    DevBuf state, raw, ts, tmp, pre, fd, src, work, slot1, slot2, tab1, tab2, counts, granules;
+    size_t cap_points = 0;
+    uint32_t tab_cap = 0;
+    // per-frame records land in pinned host memory, one slot per frame in flight
+    static constexpr int kRing = 256;
+    FrameRecord *ring = nullptr;  // hipHostMalloc
+    hipEvent_t ev[kRing][2];
+    bool ev_ok = false;
+    int in_flight = 0;
+    uint64_t frames_done = 0;
+    FrameRecord last;  // most recent completed frame
+    bool have_last = false;
+    long n_src_hint = 0;
+    // ICP timing accumulators
+    double icp_ms = 0.0;
+    uint64_t icp_launches = 0, icp_iters = 0, icp_bytes = 0;
+    std::vector<double> pending_poses;  // row-major 4x4 per frame completed by the last sync
+};
+
+static int pipe_reserve(kicp_pipeline *p, size_t n) {
+    if (n <= p->cap_points) return KICP_OK;
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    size_t cap = n + n / 8 + 1024;
+    const size_t b3 = cap * 3 * sizeof(double);
+    KICP_TRY(p->raw.reserve(b3));
+    KICP_TRY(p->ts.reserve(cap * sizeof(double)));
+    KICP_TRY(p->tmp.reserve(b3));
+    // pre/fd/src keep their contents (last frame's outputs) across a growth
+    KICP_TRY(p->pre.reserve(b3, true, p->stream));
+    KICP_TRY(p->fd.reserve(b3, true, p->stream));
+    KICP_TRY(p->src.reserve(b3, true, p->stream));
+    KICP_TRY(p->work.reserve(b3));
+    KICP_TRY(p->slot1.reserve(cap * sizeof(int)));
+    KICP_TRY(p->slot2.reserve(cap * sizeof(int)));
+    KICP_TRY(p->counts.reserve(3 * ((cap + 1023) / 1024 + 1) * sizeof(int)));
+    const uint32_t tcap = next_pow2(2 * cap);
+    KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
+    KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
+    p->tab_cap = tcap;
+    p->cap_points = cap;
+    return KICP_OK;
+}
+
+static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const double *d_ts, size_t n_ts) {
+    const kicp_config &c = p->cfg;
+    const bool do_deskew = c.deskew && n_ts > 0 && d_ts;  // Preprocessing.cpp:59
+    if (do_deskew && n_ts < n) {
+        set_error("timestamps (%zu) shorter than frame (%zu)", n_ts, n);
+        return KICP_ERR_TIMESTAMPS;
+    }
+    if (n > (size_t)0x7FFFFFF0 / 3) return KICP_ERR_INVALID_ARG;
+    if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(kicp_pipeline_sync(p));
+    KICP_TRY(pipe_reserve(p, n));
+    kicp_map *m = p->map;
+    KICP_TRY(m->ensure_capacity(n));
+    hipStream_t s = p->stream;
+    PipeState *st = p->state.as<PipeState>();
+    const int nblk = (int)((p->cap_points + 1023) / 1024 + 1);
+    int *cnt0 = p->counts.as<int>(), *cnt1 = cnt0 + nblk, *cnt2 = cnt1 + nblk;
+    const int n_i = (int)n;
+
+    // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
+    if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, st, s);
+    PreParams P;
+    memset(&P, 0, sizeof P);
+    P.xyz = d_xyz;
+    P.ts = do_deskew ? d_ts : nullptr;
+    P.n = n_i;
+    P.deskew = do_deskew ? 1 : 0;
+    P.use_state_motion = 1;
+    P.motion = se3_identity();
+    P.state = st;
+    P.max_range = c.max_range;
+    P.min_range = c.min_range;
+    P.tmp = p->tmp.as<double>();
+    P.blk_counts = cnt0;
+    P.out = p->pre.as<double>();
+    P.n_out = &st->n_pre;
+    P.ds_tab = p->tab1.as<DsSlot>();
+    P.ds_mask = p->tab_cap - 1;
+    P.ds_voxel = c.voxel_size * 0.5;  // KissICP.cpp:72
+    P.ds_slot_of = p->slot1.as<int>();
+    P.err = &st->err;
+    launch_pre_flags(P, s);
+    launch_pre_scatter(P, s);
+
+    // --- Voxelize (KissICP.cpp:70-75) ---------------------------------------------------------
+    DsParams D1;
+    memset(&D1, 0, sizeof D1);
+    D1.in = p->pre.as<double>();
+    D1.n_ptr = &st->n_pre;
+    D1.n_max = n_i;
+    D1.voxel = c.voxel_size * 0.5;
+    D1.tab = p->tab1.as<DsSlot>();
+    D1.mask = p->tab_cap - 1;
+    D1.slot_of = p->slot1.as<int>();
+    D1.blk_counts = cnt1;
+    D1.out = p->fd.as<double>();
+    D1.n_out = &st->n_fd;
+    D1.next_tab = p->tab2.as<DsSlot>();
+    D1.next_mask = p->tab_cap - 1;
+    D1.next_voxel = c.voxel_size * 1.5;  // KissICP.cpp:73
+    D1.next_slot_of = p->slot2.as<int>();
+    D1.err = &st->err;
+    launch_ds_flags(D1, s);
+    launch_ds_scatter(D1, s);
+    DsParams D2;
+    memset(&D2, 0, sizeof D2);
+    D2.in = p->fd.as<double>();
+    D2.n_ptr = &st->n_fd;
+    D2.n_max = n_i;
+    D2.voxel = c.voxel_size * 1.5;
+    D2.tab = p->tab2.as<DsSlot>();
+    D2.mask = p->tab_cap - 1;
+    D2.slot_of = p->slot2.as<int>();
+    D2.blk_counts = cnt2;
+    D2.out = p->src.as<double>();
+    D2.n_out = &st->n_src;
+    D2.err = &st->err;
+    launch_ds_flags(D2, s);
+    launch_ds_scatter(D2, s);
+
+    // --- AlignPointsToMap + threshold / pose bookkeeping (KissICP.cpp:44-63) ---------------------
+    const long hint = p->n_src_hint > 0 ? p->n_src_hint : (long)(n / 48 + 64);
+    const int G = choose_icp_blocks(hint);
+    IcpParams I;
+    memset(&I, 0, sizeof I);
+    I.frame = p->src.as<double>();
+    I.work = p->work.as<double>();
+    I.n_ptr = &st->n_src;
+    I.map = m->view();
+    I.state = st;
+    I.pipeline_mode = 1;
+    I.min_motion_th = c.min_motion_th;
+    I.max_iters = c.max_num_iterations;
+    I.conv = c.convergence_criterion;
+    I.granules = p->granules.as<unsigned long long>();
+    I.spin_limit = kSpinLimit;
+    const int slot = p->in_flight;
+    const bool timing = options().icp_timing != 0 && p->ev_ok;
+    if (timing) KICP_HIP(hipEventRecord(p->ev[slot][0], s));
+    launch_icp(I, G, s);
+    if (timing) KICP_HIP(hipEventRecord(p->ev[slot][1], s));
+
+    // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
+    KICP_TRY(m->world.reserve(p->cap_points * 3 * sizeof(double)));
+    KICP_TRY(m->slot_of.reserve(p->cap_points * sizeof(int)));
+    KICP_TRY(m->next.reserve(p->cap_points * sizeof(int)));
+    const MapView v = m->view();
+    launch_map_link(v, p->fd.as<double>(), &st->n_fd, 0, n_i, st, 1, m->world.as<double>(),
+                    m->slot_of.as<int>(), m->next.as<int>(), s);
+    launch_map_apply(v, &st->n_fd, 0, n_i, m->world.as<double>(), m->slot_of.as<int>(), m->next.as<int>(), s);
+    m->used_ub += (long)n;
+    m->bump_ub += (long)n;
+    if (m->bump_ub > m->blocks_cap) m->bump_ub = m->blocks_cap;
+    launch_map_prune(v, m->bump_ub, st, 1, nullptr, st, s);
+    KICP_HIP(hipGetLastError());
+
+    // --- frame record -> pinned host ring ---------------------------------------------------------
+    FrameRecord *rec = p->ring + slot;
+    rec->n_raw = n;
+    KICP_HIP(hipMemcpyAsync(&rec->st, st, sizeof(PipeState), hipMemcpyDeviceToHost, s));
+    KICP_HIP(hipMemcpyAsync(rec->map_ctr, m->ctr.p, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, s));
+    p->in_flight++;
+    return KICP_OK;
+}
+
+extern "C" {
+
+int kicp_config_default(kicp_config *c) {
+    if (!c) return KICP_ERR_INVALID_ARG;
+    c->voxel_size = 1.0;
+    c->max_range = 100.0;
+    c->min_range = 0.0;
+    c->max_points_per_voxel = 20;
+    c->min_motion_th = 0.1;
+    c->initial_threshold = 2.0;
+    c->max_num_iterations = 500;
+    c->convergence_criterion = 0.0001;
+    c->max_num_threads = 0;
+    c->deskew = 1;
+    return KICP_OK;
+}
+
+int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **out) {
+    if (!cfg || !out) return KICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!(cfg->voxel_size > 0.0) || cfg->max_points_per_voxel <= 0 || cfg->max_num_iterations < 0) {
+        set_error("invalid KISSConfig");
+        return KICP_ERR_INVALID_ARG;
+    }
+    KICP_TRY(check_device(device_id));
+    kicp_pipeline *p = new (std::nothrow) kicp_pipeline();
+    if (!p) return KICP_ERR_OOM;
+    p->device = device_id;
+    p->cfg = *cfg;
+    int s = KICP_OK;
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) s = KICP_ERR_HIP;
+    if (s == KICP_OK) {
+        p->ev_ok = true;
+        for (int i = 0; i < kicp_pipeline::kRing && p->ev_ok; ++i)
+            for (int j = 0; j < 2; ++j)
+                if (hipEventCreate(&p->ev[i][j]) != hipSuccess) p->ev_ok = false;
+    }
+    if (s == KICP_OK && hipHostMalloc((void **)&p->ring, sizeof(FrameRecord) * kicp_pipeline::kRing) != hipSuccess)
+        s = KICP_ERR_OOM;
+    // KissICP.hpp:62-68: local_map_(voxel_size, max_range, max_points_per_voxel)
+    if (s == KICP_OK)
+        s = map_create_on_stream(cfg->voxel_size, cfg->max_range, (unsigned)cfg->max_points_per_voxel, device_id,
+                                 p->stream, &p->map);
+    if (s == KICP_OK) s = p->state.reserve(sizeof(PipeState));
+    if (s == KICP_OK) s = p->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
+    if (s != KICP_OK) {
+        if (s == KICP_ERR_HIP) set_error("pipeline resource creation failed");
+        kicp_pipeline_destroy(p);
+        return s;
+    }
+    PipeState st;
+    init_state(st, cfg->initial_threshold);
+    KICP_HIP(hipMemcpyAsync(p->state.p, &st, sizeof st, hipMemcpyHostToDevice, p->stream));
+    KICP_HIP(hipMemsetAsync(p->granules.p, 0, p->granules.bytes, p->stream));
+    KICP_HIP(hipStreamSynchronize(p->stream));
+    memset(&p->last, 0, sizeof p->last);
+    p->last.st = st;
+    *out = p;
+    return KICP_OK;
+}
+
+int kicp_pipeline_destroy(kicp_pipeline *p) {
+    if (!p) return KICP_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->map) kicp_map_destroy(p->map);
+    for (DevBuf *b : {&p->state, &p->raw, &p->ts, &p->tmp, &p->pre, &p->fd, &p->src, &p->work, &p->slot1,
+                      &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules})
+        b->release();
+    if (p->ev_ok)
+        for (int i = 0; i < kicp_pipeline::kRing; ++i)
+            for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
+    if (p->ring) (void)hipHostFree(p->ring);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return KICP_OK;
+}
+
+int kicp_pipeline_sync(kicp_pipeline *p) {
+    if (!p) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    KICP_HIP(hipStreamSynchronize(p->stream));
+    int err_bits = 0;
+    p->pending_poses.clear();
+    for (int i = 0; i < p->in_flight; ++i) {
+        const FrameRecord &r = p->ring[i];
+        err_bits |= r.st.err | r.map_ctr[C_ERR];
+        if (options().icp_timing && p->ev_ok) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p->ev[i][0], p->ev[i][1]) == hipSuccess) p->icp_ms += ms;
+        }
+        p->icp_launches++;
+        p->icp_iters += (uint64_t)r.st.icp_iterations;
+        // algorithmic bytes of AlignPointsToMap:
+        //   per iteration N_src*(24+24) + N_src*27*16 + E*24 + 336
+        p->icp_bytes += (uint64_t)r.st.icp_iterations * ((uint64_t)r.st.n_src * (48 + 27 * 16) + 336) +
+                        r.st.icp_examined * 24;
+        double T[16];
+        se3_matrix(r.st.last_pose, T);
+        p->pending_poses.insert(p->pending_poses.end(), T, T + 16);
+    }
+    if (p->in_flight) {
+        p->last = p->ring[p->in_flight - 1];
+        p->have_last = true;
+        p->frames_done += (uint64_t)p->in_flight;
+        p->n_src_hint = p->last.st.n_src;
+        kicp_map *m = p->map;
+        memcpy(m->h_ctr, p->last.map_ctr, sizeof m->h_ctr);
+        m->used_ub = m->h_ctr[C_USED];
+        m->bump_ub = m->h_ctr[C_BUMP] < m->blocks_cap ? m->h_ctr[C_BUMP] : m->blocks_cap;
+    }
+    p->in_flight = 0;
+    if (err_bits) {
+        PipeState *st = p->state.as<PipeState>();
+        int zero = 0;
+        KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+        KICP_HIP(hipMemcpy(p->map->ctr.as<int>() + C_ERR, &zero, sizeof zero, hipMemcpyHostToDevice));
+        return err_bits_to_status(err_bits);
+    }
+    return KICP_OK;
+}
+
+int kicp_pipeline_register_frame_device(kicp_pipeline *p, const double *d_xyz, size_t n, const double *d_ts,
+                                        size_t n_ts) {
+    if (!p || (!d_xyz && n)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    return pipe_enqueue(p, d_xyz, n, d_ts, n_ts);
+}
+
+int kicp_pipeline_register_frame(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps,
+                                 size_t n_ts) {
+    if (!p || (!xyz && n)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    KICP_TRY(pipe_reserve(p, n > n_ts ? n : n_ts));
+    if (n) KICP_HIP(hipMemcpyAsync(p->raw.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    const bool have_ts = timestamps && n_ts > 0;
+    if (have_ts)
+        KICP_HIP(hipMemcpyAsync(p->ts.p, timestamps, n_ts * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    KICP_TRY(pipe_enqueue(p, p->raw.as<double>(), n, have_ts ? p->ts.as<double>() : nullptr, have_ts ? n_ts : 0));
+    return kicp_pipeline_sync(p);
+}
+
+static int pipe_state_get(kicp_pipeline *p, PipeState &h) {
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    h = p->last.st;
+    return KICP_OK;
+}
+
+int kicp_pipeline_pose(kicp_pipeline *p, double T[16]) {
+    if (!p || !T) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    se3_matrix(h.last_pose, T);
+    return KICP_OK;
+}
+
+int kicp_pipeline_delta(kicp_pipeline *p, double T[16]) {
+    if (!p || !T) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    se3_matrix(h.last_delta, T);
+    return KICP_OK;
+}
+
+static int pipe_set_se3(kicp_pipeline *p, const double T[16], bool delta) {
+    if (!p || !T) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    SE3 x;
+    if (!se3_from_matrix(T, x)) {
+        set_error("not a rigid transform (SOPHUS_ENSURE)");
+        return KICP_ERR_INVALID_ARG;
+    }
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    PipeState *st = p->state.as<PipeState>();
+    KICP_HIP(hipMemcpy(delta ? &st->last_delta : &st->last_pose, &x, sizeof x, hipMemcpyHostToDevice));
+    (delta ? p->last.st.last_delta : p->last.st.last_pose) = x;
+    return KICP_OK;
+}
+int kicp_pipeline_set_pose(kicp_pipeline *p, const double T[16]) { return pipe_set_se3(p, T, false); }
+int kicp_pipeline_set_delta(kicp_pipeline *p, const double T[16]) { return pipe_set_se3(p, T, true); }
+
+int kicp_pipeline_map(kicp_pipeline *p, kicp_map **map) {
+    if (!p || !map) return KICP_ERR_INVALID_ARG;
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    *map = p->map;
+    return KICP_OK;
+}
+
+int kicp_pipeline_output_size(kicp_pipeline *p, int which, size_t *n) {
+    if (!p || !n || which < 0 || which > 2) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    if (!p->have_last) {
+        *n = 0;
+        return KICP_OK;
+    }
+    *n = (size_t)(which == KICP_OUT_PREPROCESSED ? h.n_pre : which == KICP_OUT_SOURCE ? h.n_src : h.n_fd);
+    return KICP_OK;
+}
+
+int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, size_t *n) {
+    if (!p || !n || (!out && cap)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    size_t cnt = 0;
+    KICP_TRY(kicp_pipeline_output_size(p, which, &cnt));
+    *n = cnt;
+    const size_t c = cnt < cap ? cnt : cap;
+    if (c) {
+        const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src : p->fd;
+        KICP_HIP(hipMemcpyAsync(out, b.p, c * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        KICP_HIP(hipStreamSynchronize(p->stream));
+    }
+    return KICP_OK;
+}
+
+int kicp_pipeline_voxelize(kicp_pipeline *p, const double *xyz, size_t n, double *source_xyz, size_t *n_source,
+                           double *fd_xyz, size_t *n_fd) {
+    if (!p || !n_source || !n_fd) return KICP_ERR_INVALID_ARG;
+    // KissICP.cpp:70-75
+    KICP_TRY(kicp_voxel_downsample(xyz, n, p->cfg.voxel_size * 0.5, p->device, fd_xyz, n_fd));
+    return kicp_voxel_downsample(fd_xyz, *n_fd, p->cfg.voxel_size * 1.5, p->device, source_xyz, n_source);
+}
+
+int kicp_pipeline_last_stats(kicp_pipeline *p, kicp_frame_stats *s) {
+    if (!p || !s) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    memset(s, 0, sizeof *s);
+    s->n_raw = p->last.n_raw;
+    s->n_preprocessed = (uint64_t)h.n_pre;
+    s->n_frame_downsample = (uint64_t)h.n_fd;
+    s->n_source = (uint64_t)h.n_src;
+    s->map_voxels = (uint64_t)p->last.map_ctr[C_LIVE];
+    s->sigma = h.sigma;
+    s->icp.iterations = h.icp_iterations;
+    s->icp.converged = h.icp_converged;
+    s->icp.n_source = (uint64_t)h.n_src;
+    s->icp.n_corr_last = h.icp_ncorr_last;
+    s->icp.points_examined = h.icp_examined;
+    s->icp.n_corr_total = h.icp_ncorr_total;
+    return KICP_OK;
+}
+
+int kicp_pipeline_icp_timing(kicp_pipeline *p, double *total_ms, uint64_t *launches, uint64_t *iterations,
+                             uint64_t *bytes, int reset) {
+    if (!p) return KICP_ERR_INVALID_ARG;
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    if (total_ms) *total_ms = p->icp_ms;
+    if (launches) *launches = p->icp_launches;
+    if (iterations) *iterations = p->icp_iters;
+    if (bytes) *bytes = p->icp_bytes;
+    if (reset) {
+        p->icp_ms = 0.0;
+        p->icp_launches = p->icp_iters = p->icp_bytes = 0;
+    }
+    return KICP_OK;
+}
+
+int kicp_pipeline_stream(kicp_pipeline *p, void **stream) {
+    if (!p || !stream) return KICP_ERR_INVALID_ARG;
+    *stream = (void *)p->stream;
+    return KICP_OK;
+}
+
+/* poses of the frames completed by the most recent kicp_pipeline_sync (row-major 4x4 each) */
+int kicp_pipeline_synced_poses(kicp_pipeline *p, double *T_out, size_t cap_frames, size_t *n_frames) {
+    if (!p || !n_frames) return KICP_ERR_INVALID_ARG;
+    const size_t nf = p->pending_poses.size() / 16;
+    *n_frames = nf;
+    const size_t c = nf < cap_frames ? nf : cap_frames;
+    if (c && T_out) memcpy(T_out, p->pending_poses.data(), c * 16 * sizeof(double));
+    return KICP_OK;
+}
+
+// ---- misc ---------------------------------------------------------------------------------------
+const char *kicp_status_string(int s) {
+    switch (s) {
+        case KICP_OK: return "ok";
+        case KICP_ERR_INVALID_ARG: return "invalid argument";
+        case KICP_ERR_HIP: return "HIP runtime error";
+        case KICP_ERR_OOM: return "out of memory";
+        case KICP_ERR_CAPACITY: return "device table capacity exceeded";
+        case KICP_ERR_RANGE: return "voxel coordinate out of range";
+        case KICP_ERR_TIMEOUT: return "in-kernel wait timed out";
+        case KICP_ERR_NO_DEVICE: return "no gfx950 device";
+        case KICP_ERR_TIMESTAMPS: return "timestamps shorter than frame";
+        default: return "unknown status";
+    }
+}
+const char *kicp_last_error(void) { return get_error(); }
+int kicp_version(int *major, int *minor) {
+    if (major) *major = KICP_VERSION_MAJOR;
+    if (minor) *minor = KICP_VERSION_MINOR;
+    return KICP_OK;
+}
+int kicp_device_count(int *count) {
+    if (!count) return KICP_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return KICP_OK;
+}
+int kicp_device_name(int device_id, char *buf, size_t len) {
+    if (!buf || !len) return KICP_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    KICP_HIP(hipGetDeviceProperties(&prop, device_id));
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return KICP_OK;
+}
+int kicp_set_option(const char *name, long value) {
+    if (!name) return KICP_ERR_INVALID_ARG;
+    if (!strcmp(name, "icp_blocks")) {
+        if (value < 0 || value > kIcpMaxBlocks) return KICP_ERR_INVALID_ARG;
+        options().icp_blocks = value;
+    } else if (!strcmp(name, "icp_timing")) {
+        options().icp_timing = value;
+    } else {
+        set_error("unknown option '%s'", name);
+        return KICP_ERR_INVALID_ARG;
+    }
+    return KICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// kicp_internal.hpp -- device data layout and host-side objects of libkicp (not installed).
+//
+// HBM layout
+//   Voxel map (kiss_icp::VoxelHashMap, core/VoxelHashMap.hpp:38-57)
+//     slots[C]   : 16-byte open-addressed slots {u64 packed voxel key, i32 block id, i32 list
+//                  head}; C a power of two; linear probing; EMPTY / TOMBSTONE sentinels.  One
+//                  probe = one aligned 16-byte load.
+//     blocks[B]  : fixed-stride voxel blocks, stride = roundup(32 + 24*max_points, 128) bytes
+//                  (512 B for the default 20 points = four 128-byte lines):
+//                  {u64 key, i32 count, i32 slot, 16 B pad, points[max_points] as xyz f64}.
+//                  count == 0 marks a free block.  A voxel's points are contiguous, so a hit
+//                  costs one burst instead of the reference's std::vector pointer chase.
+//     free_ids[] : stack of recycled block ids;  ctr[] : device counters.
+//   Frame clouds : row-major xyz f64 (the reference's std::vector<Eigen::Vector3d> layout).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "kicp_math.hpp"
+#include "../../include/kicp.h"
+
+namespace kicp {
+
+// ---- device-visible structures -------------------------------------------------------------
+struct alignas(16) Slot {
+    unsigned long long key;
+    int block;  // -1 until a block is attached
+    int head;   // per-frame insertion list head, -1 when idle
+};
+
+struct alignas(16) DsSlot {  // scratch table of VoxelDownsample
+    unsigned long long key;
+    int minidx;
+    int pad;
+};
+
+constexpr int kBlockHeader = 32;  // bytes before the first point of a voxel block
+struct BlockHdr {
+    unsigned long long key;
+    int count;
+    int slot;
+};
+
+enum MapCtr {
+    C_BUMP = 0,   // blocks ever carved from the pool (high-water mark)
+    C_NFREE = 1,  // entries on the free stack
+    C_LIVE = 2,   // live voxels
+    C_TOMB = 3,   // tombstoned slots
+    C_USED = 4,   // slots ever claimed since the last rehash (live + tombstones)
+    C_ERR = 5,    // sticky error bits (ErrBits)
+    C_NPTS = 6,   // scratch: point count of the last pointcloud query
+    C_COUNT = 8
+};
+
+enum ErrBits { E_RANGE = 1, E_TABLE_FULL = 2, E_POOL_FULL = 4, E_TIMEOUT = 8 };
+
+struct MapView {
+    Slot *slots;
+    uint32_t mask;
+    char *blocks;
+    int stride;
+    int max_points;
+    int blocks_cap;
+    int *ctr;
+    int *free_ids;
+    double voxel_size;
+    double max_distance;
+    double map_resolution;  // sqrt(voxel_size^2 / max_points)  VoxelHashMap.cpp:98
+};
+
+__device__ __forceinline__ BlockHdr *block_hdr(const MapView &m, int b) {
+    return reinterpret_cast<BlockHdr *>(m.blocks + (size_t)b * m.stride);
+}
+__device__ __forceinline__ double *block_pts(const MapView &m, int b) {
+    return reinterpret_cast<double *>(m.blocks + (size_t)b * m.stride + kBlockHeader);
+}
+
+// Per-pipeline state that never leaves the device between frames
+// (pipeline/KissICP.hpp:87-95 + core/Threshold.hpp:44-50).
+struct PipeState {
+    SE3 last_pose;
+    SE3 last_delta;
+    SE3 new_pose;  // result of the frame being processed
+    SE3 guess;     // initial guess used by the frame being processed
+    double model_sse;
+    double sigma;  // threshold used by the frame being processed
+    int num_samples;
+    unsigned epoch_base;  // tag base of the in-kernel exchange, advanced by every ICP launch
+    unsigned long long tmin_bits, tmax_bits;  // timestamp min/max as order-preserving u64
+    // per-frame result block (copied D2H at sync)
+    int n_raw, n_pre, n_fd, n_src;
+    int icp_iterations, icp_converged;
+    unsigned long long icp_examined, icp_ncorr_last, icp_ncorr_total;
+    int err;
+    int pad;
+};
+
+constexpr int kIcpSums = 18;  // 16 normal-equation scalars + correspondence count + examined count
+constexpr int kIcpThreads = 256;
+constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 probe lanes)
+constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;
+constexpr int kIcpMaxBlocks = 256;
+
+struct IcpParams {
+    const double *frame;  // N x 3 source points in the sensor frame
+    double *work;         // N x 3 transformed source, private to the launch
+    const int *n_ptr;     // device count (pipeline) or nullptr
+    int n_imm;            // count when n_ptr == nullptr
+    MapView map;
+    PipeState *state;       // guess / sigma / result live here
+    int pipeline_mode;      // 1: compute guess+sigma from state and do the frame bookkeeping
+    double max_dist, kernel_scale;  // used when pipeline_mode == 0
+    double min_motion_th;           // AdaptiveThreshold::min_motion_threshold_ (pipeline mode)
+    int max_iters;
+    double conv;
+    unsigned long long *granules;  // [2][gridDim.x][kIcpSums * 2] tagged 8-byte words
+    unsigned spin_limit;
+};
+
+// ---- host-side objects ------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define KICP_HIP(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ::kicp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                    \
+            return (_e == hipErrorOutOfMemory) ? KICP_ERR_OOM : KICP_ERR_HIP;               \
+        }                                                                                   \
+    } while (0)
+
+#define KICP_TRY(expr)                  \
+    do {                                \
+        int _s = (expr);                \
+        if (_s != KICP_OK) return _s;   \
+    } while (0)
+
+struct Options {
+    long icp_blocks = 0;
+    long icp_timing = 1;
+};
+Options &options();
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need, bool keep = false, hipStream_t s = nullptr);
+    void release();
+    template <class T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+int check_device(int device_id);
+
+}  // namespace kicp
+
+// The opaque handles of the C-ABI
+struct kicp_map {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    double voxel_size = 1.0, max_distance = 100.0;
+    unsigned max_points = 20;
+    int stride = 512;
+    kicp::DevBuf slots, blocks, free_ids, ctr;
+    uint32_t slot_cap = 0;
+    int blocks_cap = 0;
+    // host-side upper bounds of the device counters (exact after refresh_counters)
+    long used_ub = 0, bump_ub = 0;
+    int h_ctr[kicp::C_COUNT] = {0};
+    // scratch of add_points
+    kicp::DevBuf pts_in, world, slot_of, next;
+    kicp::MapView view() const;
+    int ensure_capacity(size_t incoming_points);
+    int refresh_counters();  // D2H of ctr (synchronises the stream)
+    int check_errors();
+};
+
+struct kicp_registration {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_iters = 500;
+    double conv = 1e-4;
+    kicp::DevBuf frame, work, granules, state;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};

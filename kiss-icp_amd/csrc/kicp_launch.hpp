@@ -1,0 +1,72 @@
+// kicp_launch.hpp -- kernel parameter blocks and launch wrappers (kicp_kernels.hip <-> kicp_api.hip)
+#pragma once
+
+#include "kicp_internal.hpp"
+
+namespace kicp {
+
+// Preprocessor::Preprocess (core/Preprocessing.cpp:55-95) + fused first-downsample claim
+struct PreParams {
+    const double *xyz;  // raw scan
+    const double *ts;   // timestamps or nullptr
+    int n;              // raw point count (host value: the scan just arrived)
+    int deskew;         // deskew_ && !timestamps.empty()
+    int use_state_motion;
+    SE3 motion;         // relative_motion when !use_state_motion
+    PipeState *state;   // last_delta (pipeline) and timestamp min/max words
+    double max_range, min_range;
+    double *tmp;        // n x 3 deskewed cloud
+    int *blk_counts;    // one per 1024-thread workgroup
+    double *out;        // cropped cloud
+    int *n_out;         // device count of `out`
+    // fused stage A of VoxelDownsample(out, ds_voxel); ds_tab == nullptr disables it
+    DsSlot *ds_tab;
+    uint32_t ds_mask;
+    double ds_voxel;
+    int *ds_slot_of;
+    int *err;
+};
+
+// VoxelDownsample (core/VoxelUtils.cpp:7-21)
+struct DsParams {
+    const double *in;
+    const int *n_ptr;  // device count of `in`, or nullptr -> n_imm
+    int n_imm;
+    int n_max;         // host upper bound of the count (sizes the grid)
+    double voxel;
+    DsSlot *tab;
+    uint32_t mask;
+    int *slot_of;
+    int *blk_counts;
+    double *out;
+    int *n_out;
+    // fused stage A of the next VoxelDownsample(out, next_voxel); next_tab == nullptr disables it
+    DsSlot *next_tab;
+    uint32_t next_mask;
+    double next_voxel;
+    int *next_slot_of;
+    int *err;
+};
+
+size_t icp_smem_bytes(int G);
+size_t icp_granule_words(int G);
+void launch_icp(const IcpParams &P, int G, hipStream_t s);
+void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
+                             hipStream_t s);
+void launch_ts_minmax(const double *ts, int n_ts, PipeState *st, hipStream_t s);
+void launch_pre_flags(const PreParams &P, hipStream_t s);
+void launch_pre_scatter(const PreParams &P, hipStream_t s);
+void launch_ds_claim(const DsParams &P, hipStream_t s);
+void launch_ds_flags(const DsParams &P, hipStream_t s);
+void launch_ds_scatter(const DsParams &P, hipStream_t s);
+void launch_map_link(const MapView &m, const double *in, const int *n_ptr, int n_imm, int n_max,
+                     const PipeState *state, int use_pose, double *world, int *slot_of, int *next,
+                     hipStream_t s);
+void launch_map_apply(const MapView &m, const int *n_ptr, int n_imm, int n_max, const double *world,
+                      const int *slot_of, const int *next, hipStream_t s);
+void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
+                      const double origin[3], PipeState *reset_state, hipStream_t s);
+void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s);
+void launch_map_count_points(const MapView &m, long bump_ub, hipStream_t s);
+
+}  // namespace kicp

@@ -1,0 +1,231 @@
+"""Synthetic spinning-LiDAR sequences (no real datasets are available offline).
+
+Stands in for the reference's dataloaders; the *layout* of what they return is kept:
+  * KITTI-like   (python/kiss_icp/datasets/kitti.py:56-69): (N,3) float32 values widened to
+    float64, timestamps = empty array  -> deskew is skipped (Preprocessing.cpp:59).
+  * MulRan-like  (python/kiss_icp/datasets/mulran.py:46-58): per-point timestamps
+    floor(arange(H*W)/H)/W (column-major sweep), scans are motion-distorted so that deskewing
+    is meaningful.
+
+Scene: ground plane z = 0 plus axis-aligned boxes (buildings, cars, poles, "vegetation" with
+large range jitter) scattered along a curved road.  The sensor drives forward `step` metres
+and yaws `yaw_deg` degrees per frame.  Everything is seeded and pure numpy, so the same
+sequence is produced on any machine.
+"""
+import numpy as np
+
+
+def _rotz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+class SyntheticLidar:
+    def __init__(
+        self,
+        beams=64,
+        azimuth_steps=2048,
+        elev_deg=(2.0, -24.8),
+        sensor_height=1.73,
+        step=1.0,
+        yaw_deg=0.5,
+        n_frames=200,
+        seed=0,
+        range_noise=0.02,
+        sensor_max_range=120.0,
+        timestamps=False,
+        motion_distortion=False,
+        density=1.0,
+    ):
+        self.H, self.W = beams, azimuth_steps
+        self.height = sensor_height
+        self.step, self.yaw = step, np.deg2rad(yaw_deg)
+        self.n_frames = n_frames
+        self.seed = seed
+        self.range_noise = range_noise
+        self.sensor_max_range = sensor_max_range
+        self.with_timestamps = timestamps
+        self.motion_distortion = motion_distortion
+        el = np.deg2rad(np.linspace(elev_deg[0], elev_deg[1], beams))
+        az = -np.arange(azimuth_steps) * (2.0 * np.pi / azimuth_steps)  # clockwise sweep
+        # column-major sweep: consecutive H points share one azimuth column
+        azg, elg = np.meshgrid(az, el, indexing="ij")
+        self.dirs = np.stack(
+            [np.cos(elg) * np.cos(azg), np.cos(elg) * np.sin(azg), np.sin(elg)], axis=-1
+        ).reshape(-1, 3)
+        self.col = np.repeat(np.arange(azimuth_steps), beams)
+        self.stamps = np.floor(np.arange(beams * azimuth_steps) / beams) / azimuth_steps
+        self._build_scene(density)
+
+    # ---- trajectory ------------------------------------------------------------------
+    def _path(self, s):
+        """pose (R, t) of the vehicle after driving arc length s (metres)"""
+        if abs(self.yaw) < 1e-12:
+            return np.eye(3), np.array([s, 0.0, self.height])
+        radius = self.step / self.yaw
+        th = s / radius
+        t = np.array([radius * np.sin(th), radius * (1.0 - np.cos(th)), self.height])
+        return _rotz(th), t
+
+    def gt_pose(self, k):
+        R, t = self._path(k * self.step)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        return T
+
+    # ---- scene -----------------------------------------------------------------------
+    def _build_scene(self, density):
+        """Street scene along the road: building facades, parked cars, poles, tree crowns and
+        bushes ("vegetation": boxes whose returns get large range jitter)."""
+        rng = np.random.default_rng(1000003 * (self.seed + 1))
+        total = self.step * self.n_frames
+        lo, hi, veg = [], [], []
+
+        def add(s, lateral, half, zc, is_veg):
+            R, t = self._path(s)
+            c = t + R @ np.array([0.0, lateral, 0.0])
+            c[2] = zc
+            lo.append(c - half)
+            hi.append(c + half)
+            veg.append(is_veg)
+
+        s = -80.0
+        while s < total + 80.0:
+            for side in (1.0, -1.0):
+                if rng.random() < 0.5 * density:  # facade segment
+                    front, depth, h = rng.uniform(4, 7), rng.uniform(3, 6), rng.uniform(2.5, 7)
+                    add(s + rng.uniform(-2, 2), side * (rng.uniform(9, 16) + depth), np.array([front, depth, h]), h, False)
+                if rng.random() < 0.8 * density:  # second row / back buildings
+                    front, depth, h = rng.uniform(4, 8), rng.uniform(4, 8), rng.uniform(4, 10)
+                    add(s + rng.uniform(-4, 4), side * rng.uniform(32, 55), np.array([front, depth, h]), h, False)
+                for _ in range(3):
+                    if rng.random() < 0.8 * density:  # far-field buildings (seen by the near-horizontal beams)
+                        front, depth, h = rng.uniform(5, 12), rng.uniform(5, 12), rng.uniform(4, 12)
+                        add(s + rng.uniform(-6, 6), side * rng.uniform(55, 100), np.array([front, depth, h]), h, False)
+                for ds in (0.0, 6.0):
+                    if rng.random() < 0.45 * density:  # parked car
+                        add(s + ds + rng.uniform(-1, 1), side * rng.uniform(3.2, 4.5), np.array([2.1, 0.9, 0.75]), 0.75, False)
+                if rng.random() < 0.5 * density:  # pole / trunk + crown
+                    lat = side * rng.uniform(5.5, 8.0)
+                    sp = s + rng.uniform(-5, 5)
+                    add(sp, lat, np.array([0.15, 0.15, 3.0]), 3.0, False)
+                    if rng.random() < 0.7:
+                        r = rng.uniform(1.2, 2.5)
+                        add(sp, lat, np.array([r, r, rng.uniform(1.0, 2.0)]), rng.uniform(4.0, 6.0), True)
+                for _ in range(5):
+                    if rng.random() < 0.6 * density:  # bush / hedge
+                        add(s + rng.uniform(-6, 6), side * rng.uniform(6, 60), np.array([rng.uniform(0.5, 2.5), rng.uniform(0.5, 2.5), rng.uniform(0.4, 1.2)]), rng.uniform(0.4, 1.2), True)
+            s += 12.0
+        self.box_lo, self.box_hi = np.array(lo), np.array(hi)
+        self.box_veg = np.array(veg)
+
+    # ---- ray casting -----------------------------------------------------------------
+    def _cast(self, origins, dirs, R0, t0):
+        """nearest hit range along each ray + vegetation flag; inf where nothing is hit.
+        Rays are stored column-major (H consecutive rays share an azimuth column), so each box
+        is only tested against the contiguous slice(s) of columns it subtends from (R0, t0)."""
+        H, W = self.H, self.W
+        dz = dirs[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            best = np.where(dz < 0.0, -origins[:, 2] / dz, np.inf)
+            inv = 1.0 / dirs
+        veg = np.zeros(len(dirs), dtype=bool)
+        bc = 0.5 * (self.box_lo + self.box_hi)
+        near = np.where(np.linalg.norm(bc[:, :2] - t0[:2], axis=1) < self.sensor_max_range + 15.0)[0]
+        margin = 3 + (int(0.02 * W) if self.motion_distortion else 0)
+        for b in near:
+            lo, hi = self.box_lo[b], self.box_hi[b]
+            corners = np.array([[lo[0], lo[1]], [lo[0], hi[1]], [hi[0], lo[1]], [hi[0], hi[1]]]) - t0[:2]
+            if (lo[0] - 1.0 <= t0[0] <= hi[0] + 1.0) and (lo[1] - 1.0 <= t0[1] <= hi[1] + 1.0):
+                spans = [(0, W)]
+            else:
+                loc = corners @ R0[:2, :2]  # into the sensor frame (R0^T applied to rows)
+                ang = np.arctan2(loc[:, 1], loc[:, 0])
+                rel = (ang - ang[0] + np.pi) % (2 * np.pi) - np.pi
+                a_lo, a_hi = ang[0] + rel.min(), ang[0] + rel.max()
+                # column index c <-> azimuth -c*2pi/W
+                c_lo = int(np.floor(-a_hi * W / (2 * np.pi))) - margin
+                n_col = int(np.ceil(-a_lo * W / (2 * np.pi))) + margin + 1 - c_lo
+                if n_col >= W:
+                    spans = [(0, W)]
+                else:
+                    c_lo %= W
+                    spans = [(c_lo, min(c_lo + n_col, W))]
+                    if c_lo + n_col > W:
+                        spans.append((0, c_lo + n_col - W))
+            for (c0, c1) in spans:
+                sl = slice(c0 * H, c1 * H)
+                o, iv = origins[sl], inv[sl]
+                with np.errstate(invalid="ignore"):
+                    t1 = (lo - o) * iv
+                    t2 = (hi - o) * iv
+                tn = np.minimum(t1, t2).max(axis=1)
+                tf = np.maximum(t1, t2).min(axis=1)
+                hit = (tn <= tf) & (tn > 0.0) & (tn < best[sl])
+                best[sl] = np.where(hit, tn, best[sl])
+                veg[sl] = np.where(hit, self.box_veg[b], veg[sl])
+        return best, veg
+
+    def scan(self, k):
+        """(points (N,3) f64 in the sensor frame, timestamps (N,) or empty) for frame k"""
+        rng = np.random.default_rng(7919 * (self.seed + 1) + k)
+        if self.motion_distortion:
+            # pose of the sensor while column c is fired: between frame k-1 (s=0) and k (s=1)
+            frac = (np.arange(self.W) + 0.0) / self.W
+            Rs = np.empty((self.W, 3, 3))
+            ts = np.empty((self.W, 3))
+            for c in range(self.W):
+                Rs[c], ts[c] = self._path((k - 1.0 + frac[c]) * self.step)
+            Rr = Rs[self.col]
+            dirs_w = np.einsum("nij,nj->ni", Rr, self.dirs)
+            origins = ts[self.col]
+        else:
+            R, t = self._path(k * self.step)
+            dirs_w = self.dirs @ R.T
+            origins = np.broadcast_to(t, dirs_w.shape)
+        R0, t0 = self._path(k * self.step)
+        rng_hit, veg = self._cast(np.ascontiguousarray(origins), dirs_w, R0, t0)
+        ok = np.isfinite(rng_hit) & (rng_hit < self.sensor_max_range)
+        noise = rng.normal(0.0, self.range_noise, size=len(rng_hit))
+        noise = np.where(veg, rng.normal(0.0, 0.3, size=len(rng_hit)), noise)
+        r = rng_hit + noise
+        ok &= r > 0.5
+        pts = self.dirs[ok] * r[ok, None]  # sensor frame at firing time
+        pts = pts.astype(np.float32).astype(np.float64)  # loaders read float32 files
+        if self.with_timestamps:
+            return pts, self.stamps[ok].copy()
+        return pts, np.array([])
+
+    def __len__(self):
+        return self.n_frames
+
+    def __getitem__(self, k):
+        return self.scan(k)
+
+
+def kitti_like(seed=0, n_frames=200, beams=64, azimuth_steps=2048, **kw):
+    """BASELINE config 2: 64 x 2048 = 131 072 rays, no timestamps"""
+    return SyntheticLidar(beams=beams, azimuth_steps=azimuth_steps, elev_deg=(2.0, -24.8), seed=seed,
+                          n_frames=n_frames, timestamps=False, motion_distortion=False, **kw)
+
+
+def mulran_like(seed=1, n_frames=200, beams=64, azimuth_steps=1024, **kw):
+    """BASELINE config 3: 64 x 1024 = 65 536 rays, timestamps + motion distortion"""
+    return SyntheticLidar(beams=beams, azimuth_steps=azimuth_steps, elev_deg=(16.6, -16.6), seed=seed,
+                          n_frames=n_frames, timestamps=True, motion_distortion=True, **kw)
+
+
+def livox_like(seed=2, n_frames=50, beams=128, azimuth_steps=8192, **kw):
+    """BASELINE config 5: 128 x 8192 = 1 048 576 rays (use voxel_size 0.1)"""
+    return SyntheticLidar(beams=beams, azimuth_steps=azimuth_steps, elev_deg=(2.0, -24.8), seed=seed,
+                          n_frames=n_frames, timestamps=False, motion_distortion=False, **kw)
+
+
+def plane_pair(seed=42, n=5000, noise=0.01):
+    """BASELINE config 1 building block: n points on the floor z=0, (x,y) in [-20,20]^2, and n on
+    the wall x = 10, y in [-20,20], z in [0,8]; N(0, noise^2) added."""
+    rng = np.random.default_rng(seed)
+    floor = np.stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), np.zeros(n)], axis=1)
+    wall = np.stack([np.full(n, 10.0), rng.uniform(-20, 20, n), rng.uniform(0, 8, n)], axis=1)
+    pts = np.concatenate([floor, wall]) + rng.normal(0.0, noise, size=(2 * n, 3))
+    return pts

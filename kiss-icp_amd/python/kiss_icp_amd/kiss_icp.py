@@ -1,0 +1,176 @@
+"""KissICP odometry pipelines with the reference's Python interface
+(python/kiss_icp/kiss_icp.py:33-80: register_frame(frame, timestamps) -> (frame, source),
+last_pose, last_delta, local_map, voxelize).
+
+* ``KissICP``          the fused device pipeline (kicp_pipeline_*, include/kicp.h), a restatement
+                       of pipeline::KissICP::RegisterFrame (cpp/kiss_icp/pipeline/KissICP.cpp:35-68)
+                       in which every stage is a HIP kernel and all state stays in HBM.
+* ``KissICPComposed``  the reference's own Python composition, stage by stage over the standalone
+                       C-ABI calls (host round trip between stages) -- slower, used to show that
+                       the pieces behave like the reference's pybind classes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi
+from .config import KISSConfig
+from .mapping import VoxelHashMap, get_voxel_hash_map
+from .preprocess import get_preprocessor
+from .registration import get_registration
+from .threshold import get_threshold_estimator
+from .voxelization import voxel_down_sample
+
+
+def _c_config(config: KISSConfig) -> _cabi.Config:
+    c = _cabi.Config()
+    _cabi.check(_cabi.lib().kicp_config_default(C.byref(c)))
+    c.voxel_size = config.mapping.voxel_size
+    c.max_range = config.data.max_range
+    c.min_range = config.data.min_range
+    c.max_points_per_voxel = config.mapping.max_points_per_voxel
+    c.min_motion_th = config.adaptive_threshold.min_motion_th
+    c.initial_threshold = config.adaptive_threshold.initial_threshold
+    c.max_num_iterations = config.registration.max_num_iterations
+    c.convergence_criterion = config.registration.convergence_criterion
+    c.max_num_threads = config.registration.max_num_threads
+    c.deskew = int(bool(config.data.deskew))
+    return c
+
+
+class KissICP:
+    def __init__(self, config: KISSConfig = None, device_id: int = 0):
+        self.config = config if config is not None else KISSConfig()
+        if self.config.adaptive_threshold.fixed_threshold is not None:
+            raise ValueError("fixed_threshold is a Python-only option of the reference; use KissICPComposed")
+        cc = _c_config(self.config)
+        h = C.c_void_p()
+        _cabi.check(_cabi.lib().kicp_pipeline_create(C.byref(cc), device_id, C.byref(h)))
+        self._h = h
+        self.device_id = device_id
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _cabi.lib().kicp_pipeline_destroy(self._h)
+            self._h = None
+
+    # -- reference interface -------------------------------------------------------------------
+    def register_frame(self, frame, timestamps=()):
+        pts = _cabi.points(frame)
+        ts = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64).ravel())
+        st = _cabi.lib().kicp_pipeline_register_frame(self._h, _cabi.ptr(pts), len(pts), _cabi.ptr(ts) if len(ts) else None, len(ts))
+        if st == 8:
+            raise IndexError(_cabi.lib().kicp_last_error().decode())
+        _cabi.check(st)
+        return self.output(0), self.output(1)
+
+    def voxelize(self, iframe):
+        frame_downsample = voxel_down_sample(iframe, self.config.mapping.voxel_size * 0.5, self.device_id)
+        source = voxel_down_sample(frame_downsample, self.config.mapping.voxel_size * 1.5, self.device_id)
+        return source, frame_downsample
+
+    @property
+    def last_pose(self):
+        T = np.empty((4, 4))
+        _cabi.check(_cabi.lib().kicp_pipeline_pose(self._h, _cabi.dptr(T)))
+        return T
+
+    @last_pose.setter
+    def last_pose(self, T):
+        _cabi.check(_cabi.lib().kicp_pipeline_set_pose(self._h, _cabi.dptr(_cabi.mat4(T))))
+
+    @property
+    def last_delta(self):
+        T = np.empty((4, 4))
+        _cabi.check(_cabi.lib().kicp_pipeline_delta(self._h, _cabi.dptr(T)))
+        return T
+
+    @last_delta.setter
+    def last_delta(self, T):
+        _cabi.check(_cabi.lib().kicp_pipeline_set_delta(self._h, _cabi.dptr(_cabi.mat4(T))))
+
+    @property
+    def local_map(self):
+        h = C.c_void_p()
+        _cabi.check(_cabi.lib().kicp_pipeline_map(self._h, C.byref(h)))
+        return VoxelHashMap(0, 0, 0, _borrowed=h)
+
+    # -- device-side extras ---------------------------------------------------------------------
+    def output(self, which):
+        n = C.c_size_t(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_output_size(self._h, which, C.byref(n)))
+        out = np.empty((n.value, 3))
+        _cabi.check(_cabi.lib().kicp_pipeline_output(self._h, which, _cabi.ptr(out), n.value, C.byref(n)))
+        return out
+
+    def register_frame_device(self, d_xyz_ptr, n, d_ts_ptr=None, n_ts=0):
+        """enqueue a frame whose points already live in this GPU's HBM (raw device pointers);
+        returns immediately, call sync() to wait"""
+        st = _cabi.lib().kicp_pipeline_register_frame_device(self._h, d_xyz_ptr, n, d_ts_ptr, n_ts)
+        if st == 8:
+            raise IndexError(_cabi.lib().kicp_last_error().decode())
+        _cabi.check(st)
+
+    def sync(self):
+        _cabi.check(_cabi.lib().kicp_pipeline_sync(self._h))
+
+    def synced_poses(self):
+        n = C.c_size_t(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_synced_poses(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 4, 4))
+        _cabi.check(_cabi.lib().kicp_pipeline_synced_poses(self._h, _cabi.ptr(out), n.value, C.byref(n)))
+        return out
+
+    def last_stats(self):
+        s = _cabi.FrameStats()
+        _cabi.check(_cabi.lib().kicp_pipeline_last_stats(self._h, C.byref(s)))
+        return s.asdict()
+
+    def icp_timing(self, reset=False):
+        ms = C.c_double(0)
+        launches, iters, nbytes = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_icp_timing(self._h, C.byref(ms), C.byref(launches), C.byref(iters), C.byref(nbytes), int(reset)))
+        return {"total_ms": ms.value, "launches": launches.value, "iterations": iters.value, "algorithmic_bytes": nbytes.value}
+
+    def stream(self):
+        s = C.c_void_p()
+        _cabi.check(_cabi.lib().kicp_pipeline_stream(self._h, C.byref(s)))
+        return s.value
+
+
+class KissICPComposed:
+    """python/kiss_icp/kiss_icp.py:33-80, line for line in behaviour, over our wrappers"""
+
+    def __init__(self, config: KISSConfig = None, device_id: int = 0):
+        self.last_pose = np.eye(4)
+        self.last_delta = np.eye(4)
+        self.config = config if config is not None else KISSConfig()
+        self.adaptive_threshold = get_threshold_estimator(self.config)
+        self.preprocessor = get_preprocessor(self.config, device_id)
+        self.registration = get_registration(self.config, device_id)
+        self.local_map = get_voxel_hash_map(self.config, device_id)
+        self.device_id = device_id
+
+    def register_frame(self, frame, timestamps=()):
+        frame = self.preprocessor.preprocess(frame, np.asarray(timestamps, dtype=np.float64), self.last_delta)
+        source, frame_downsample = self.voxelize(frame)
+        sigma = self.adaptive_threshold.get_threshold()
+        initial_guess = self.last_pose @ self.last_delta
+        new_pose = self.registration.align_points_to_map(
+            points=source,
+            voxel_map=self.local_map,
+            initial_guess=initial_guess,
+            max_correspondance_distance=3 * sigma,
+            kernel=sigma,
+        )
+        model_deviation = np.linalg.inv(initial_guess) @ new_pose
+        self.adaptive_threshold.update_model_deviation(model_deviation)
+        self.local_map.update(frame_downsample, new_pose)
+        self.last_delta = np.linalg.inv(self.last_pose) @ new_pose
+        self.last_pose = new_pose
+        return frame, source
+
+    def voxelize(self, iframe):
+        frame_downsample = voxel_down_sample(iframe, self.config.mapping.voxel_size * 0.5, self.device_id)
+        source = voxel_down_sample(frame_downsample, self.config.mapping.voxel_size * 1.5, self.device_id)
+        return source, frame_downsample

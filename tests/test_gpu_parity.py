@@ -1,0 +1,349 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes), against the CPU oracle on the
+same seeded inputs.  Index/selection work must agree exactly; poses within the tolerance of
+BASELINE.json's north_star (1e-4 m / 1e-4 rad) -- we assert a much tighter 1e-7."""
+import numpy as np
+import pytest
+
+from helpers import make_pose, pose_error, random_cloud, sort_rows
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4  # north_star tolerance
+POSE_TOL_RAD = 1e-4
+TIGHT = 1e-7  # what we actually hold
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    oracle.lib()
+    return oracle
+
+
+def test_device_is_gfx950(gpu):
+    from kiss_icp_amd import _cabi
+
+    assert "gfx950" in _cabi.device_name(0)
+
+
+# ---- VoxelDownsample ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,voxel", [(0, 0.5), (1, 0.5), (1000, 0.5), (50000, 0.5), (50000, 1.5), (131072, 0.05)])
+def test_voxel_downsample_bit_exact(gpu, O, n, voxel):
+    from kiss_icp_amd.voxelization import voxel_down_sample
+
+    rng = np.random.default_rng(n + 7)
+    pts = random_cloud(rng, n)
+    got = voxel_down_sample(pts, voxel)
+    want = O.voxel_down_sample(pts, voxel)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)  # same points, same (ascending index) order
+
+
+def test_voxel_downsample_duplicates_and_boundaries(gpu, O):
+    from kiss_icp_amd.voxelization import voxel_down_sample
+
+    pts = np.array([[0.0, 0.0, 0.0], [-0.0, 0.0, 0.0], [-1e-12, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, 0.5, 0.5],
+                    [1.0, 1.0, 1.0], [0.999999999, 0.0, 0.0], [-0.5, -0.5, -0.5], [2.0, -2.0, 2.0]])
+    for v in (0.5, 1.0, 1.5):
+        assert np.array_equal(voxel_down_sample(pts, v), O.voxel_down_sample(pts, v))
+
+
+def test_voxel_out_of_range_is_loud(gpu):
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.voxelization import voxel_down_sample
+
+    pts = np.array([[0.0, 0.0, 0.0], [3.0e6, 0.0, 0.0]])
+    with pytest.raises(_cabi.KicpError) as e:
+        voxel_down_sample(pts, 1.0)
+    assert e.value.status == 5
+
+
+# ---- Preprocess ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("deskew", [False, True])
+def test_preprocess(gpu, O, deskew):
+    from kiss_icp_amd.preprocess import Preprocessor
+
+    rng = np.random.default_rng(3)
+    n = 40000
+    pts = random_cloud(rng, n, extent=130.0, z_extent=10.0)
+    ts = rng.uniform(0.0, 0.1, n)
+    motion = make_pose((0.9, 0.05, -0.01), (0.002, -0.001, 0.01))
+    got = Preprocessor(100.0, 2.0, deskew, 0).preprocess(pts, ts, motion)
+    want = O.Preprocessor(100.0, 2.0, deskew, 0).preprocess(pts, ts, motion)
+    assert got.shape == want.shape
+    if deskew:
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)  # sin/cos/atan2 differ in the last ulp
+    else:
+        assert np.array_equal(got, want)
+
+
+def test_preprocess_empty_timestamps_skips_deskew(gpu, O):
+    from kiss_icp_amd.preprocess import Preprocessor
+
+    pts = random_cloud(np.random.default_rng(4), 5000, extent=150.0)
+    got = Preprocessor(100.0, 0.0, True, 0).preprocess(pts, np.array([]), make_pose((1, 0, 0)))
+    want = O.Preprocessor(100.0, 0.0, True, 0).preprocess(pts, np.array([]), make_pose((1, 0, 0)))
+    assert np.array_equal(got, want)
+
+
+def test_preprocess_short_timestamps_raises(gpu):
+    from kiss_icp_amd.preprocess import Preprocessor
+
+    pts = random_cloud(np.random.default_rng(5), 100)
+    with pytest.raises(IndexError):
+        Preprocessor(100.0, 0.0, True, 0).preprocess(pts, np.zeros(10), np.eye(4))
+
+
+# ---- VoxelHashMap ----------------------------------------------------------------------------------
+def _maps(O, voxel=1.0, max_dist=100.0, mp=20):
+    from kiss_icp_amd.mapping import VoxelHashMap
+
+    return VoxelHashMap(voxel, max_dist, mp), O.VoxelHashMap(voxel, max_dist, mp)
+
+
+def test_map_add_points_same_content(gpu, O):
+    rng = np.random.default_rng(11)
+    g, o = _maps(O)
+    assert g.empty() and o.empty()
+    for k in range(4):
+        pts = random_cloud(rng, 20000, extent=25.0, z_extent=3.0)
+        g.add_points(pts)
+        o.add_points(pts)
+        assert g.num_voxels() == o.num_voxels()
+        assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud()))
+    assert not g.empty()
+
+
+def test_map_full_voxels_and_spacing_rule(gpu, O):
+    # many points in few voxels: exercises the 20-point cap and the sqrt(v^2/20) spacing rule,
+    # whose outcome depends on the arrival order
+    rng = np.random.default_rng(12)
+    g, o = _maps(O)
+    pts = rng.uniform(0.0, 3.0, size=(30000, 3))
+    g.add_points(pts)
+    o.add_points(pts)
+    assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud()))
+    g2, o2 = _maps(O, voxel=0.5, mp=3)
+    g2.add_points(pts)
+    o2.add_points(pts)
+    assert np.array_equal(sort_rows(g2.point_cloud()), sort_rows(o2.point_cloud()))
+
+
+def test_map_update_and_prune(gpu, O):
+    rng = np.random.default_rng(13)
+    g, o = _maps(O, max_dist=30.0)
+    for k in range(6):
+        pts = random_cloud(rng, 8000, extent=28.0, z_extent=2.0)
+        T = make_pose((4.0 * k, 0.5 * k, 0.0), (0, 0, 0.05 * k))
+        g.update(pts, T)
+        o.update(pts, T)
+        assert g.num_voxels() == o.num_voxels()
+        gp, op = sort_rows(g.point_cloud()), sort_rows(o.point_cloud())
+        assert gp.shape == op.shape
+        np.testing.assert_allclose(gp, op, rtol=0, atol=1e-12)
+    # origin overload + explicit prune
+    g.update(pts, np.array([100.0, 0.0, 0.0]))
+    o.update(pts, np.array([100.0, 0.0, 0.0]))
+    assert g.num_voxels() == o.num_voxels()
+    g.remove_far_away_points(np.array([1e4, 0, 0]))
+    assert g.empty()
+    g.add_points(pts)  # tombstoned table still works
+    o.clear()
+    o.add_points(pts)
+    assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud()))
+    g.clear()
+    assert g.empty() and len(g.point_cloud()) == 0
+
+
+def test_closest_neighbor_exact(gpu, O):
+    rng = np.random.default_rng(14)
+    g, o = _maps(O)
+    pts = random_cloud(rng, 60000, extent=20.0, z_extent=3.0)
+    g.add_points(pts)
+    o.add_points(pts)
+    q = random_cloud(rng, 3000, extent=24.0, z_extent=5.0)
+    nn, dist = g.closest_neighbor(q)
+    for i in range(len(q)):
+        onn, od = o.closest_neighbor(q[i])
+        assert np.array_equal(nn[i], onn), i
+        assert dist[i] == od, i
+    # empty neighbourhood convention: zero vector, DBL_MAX
+    nn, dist = g.closest_neighbor(np.array([[500.0, 500.0, 500.0]]))
+    assert np.array_equal(nn[0], np.zeros(3)) and dist[0] == np.finfo(np.float64).max
+
+
+# ---- Registration ------------------------------------------------------------------------------------
+def _scene(rng, n=12000):
+    floor = np.stack([rng.uniform(-25, 25, n), rng.uniform(-25, 25, n), rng.normal(0, 0.01, n)], axis=1)
+    wall1 = np.stack([np.full(n // 2, 12.0) + rng.normal(0, 0.01, n // 2), rng.uniform(-25, 25, n // 2), rng.uniform(0, 6, n // 2)], axis=1)
+    wall2 = np.stack([rng.uniform(-25, 25, n // 2), np.full(n // 2, -9.0) + rng.normal(0, 0.01, n // 2), rng.uniform(0, 6, n // 2)], axis=1)
+    return np.concatenate([floor, wall1, wall2])
+
+
+@pytest.mark.parametrize("blocks", [0, 1, 7, 64, 256])
+def test_align_points_to_map_matches_oracle(gpu, O, blocks):
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.registration import Registration
+
+    _cabi.set_option("icp_blocks", blocks)
+    try:
+        rng = np.random.default_rng(21)
+        g, o = _maps(O)
+        world = _scene(rng)
+        g.add_points(world)
+        o.add_points(world)
+        T_true = make_pose((0.35, -0.2, 0.05), (0.004, -0.003, 0.02))
+        src_world = _scene(np.random.default_rng(22), 3000)
+        src = (np.linalg.inv(T_true) @ np.c_[src_world, np.ones(len(src_world))].T).T[:, :3]
+        guess = make_pose((0.1, 0.0, 0.0))
+        reg_g, reg_o = Registration(500, 1e-4), O.Registration(500, 1e-4)
+        Tg = reg_g.align_points_to_map(src, g, guess, 3.0, 1.0)
+        To = reg_o.align_points_to_map(src, o, guess, 3.0, 1.0)
+        dt, dr = pose_error(To, Tg)
+        assert dt < TIGHT and dr < TIGHT, (dt, dr)
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+        assert reg_g.last_stats["iterations"] == reg_o.last_stats["iterations"]
+        assert reg_g.last_stats["n_corr_last"] == reg_o.last_stats["n_corr_last"]
+        assert reg_g.last_stats["points_examined"] == reg_o.last_stats["points_examined"]
+        # it actually registered: close to the true pose in the observable directions
+        assert pose_error(T_true, Tg)[0] < 0.05
+        # determinism: a second run is bitwise identical
+        Tg2 = reg_g.align_points_to_map(src, g, guess, 3.0, 1.0)
+        assert np.array_equal(Tg, Tg2)
+    finally:
+        _cabi.set_option("icp_blocks", 0)
+
+
+def test_align_degenerate_cases(gpu, O):
+    from kiss_icp_amd.registration import Registration
+
+    g, o = _maps(O)
+    reg = Registration(500, 1e-4)
+    guess = make_pose((1.0, 2.0, 3.0), (0.1, 0.2, 0.3))
+    src = random_cloud(np.random.default_rng(1), 500)
+    # empty map -> initial guess (Registration.cpp:143)
+    T = reg.align_points_to_map(src, g, guess, 3.0, 1.0)
+    np.testing.assert_allclose(T, guess, atol=1e-15)
+    assert reg.last_stats["iterations"] == 0
+    # no correspondence within the threshold -> dx = 0 -> guess, one iteration
+    g.add_points(np.array([[1000.0, 1000.0, 1000.0]]))
+    o.add_points(np.array([[1000.0, 1000.0, 1000.0]]))
+    T = reg.align_points_to_map(src, g, guess, 3.0, 1.0)
+    To = O.Registration(500, 1e-4).align_points_to_map(src, o, guess, 3.0, 1.0)
+    np.testing.assert_allclose(T, To, atol=1e-15)
+    assert reg.last_stats["iterations"] == 1
+    # empty source
+    T = reg.align_points_to_map(np.zeros((0, 3)), g, guess, 3.0, 1.0)
+    np.testing.assert_allclose(T, guess, atol=1e-15)
+    # non-rigid guess -> loud error (SOPHUS_ENSURE in the reference)
+    from kiss_icp_amd import _cabi
+
+    with pytest.raises(_cabi.KicpError):
+        reg.align_points_to_map(src, g, np.diag([2.0, 1, 1, 1]), 3.0, 1.0)
+
+
+def test_max_iterations_respected(gpu, O):
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(31)
+    g, o = _maps(O)
+    world = _scene(rng, 6000)
+    g.add_points(world)
+    o.add_points(world)
+    src = _scene(np.random.default_rng(32), 1500)
+    guess = make_pose((0.8, 0.5, 0.0), (0, 0, 0.05))
+    for iters in (1, 3):
+        rg, ro = Registration(iters, 1e-9), O.Registration(iters, 1e-9)
+        Tg = rg.align_points_to_map(src, g, guess, 3.0, 1.0)
+        To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
+        assert rg.last_stats["iterations"] == iters == ro.last_stats["iterations"]
+        dt, dr = pose_error(To, Tg)
+        assert dt < TIGHT and dr < TIGHT
+
+
+# ---- pipeline (RegisterFrame) over synthetic LiDAR sequences -------------------------------------------
+def _run_sequence(O, ds, n_frames, deskew, composed=False, **cfg):
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.kiss_icp import KissICP, KissICPComposed
+
+    config = load_config(deskew=deskew, **cfg)
+    kg = (KissICPComposed if composed else KissICP)(config)
+    ko = O.KissICP(deskew=int(deskew), **{("voxel_size" if k == "voxel_size" else k): v for k, v in cfg.items()})
+    worst = (0.0, 0.0)
+    for i in range(n_frames):
+        pts, ts = ds[i]
+        fg, sg = kg.register_frame(pts, ts)
+        fo, so = ko.register_frame(pts, ts)
+        assert fg.shape == fo.shape and sg.shape == so.shape, i
+        if deskew and len(ts):
+            np.testing.assert_allclose(fg, fo, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(sg, so, rtol=0, atol=1e-9)
+        else:
+            assert np.array_equal(fg, fo) and np.array_equal(sg, so), i
+        dt, dr = pose_error(ko.last_pose, kg.last_pose)
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (i, dt, dr)
+    return kg, ko, worst
+
+
+def test_pipeline_kitti_like_sequence(gpu, O):
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=0, n_frames=12, beams=32, azimuth_steps=512)
+    kg, ko, worst = _run_sequence(O, ds, 12, deskew=False)
+    assert worst[0] < TIGHT and worst[1] < TIGHT, worst
+    assert kg.local_map.num_voxels() == ko.local_map.num_voxels()
+    np.testing.assert_allclose(sort_rows(kg.local_map.point_cloud()), sort_rows(ko.local_map.point_cloud()), rtol=0, atol=1e-9)
+    sg, so = kg.last_stats(), ko.last_stats()
+    assert sg["icp"]["iterations"] == so["iterations"]
+    assert abs(sg["sigma"] - so["sigma"]) < 1e-9
+    np.testing.assert_allclose(kg.last_delta, ko.last_delta, atol=1e-9)
+
+
+def test_pipeline_mulran_like_sequence_with_deskew(gpu, O):
+    from kiss_icp_amd.datasets import mulran_like
+
+    ds = mulran_like(seed=1, n_frames=10, beams=32, azimuth_steps=512)
+    kg, ko, worst = _run_sequence(O, ds, 10, deskew=True)
+    assert worst[0] < TIGHT and worst[1] < TIGHT, worst
+
+
+def test_pipeline_composed_matches_too(gpu, O):
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=3, n_frames=6, beams=32, azimuth_steps=512)
+    kg, ko, worst = _run_sequence(O, ds, 6, deskew=False, composed=True)
+    assert worst[0] < 1e-6 and worst[1] < 1e-6, worst  # the Python composition round-trips poses through 4x4 matrices
+
+
+def test_pipeline_full_size_scan(gpu, O):
+    """BASELINE config 2 size: 64 x 2048 rays (~130k points) for a few frames"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=0, n_frames=5)
+    kg, ko, worst = _run_sequence(O, ds, 5, deskew=False)
+    assert worst[0] < TIGHT and worst[1] < TIGHT, worst
+    assert kg.last_stats()["n_raw"] > 120000
+
+
+def test_pipeline_async_device_frames_match_sync(gpu, O):
+    """frames already in HBM, enqueued back-to-back without host synchronisation, give the same
+    trajectory as the synchronous host-buffer path"""
+    import torch
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.datasets import kitti_like
+    from kiss_icp_amd.kiss_icp import KissICP
+
+    ds = kitti_like(seed=5, n_frames=8, beams=32, azimuth_steps=512)
+    scans = [ds[i][0] for i in range(8)]
+    ka, ks = KissICP(load_config(deskew=False)), KissICP(load_config(deskew=False))
+    dev = [torch.from_numpy(s).cuda() for s in scans]
+    torch.cuda.synchronize()
+    for d in dev:
+        ka.register_frame_device(d.data_ptr(), d.shape[0])
+    ka.sync()
+    poses_async = ka.synced_poses()
+    for i, s in enumerate(scans):
+        ks.register_frame(s)
+        assert np.array_equal(ks.last_pose, poses_async[i]), i
