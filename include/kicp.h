@@ -205,6 +205,16 @@ int kicp_pipeline_icp_timing(kicp_pipeline *p, double *total_ms, uint64_t *launc
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-memory helpers for hosts without a HIP binding of their own (cgo / JNI / ctypes): enough
+ * to stage scans in HBM for kicp_pipeline_register_frame_device.  Plain hipMalloc / hipMemcpy.
+ * ---------------------------------------------------------------------------------------- */
+int kicp_device_alloc(int device_id, size_t bytes, void **d_ptr);
+int kicp_device_free(int device_id, void *d_ptr);
+int kicp_device_upload(int device_id, void *d_dst, const void *h_src, size_t bytes);
+int kicp_device_download(int device_id, void *h_dst, const void *d_src, size_t bytes);
+int kicp_device_synchronize(int device_id);
+
+/* ------------------------------------------------------------------------------------------
  * tuning knobs (process-wide; read when a handle is created).  Unknown names are an error.
  *   "icp_blocks"      workgroups of the persistent ICP kernel (0 = choose from N_src)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)

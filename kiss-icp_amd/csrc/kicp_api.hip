@@ -1206,6 +1206,34 @@ int kicp_device_name(int device_id, char *buf, size_t len) {
     snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return KICP_OK;
 }
+int kicp_device_alloc(int device_id, size_t bytes, void **d_ptr) {
+    if (!d_ptr) return KICP_ERR_INVALID_ARG;
+    KICP_TRY(check_device(device_id));
+    KICP_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return KICP_OK;
+}
+int kicp_device_free(int device_id, void *d_ptr) {
+    KICP_HIP(hipSetDevice(device_id));
+    if (d_ptr) KICP_HIP(hipFree(d_ptr));
+    return KICP_OK;
+}
+int kicp_device_upload(int device_id, void *d_dst, const void *h_src, size_t bytes) {
+    if ((!d_dst || !h_src) && bytes) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(device_id));
+    if (bytes) KICP_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return KICP_OK;
+}
+int kicp_device_download(int device_id, void *h_dst, const void *d_src, size_t bytes) {
+    if ((!h_dst || !d_src) && bytes) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(device_id));
+    if (bytes) KICP_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return KICP_OK;
+}
+int kicp_device_synchronize(int device_id) {
+    KICP_HIP(hipSetDevice(device_id));
+    KICP_HIP(hipDeviceSynchronize());
+    return KICP_OK;
+}
 int kicp_set_option(const char *name, long value) {
     if (!name) return KICP_ERR_INVALID_ARG;
     if (!strcmp(name, "icp_blocks")) {

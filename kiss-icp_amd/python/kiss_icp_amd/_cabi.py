@@ -101,6 +101,11 @@ SIGNATURES = {
     "kicp_pipeline_last_stats": [_vp, C.POINTER(FrameStats)],
     "kicp_pipeline_icp_timing": [_vp, _dp, _u64p, _u64p, _u64p, _i],
     "kicp_pipeline_stream": [_vp, C.POINTER(_vp)],
+    "kicp_device_alloc": [_i, _sz, C.POINTER(_vp)],
+    "kicp_device_free": [_i, _vp],
+    "kicp_device_upload": [_i, _vp, _vp, _sz],
+    "kicp_device_download": [_i, _vp, _vp, _sz],
+    "kicp_device_synchronize": [_i],
 }
 _STRING_FUNCS = ("kicp_status_string", "kicp_last_error")
 
@@ -175,3 +180,31 @@ def device_name(device_id=0):
 
 def set_option(name, value):
     check(lib().kicp_set_option(name.encode(), int(value)))
+
+
+class DeviceArray:
+    """a host numpy array staged in HBM through the C-ABI's device-memory helpers"""
+
+    def __init__(self, host, device_id=0):
+        host = np.ascontiguousarray(host)
+        self.device_id, self.shape, self.dtype, self.nbytes = device_id, host.shape, host.dtype, host.nbytes
+        p = C.c_void_p()
+        check(lib().kicp_device_alloc(device_id, host.nbytes, C.byref(p)))
+        self.ptr = p
+        check(lib().kicp_device_upload(device_id, p, ptr(host), host.nbytes))
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().kicp_device_download(self.device_id, ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().kicp_device_free(self.device_id, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -330,7 +330,7 @@ def test_pipeline_full_size_scan(gpu, O):
 def test_pipeline_async_device_frames_match_sync(gpu, O):
     """frames already in HBM, enqueued back-to-back without host synchronisation, give the same
     trajectory as the synchronous host-buffer path"""
-    import torch
+    from kiss_icp_amd import _cabi
     from kiss_icp_amd.config import load_config
     from kiss_icp_amd.datasets import kitti_like
     from kiss_icp_amd.kiss_icp import KissICP
@@ -338,10 +338,9 @@ def test_pipeline_async_device_frames_match_sync(gpu, O):
     ds = kitti_like(seed=5, n_frames=8, beams=32, azimuth_steps=512)
     scans = [ds[i][0] for i in range(8)]
     ka, ks = KissICP(load_config(deskew=False)), KissICP(load_config(deskew=False))
-    dev = [torch.from_numpy(s).cuda() for s in scans]
-    torch.cuda.synchronize()
+    dev = [_cabi.DeviceArray(s) for s in scans]
     for d in dev:
-        ka.register_frame_device(d.data_ptr(), d.shape[0])
+        ka.register_frame_device(d.ptr, d.shape[0])
     ka.sync()
     poses_async = ka.synced_poses()
     for i, s in enumerate(scans):
