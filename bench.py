@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--icp-blocks", type=int, default=0)
+    ap.add_argument("--icp-ppg", type=int, default=0, help="icp_points_per_group option")
     return ap.parse_args()
 
 
@@ -58,7 +59,7 @@ def cpu_baseline(scans, warmup, steps, cfg):
     cores = O.num_procs()
     best = None
     detail = {}
-    for threads in sorted({1, cores}):
+    for threads in sorted({1, min(8, cores), min(16, cores), min(32, cores)}):
         kw = dict(cfg)
         kw["deskew"] = int(kw.get("deskew", False))
         k = O.KissICP(max_num_threads=threads, **kw)
@@ -92,6 +93,8 @@ def main():
     dist = multistream.init_process_group("nccl") if world > 1 else None
     if args.icp_blocks:
         _cabi.set_option("icp_blocks", args.icp_blocks)
+    if args.icp_ppg:
+        _cabi.set_option("icp_points_per_group", args.icp_ppg)
 
     W, K = args.warmup, args.steps
     ds, cfg_over, workload_name = make_dataset(args.workload, multistream.stream_seed(args.seed, rank), W + K)
@@ -161,6 +164,7 @@ def main():
         "ms_per_icp_iter": icp["total_ms"] / max(1, icp["iterations"]),
         "ms_per_frame_host_synced": sync_latency_ms,
         "async_equals_synced_trajectory": same_traj,
+        "icp_last_launch_phase_cycles": pipe.icp_profile(),
     }
     # roofline of the dominant kernel (k_icp): algorithmic bytes of AlignPointsToMap
     # (per iteration N_src*(24+24) + N_src*27*16 + E*24 + 336) / device time

@@ -201,6 +201,10 @@ int kicp_pipeline_last_stats(kicp_pipeline *p, kicp_frame_stats *stats);
  * the last reset, its launch count and iteration count -- for roofline accounting */
 int kicp_pipeline_icp_timing(kicp_pipeline *p, double *total_ms, uint64_t *launches,
                              uint64_t *iterations, uint64_t *algorithmic_bytes, int reset);
+/* shader-clock cycles workgroup 0 spent in the four phases of the LAST ICP launch
+ * ([0] association + accumulation, [1] workgroup reduction + publish, [2] cross-workgroup gather,
+ * [3] 6x6 solve + pose update) and the number of workgroups that took part */
+int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgroups);
 /* the HIP stream (hipStream_t) the pipeline launches on, as an opaque pointer */
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
 
@@ -216,7 +220,9 @@ int kicp_device_synchronize(int device_id);
 
 /* ------------------------------------------------------------------------------------------
  * tuning knobs (process-wide; read when a handle is created).  Unknown names are an error.
- *   "icp_blocks"      workgroups of the persistent ICP kernel (0 = choose from N_src)
+ *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src
+ *                     on the device: ceil(N_src / (8 * icp_points_per_group)), at most 256)
+ *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 2)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
  * ---------------------------------------------------------------------------------------- */
 int kicp_set_option(const char *name, long value);

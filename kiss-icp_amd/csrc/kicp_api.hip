@@ -89,15 +89,12 @@ static int err_bits_to_status(int bits) {
     return KICP_ERR_CAPACITY;
 }
 
-static int choose_icp_blocks(long n_hint) {
-    long g = options().icp_blocks;
-    if (g <= 0) {
-        // two rounds of 8 points per workgroup and iteration
-        g = (n_hint + 2 * kIcpGroupsPerBlock - 1) / (2 * kIcpGroupsPerBlock);
-    }
-    if (g < 1) g = 1;
-    if (g > kIcpMaxBlocks) g = kIcpMaxBlocks;
-    return (int)g;
+// The ICP grid is always launched at its maximum (one workgroup per CU); the kernel itself picks
+// how many of them take part from the actual N_src (surplus workgroups exit at once).
+static int icp_launch_blocks() { return kIcpMaxBlocks; }
+static void icp_fill_policy(IcpParams &P) {
+    P.force_blocks = (int)options().icp_blocks;
+    P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 2);
 }
 
 }  // namespace kicp
@@ -117,6 +114,8 @@ MapView kicp_map::view() const {
     v.blocks_cap = blocks_cap;
     v.ctr = ctr.as<int>();
     v.free_ids = free_ids.as<int>();
+    v.heads = heads.as<int>();
+    v.z_off = kBlockHeader + 16 * (int)max_points;
     v.voxel_size = voxel_size;
     v.max_distance = max_distance;
     v.map_resolution = sqrt(voxel_size * voxel_size / (double)max_points);
@@ -152,8 +151,10 @@ static int map_rehash(kicp_map *m, uint32_t new_cap) {
         m->slots.release();
         m->slots = ns;
         m->slot_cap = new_cap;
+        KICP_TRY(m->heads.reserve((size_t)new_cap * sizeof(int)));
     }
     KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
+    KICP_HIP(hipMemsetAsync(m->heads.p, 0xFF, (size_t)m->slot_cap * sizeof(int), m->stream));
     launch_map_rehash(m->view(), m->bump_ub, m->stream);
     KICP_HIP(hipGetLastError());
     KICP_TRY(m->refresh_counters());
@@ -200,6 +201,8 @@ static int map_alloc(kicp_map *m) {
     m->slot_cap = 1u << 16;
     m->blocks_cap = 1 << 14;
     KICP_TRY(m->slots.reserve((size_t)m->slot_cap * sizeof(Slot)));
+    KICP_TRY(m->heads.reserve((size_t)m->slot_cap * sizeof(int)));
+    KICP_HIP(hipMemsetAsync(m->heads.p, 0xFF, (size_t)m->slot_cap * sizeof(int), m->stream));
     KICP_TRY(m->blocks.reserve((size_t)m->blocks_cap * m->stride + 64));
     KICP_TRY(m->free_ids.reserve((size_t)m->blocks_cap * sizeof(int)));
     KICP_TRY(m->ctr.reserve(sizeof(int) * C_COUNT + sizeof(PipeState)));
@@ -263,6 +266,7 @@ int kicp_map_destroy(kicp_map *m) {
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
     m->slots.release();
+    m->heads.release();
     m->blocks.release();
     m->free_ids.release();
     m->ctr.release();
@@ -280,6 +284,7 @@ int kicp_map_clear(kicp_map *m) {
     KICP_HIP(hipSetDevice(m->device));
     KICP_TRY(m->refresh_counters());
     KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
+    KICP_HIP(hipMemsetAsync(m->heads.p, 0xFF, (size_t)m->slot_cap * sizeof(int), m->stream));
     KICP_HIP(hipMemsetAsync(m->blocks.p, 0, (size_t)m->bump_ub * m->stride, m->stream));
     KICP_HIP(hipMemsetAsync(m->ctr.p, 0, sizeof(int) * C_COUNT, m->stream));
     KICP_HIP(hipStreamSynchronize(m->stream));
@@ -399,9 +404,14 @@ int kicp_map_pointcloud(const kicp_map *cm, double *out_xyz, size_t cap, size_t 
     size_t k = 0;
     for (size_t b = 0; b < nb; ++b) {
         const BlockHdr *h = reinterpret_cast<const BlockHdr *>(host.data() + b * m->stride);
-        const double *pts = reinterpret_cast<const double *>(host.data() + b * m->stride + kBlockHeader);
+        const double *xy = reinterpret_cast<const double *>(host.data() + b * m->stride + kBlockHeader);
+        const double *z = reinterpret_cast<const double *>(host.data() + b * m->stride + kBlockHeader + 16 * m->max_points);
         for (int i = 0; i < h->count; ++i, ++k)
-            if (k < cap) memcpy(out_xyz + 3 * k, pts + 3 * i, 3 * sizeof(double));
+            if (k < cap) {
+                out_xyz[3 * k] = xy[2 * i];
+                out_xyz[3 * k + 1] = xy[2 * i + 1];
+                out_xyz[3 * k + 2] = z[i];
+            }
     }
     *n_out = k;
     return KICP_OK;
@@ -516,9 +526,10 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
     if (n) KICP_HIP(hipMemcpyAsync(r->frame.p, frame_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, r->stream));
     PipeState *st = r->state.as<PipeState>();
     KICP_HIP(hipMemcpyAsync(&st->guess, &guess, sizeof guess, hipMemcpyHostToDevice, r->stream));
-    const int G = choose_icp_blocks((long)n);
+    const int G = icp_launch_blocks();
     IcpParams P;
     memset(&P, 0, sizeof P);
+    icp_fill_policy(P);
     P.frame = r->frame.as<double>();
     P.work = r->work.as<double>();
     P.n_ptr = nullptr;
@@ -852,10 +863,10 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     launch_ds_scatter(D2, s);
 
     // --- AlignPointsToMap + threshold / pose bookkeeping (KissICP.cpp:44-63) ---------------------
-    const long hint = p->n_src_hint > 0 ? p->n_src_hint : (long)(n / 48 + 64);
-    const int G = choose_icp_blocks(hint);
+    const int G = icp_launch_blocks();
     IcpParams I;
     memset(&I, 0, sizeof I);
+    icp_fill_policy(I);
     I.frame = p->src.as<double>();
     I.work = p->work.as<double>();
     I.n_ptr = &st->n_src;
@@ -1155,6 +1166,15 @@ int kicp_pipeline_icp_timing(kicp_pipeline *p, double *total_ms, uint64_t *launc
     return KICP_OK;
 }
 
+int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgroups) {
+    if (!p || !cycles) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    for (int i = 0; i < 4; ++i) cycles[i] = h.prof[i];
+    if (workgroups) *workgroups = h.icp_blocks_used;
+    return KICP_OK;
+}
+
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream) {
     if (!p || !stream) return KICP_ERR_INVALID_ARG;
     *stream = (void *)p->stream;
@@ -1239,6 +1259,9 @@ int kicp_set_option(const char *name, long value) {
     if (!strcmp(name, "icp_blocks")) {
         if (value < 0 || value > kIcpMaxBlocks) return KICP_ERR_INVALID_ARG;
         options().icp_blocks = value;
+    } else if (!strcmp(name, "icp_points_per_group")) {
+        if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;
+        options().icp_points_per_group = value;
     } else if (!strcmp(name, "icp_timing")) {
         options().icp_timing = value;
     } else {

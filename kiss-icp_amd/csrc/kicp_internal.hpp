@@ -2,14 +2,16 @@
 //
 // HBM layout
 //   Voxel map (kiss_icp::VoxelHashMap, core/VoxelHashMap.hpp:38-57)
-//     slots[C]   : 16-byte open-addressed slots {u64 packed voxel key, i32 block id, i32 list
-//                  head}; C a power of two; linear probing; EMPTY / TOMBSTONE sentinels.  One
-//                  probe = one aligned 16-byte load.
+//     slots[C]   : 16-byte open-addressed slots {u64 packed voxel key, i32 block id, i32 point
+//                  count}; C a power of two; linear probing; EMPTY / TOMBSTONE sentinels.  One
+//                  probe = one aligned 16-byte load and tells the prober how many points to read.
 //     blocks[B]  : fixed-stride voxel blocks, stride = roundup(32 + 24*max_points, 128) bytes
 //                  (512 B for the default 20 points = four 128-byte lines):
-//                  {u64 key, i32 count, i32 slot, 16 B pad, points[max_points] as xyz f64}.
-//                  count == 0 marks a free block.  A voxel's points are contiguous, so a hit
-//                  costs one burst instead of the reference's std::vector pointer chase.
+//                  {u64 key, i32 count, i32 slot, 16 B pad | xy[max_points] as 16-byte pairs |
+//                  z[max_points]}.  Lane i of a 32-lane group reads point i of a voxel with one
+//                  16-byte and one 8-byte load, both coalesced across the group -- instead of the
+//                  reference's std::vector pointer chase.  count == 0 marks a free block.
+//     heads[C]   : per-slot list head used only while inserting a frame.
 //     free_ids[] : stack of recycled block ids;  ctr[] : device counters.
 //   Frame clouds : row-major xyz f64 (the reference's std::vector<Eigen::Vector3d> layout).
 #pragma once
@@ -29,7 +31,7 @@ namespace kicp {
 struct alignas(16) Slot {
     unsigned long long key;
     int block;  // -1 until a block is attached
-    int head;   // per-frame insertion list head, -1 when idle
+    int count;  // points stored in the voxel (mirror of the block header's count)
 };
 
 struct alignas(16) DsSlot {  // scratch table of VoxelDownsample
@@ -67,6 +69,8 @@ struct MapView {
     int blocks_cap;
     int *ctr;
     int *free_ids;
+    int *heads;  // per-slot insertion list heads (-1 when idle)
+    int z_off;   // byte offset of the z array inside a block = 32 + 16 * max_points
     double voxel_size;
     double max_distance;
     double map_resolution;  // sqrt(voxel_size^2 / max_points)  VoxelHashMap.cpp:98
@@ -75,8 +79,11 @@ struct MapView {
 __device__ __forceinline__ BlockHdr *block_hdr(const MapView &m, int b) {
     return reinterpret_cast<BlockHdr *>(m.blocks + (size_t)b * m.stride);
 }
-__device__ __forceinline__ double *block_pts(const MapView &m, int b) {
-    return reinterpret_cast<double *>(m.blocks + (size_t)b * m.stride + kBlockHeader);
+__device__ __forceinline__ double2 *block_xy(const MapView &m, int b) {
+    return reinterpret_cast<double2 *>(m.blocks + (size_t)b * m.stride + kBlockHeader);
+}
+__device__ __forceinline__ double *block_z(const MapView &m, int b) {
+    return reinterpret_cast<double *>(m.blocks + (size_t)b * m.stride + m.z_off);
 }
 
 // Per-pipeline state that never leaves the device between frames
@@ -96,7 +103,10 @@ struct PipeState {
     int icp_iterations, icp_converged;
     unsigned long long icp_examined, icp_ncorr_last, icp_ncorr_total;
     int err;
-    int pad;
+    int icp_blocks_used;  // workgroups that took part in the last ICP launch
+    // shader-clock cycles spent by workgroup 0 in the phases of the last ICP launch:
+    // [0] association+accumulate, [1] workgroup reduce+publish, [2] gather, [3] solve+update
+    unsigned long long prof[4];
 };
 
 constexpr int kIcpSums = 18;  // 16 normal-equation scalars + correspondence count + examined count
@@ -119,6 +129,9 @@ struct IcpParams {
     double conv;
     unsigned long long *granules;  // [2][gridDim.x][kIcpSums * 2] tagged 8-byte words
     unsigned spin_limit;
+    int points_per_group;  // target points per 32-lane group and iteration (sets how many
+                           // of the launched workgroups take part: ceil(n / (8 * this)))
+    int force_blocks;      // > 0: exactly this many workgroups take part
 };
 
 // ---- host-side objects ------------------------------------------------------------------------
@@ -143,6 +156,7 @@ const char *get_error();
 
 struct Options {
     long icp_blocks = 0;
+    long icp_points_per_group = 2;
     long icp_timing = 1;
 };
 Options &options();
@@ -171,7 +185,7 @@ struct kicp_map {
     double voxel_size = 1.0, max_distance = 100.0;
     unsigned max_points = 20;
     int stride = 512;
-    kicp::DevBuf slots, blocks, free_ids, ctr;
+    kicp::DevBuf slots, heads, blocks, free_ids, ctr;
     uint32_t slot_cap = 0;
     int blocks_cap = 0;
     // host-side upper bounds of the device counters (exact after refresh_counters)

@@ -44,16 +44,19 @@ __device__ __forceinline__ Slot load_slot(const Slot *p) {
     Slot s;
     s.key = (unsigned long long)(unsigned)v.x | ((unsigned long long)(unsigned)v.y << 32);
     s.block = v.z;
-    s.head = v.w;
+    s.count = v.w;
     return s;
 }
 
-// block id of a voxel, or -1
-__device__ __forceinline__ int map_find(const MapView &m, unsigned long long key) {
+// block id (and stored point count) of a voxel, or -1
+__device__ __forceinline__ int map_find(const MapView &m, unsigned long long key, int &count) {
     uint32_t s = hash_key(key, m.mask);
     for (uint32_t probes = 0; probes <= m.mask; ++probes) {
         const Slot sl = load_slot(m.slots + s);
-        if (sl.key == key) return sl.block;
+        if (sl.key == key) {
+            count = sl.count;
+            return sl.block;
+        }
         if (sl.key == kKeyEmpty) return -1;
         s = (s + 1) & m.mask;
     }
@@ -81,66 +84,87 @@ constexpr ShiftCodes make_shift_codes() {
 }
 constexpr ShiftCodes kShift = make_shift_codes();
 
-// GetClosestNeighbor for one query, cooperatively by a 32-lane group: lane j < 27 probes voxel
-// (v + shift_j) and scans that voxel's points; the group then takes the lexicographic minimum of
-// (squared distance, shift index), i.e. the reference's strict '<' in shift order; inside a voxel
-// the first minimum wins like std::min_element.  Returns the squared distance (DBL_MAX when the
-// neighbourhood is empty), the neighbour, and the number of map points examined.
+// GetClosestNeighbor for one query, cooperatively by a 32-lane group (two groups per wave):
+//   1. lane j < 27 probes voxel (v + shift_j): one 16-byte slot load gives block id + point count;
+//   2. the hit voxels are visited in shift order, kChunk at a time: for each, lane i < count loads
+//      point i (one 16-byte xy load + one 8-byte z load, coalesced over the group); all loads of a
+//      chunk are issued before the first distance is computed, so a chunk costs one memory round
+//      trip instead of one per point;
+//   3. every lane keeps its best (squared distance, shift j, index i); a 5-step xor-shuffle takes
+//      the lexicographic minimum = the reference's strict '<' in shift order and, inside a voxel,
+//      std::min_element's first minimum.
+// Returns the squared distance (DBL_MAX when the neighbourhood is empty), the neighbour, and the
+// number of map points examined.
+constexpr int kChunk = 9;
+
 __device__ __forceinline__ double group_closest_neighbor(const MapView &m, double sx, double sy,
                                                          double sz, int lane, double nn[3],
                                                          int &examined, int &range_err) {
     const int vx = voxel_coord(sx, m.voxel_size);
     const int vy = voxel_coord(sy, m.voxel_size);
     const int vz = voxel_coord(sz, m.voxel_size);
-    double best = DBL_MAX;
-    double bx = 0.0, by = 0.0, bz = 0.0;
-    int cnt = 0;
+    int blk = -1, cnt = 0;
     if (lane < 27) {
         const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
         const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
         const int qz = vz + (int)((kShift.z >> (2 * lane)) & 3) - 1;
         if (voxel_in_range(qx, qy, qz)) {
-            const int b = map_find(m, pack_voxel(qx, qy, qz));
-            if (b >= 0) {
-                cnt = block_hdr(m, b)->count;
-                const double2 *p2 = reinterpret_cast<const double2 *>(block_pts(m, b));
-                for (int k = 0; k < cnt; k += 2) {
-                    // two points = 48 bytes = three aligned 16-byte loads
-                    const double2 a = p2[0], bb = p2[1], c = p2[2];
-                    p2 += 3;
-                    const double dx0 = a.x - sx, dy0 = a.y - sy, dz0 = bb.x - sz;
-                    const double d0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0;
-                    if (d0 < best) {
-                        best = d0;
-                        bx = a.x;
-                        by = a.y;
-                        bz = bb.x;
-                    }
-                    if (k + 1 < cnt) {
-                        const double dx1 = bb.y - sx, dy1 = c.x - sy, dz1 = c.y - sz;
-                        const double d1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
-                        if (d1 < best) {
-                            best = d1;
-                            bx = bb.y;
-                            by = c.x;
-                            bz = c.y;
-                        }
-                    }
-                }
-            }
+            blk = map_find(m, pack_voxel(qx, qy, qz), cnt);
+            if (blk < 0) cnt = 0;
         } else {
             range_err = 1;
         }
     }
-    // lexicographic min over (distance, lane) inside the 32-lane group
+    // hit mask of this group (the wave holds two groups)
+    const unsigned long long ball = __ballot(blk >= 0);
+    unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
+    double best = DBL_MAX;
+    double bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF;
+    while (__ballot(hits != 0) != 0ull) {  // wave-uniform trip count
+        double2 xy[kChunk];
+        double zz[kChunk];
+        int jj[kChunk];
+        bool ld[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            const int j = hits ? (__ffs(hits) - 1) : -1;
+            hits &= hits - 1;  // (0 & -1) == 0
+            const int bj = __shfl(blk, j & 31, 32);
+            const int cj = __shfl(cnt, j & 31, 32);
+            jj[u] = j;
+            ld[u] = (j >= 0) && (lane < cj);
+            if (ld[u]) {
+                xy[u] = block_xy(m, bj)[lane];
+                zz[u] = block_z(m, bj)[lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            if (ld[u]) {
+                const double dx = xy[u].x - sx, dy = xy[u].y - sy, dz = zz[u] - sz;
+                const double d = (dx * dx + dy * dy) + dz * dz;
+                if (d < best) {  // shifts arrive in increasing j: strict '<' keeps the earliest
+                    best = d;
+                    bx = xy[u].x;
+                    by = xy[u].y;
+                    bz = zz[u];
+                    bkey = (jj[u] << 12) | lane;
+                }
+            }
+        }
+    }
+    // lexicographic min over (distance, shift, index) inside the 32-lane group
     double gbest = best;
-    int glane = lane;
+    int gkey = bkey, glane = lane;
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) {
         const double ob = __shfl_xor(gbest, off, 32);
+        const int ok = __shfl_xor(gkey, off, 32);
         const int ol = __shfl_xor(glane, off, 32);
-        if (ob < gbest || (ob == gbest && ol < glane)) {
+        if (ob < gbest || (ob == gbest && ok < gkey)) {
             gbest = ob;
+            gkey = ok;
             glane = ol;
         }
     }
@@ -154,6 +178,72 @@ __device__ __forceinline__ double group_closest_neighbor(const MapView &m, doubl
     return gbest;
 }
 
+// Same search for voxels that hold more than 32 points (max_points_per_voxel > 32): every lane
+// strides over the voxel's points.  Rare configuration, kept simple.
+__device__ __forceinline__ double group_closest_neighbor_wide(const MapView &m, double sx, double sy,
+                                                              double sz, int lane, double nn[3],
+                                                              int &examined, int &range_err) {
+    const int vx = voxel_coord(sx, m.voxel_size);
+    const int vy = voxel_coord(sy, m.voxel_size);
+    const int vz = voxel_coord(sz, m.voxel_size);
+    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF, cnt = 0;
+    if (lane < 27) {
+        const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
+        const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
+        const int qz = vz + (int)((kShift.z >> (2 * lane)) & 3) - 1;
+        if (voxel_in_range(qx, qy, qz)) {
+            const int b = map_find(m, pack_voxel(qx, qy, qz), cnt);
+            if (b >= 0) {
+                const double2 *xy = block_xy(m, b);
+                const double *z = block_z(m, b);
+                for (int k = 0; k < cnt; ++k) {
+                    const double dx = xy[k].x - sx, dy = xy[k].y - sy, dz = z[k] - sz;
+                    const double d = (dx * dx + dy * dy) + dz * dz;
+                    if (d < best) {
+                        best = d;
+                        bx = xy[k].x;
+                        by = xy[k].y;
+                        bz = z[k];
+                    }
+                }
+                bkey = lane;
+            } else {
+                cnt = 0;
+            }
+        } else {
+            range_err = 1;
+        }
+    }
+    double gbest = best;
+    int gkey = bkey, glane = lane;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(gbest, off, 32);
+        const int ok = __shfl_xor(gkey, off, 32);
+        const int ol = __shfl_xor(glane, off, 32);
+        if (ob < gbest || (ob == gbest && ok < gkey)) {
+            gbest = ob;
+            gkey = ok;
+            glane = ol;
+        }
+    }
+    nn[0] = __shfl(bx, glane, 32);
+    nn[1] = __shfl(by, glane, 32);
+    nn[2] = __shfl(bz, glane, 32);
+    int ex = cnt;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) ex += __shfl_xor(ex, off, 32);
+    examined = ex;
+    return gbest;
+}
+
+__device__ __forceinline__ double closest_neighbor_any(const MapView &m, double sx, double sy, double sz,
+                                                       int lane, double nn[3], int &examined, int &range_err) {
+    if (m.max_points <= 32) return group_closest_neighbor(m, sx, sy, sz, lane, nn, examined, range_err);
+    return group_closest_neighbor_wide(m, sx, sy, sz, lane, nn, examined, range_err);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_closest_neighbor: VoxelHashMap::GetClosestNeighbor batched over nq queries
 // ------------------------------------------------------------------------------------------
@@ -165,7 +255,7 @@ __global__ __launch_bounds__(256) void k_closest_neighbor(MapView m, const doubl
     for (int i = grp; i < nq; i += ngrp) {
         double nn[3];
         int ex, rerr = 0;
-        const double d2 = group_closest_neighbor(m, q[3 * i], q[3 * i + 1], q[3 * i + 2], lane, nn, ex, rerr);
+        const double d2 = closest_neighbor_any(m, q[3 * i], q[3 * i + 1], q[3 * i + 2], lane, nn, ex, rerr);
         if (lane == 0) {
             const bool found = d2 < DBL_MAX;
             nn_out[3 * i] = found ? nn[0] : 0.0;
@@ -194,7 +284,6 @@ __global__ __launch_bounds__(256) void k_closest_neighbor(MapView m, const doubl
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int G = gridDim.x;
     double *sh_part = reinterpret_cast<double *>(smem);                     // [8][kIcpSums]
     double *sh_tot = sh_part + kIcpGroupsPerBlock * kIcpSums;                // [kIcpSums]
     double *sh_p8 = sh_tot + kIcpSums;                                       // [8][kIcpSums]
@@ -210,7 +299,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     PipeState *st = P.state;
 
     const int n = count_of(P.n_ptr, P.n_imm);
+    // How many of the launched workgroups take part is decided here, from the actual N_src, so the
+    // summation order (hence the result, bit for bit) never depends on host-side hints.
+    int G = P.force_blocks > 0 ? P.force_blocks
+                               : (n + kIcpGroupsPerBlock * P.points_per_group - 1) / (kIcpGroupsPerBlock * P.points_per_group);
+    G = max(1, min(G, (int)gridDim.x));
+    if ((int)blockIdx.x >= G) return;
     const unsigned epoch_base = st->epoch_base;
+    unsigned long long t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
 
     SE3 guess;
     double max_dist, ks;
@@ -239,6 +335,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 
     const int max_iters = map_empty ? 0 : P.max_iters;
     for (int it = 0; it < max_iters; ++it) {
+        const unsigned long long c0 = wall_clock64();
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
@@ -254,7 +351,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
             double nn[3];
             int ex;
-            const double d2 = group_closest_neighbor(m, s[0], s[1], s[2], lane, nn, ex, range_err);
+            const double d2 = closest_neighbor_any(m, s[0], s[1], s[2], lane, nn, ex, range_err);
             if (lane == 0) {
                 acc[17] += (double)ex;
                 if (d2 < DBL_MAX && sqrt(d2) < max_dist) {
@@ -284,6 +381,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
+        const unsigned long long c1 = wall_clock64();
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < kIcpSums; ++k) sh_part[grp * kIcpSums + k] = acc[k];
@@ -301,6 +399,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
         }
         // ---- gather every workgroup's partial (bounded spin) --------------------------------
+        const unsigned long long c2 = wall_clock64();
         {
             const int nwords = G * 2 * kIcpSums;
             unsigned spins = 0;
@@ -346,6 +445,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         __syncthreads();
         // ---- every thread solves the same system (uniform, no broadcast needed) ------------
+        const unsigned long long c3 = wall_clock64();
         double S[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) S[k] = sh_tot[k];
@@ -384,6 +484,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         double nrm = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) nrm += dx[i] * dx[i];
+        const unsigned long long c4 = wall_clock64();
+        t_assoc += c1 - c0;
+        t_publish += c2 - c1;
+        t_gather += c3 - c2;
+        t_solve += c4 - c3;
         if (sqrt(nrm) < P.conv) {
             converged = 1;
             break;
@@ -403,6 +508,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         st->icp_ncorr_last = ncorr_last;
         st->icp_ncorr_total = ncorr_total;
         st->n_src = n;
+        st->icp_blocks_used = G;
+        st->prof[0] = t_assoc;
+        st->prof[1] = t_publish;
+        st->prof[2] = t_gather;
+        st->prof[3] = t_solve;
         st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
         if (P.pipeline_mode) {
             st->sigma = ks;
@@ -538,13 +648,22 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_flags(PreParams P) {
 
 // find-or-claim the slot of a voxel in the downsample scratch table
 __device__ __forceinline__ int ds_claim(DsSlot *tab, uint32_t mask, unsigned long long key) {
+    // Read before CAS: ~15 scan points share a voxel, so most arrivals find their key already
+    // there and never touch the atomic unit.  Keys are stable for the lifetime of a claim phase,
+    // so a (possibly L1-stale) plain read can only cost an extra CAS, never a wrong answer.
     uint32_t s = hash_key(key, mask);
     for (uint32_t probes = 0; probes <= mask; ++probes) {
-        const unsigned long long old = atomicCAS(&tab[s].key, kKeyEmpty, key);
-        if (old == kKeyEmpty || old == key) return (int)s;
+        unsigned long long cur = tab[s].key;
+        if (cur == kKeyEmpty) cur = atomicCAS(&tab[s].key, kKeyEmpty, key);
+        if (cur == kKeyEmpty || cur == key) return (int)s;
         s = (s + 1) & mask;
     }
     return -1;
+}
+// atomicMin that skips the atomic when a plain read already shows a smaller index (the stored
+// index only ever decreases, so a stale read can only cause a redundant atomic)
+__device__ __forceinline__ void ds_min_index(DsSlot *tab, int s, int idx) {
+    if (tab[s].minidx > idx) atomicMin(&tab[s].minidx, idx);
 }
 
 // scatter the range-cropped cloud (order preserving) and, fused, stage A of the first
@@ -574,7 +693,7 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_scatter(PreParams P) {
             int s = -1;
             if (voxel_in_range(vx, vy, vz)) {
                 s = ds_claim(P.ds_tab, P.ds_mask, pack_voxel(vx, vy, vz));
-                if (s >= 0) atomicMin(&P.ds_tab[s].minidx, j);
+                if (s >= 0) ds_min_index(P.ds_tab, s, j);
                 else atomicOr(P.err, E_TABLE_FULL);
             } else {
                 atomicOr(P.err, E_RANGE);
@@ -595,7 +714,7 @@ __global__ __launch_bounds__(256) void k_ds_claim(DsParams P) {
         int s = -1;
         if (voxel_in_range(vx, vy, vz)) {
             s = ds_claim(P.tab, P.mask, pack_voxel(vx, vy, vz));
-            if (s >= 0) atomicMin(&P.tab[s].minidx, i);
+            if (s >= 0) ds_min_index(P.tab, s, i);
             else atomicOr(P.err, E_TABLE_FULL);
         } else {
             atomicOr(P.err, E_RANGE);
@@ -645,7 +764,7 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
             int s2 = -1;
             if (voxel_in_range(vx, vy, vz)) {
                 s2 = ds_claim(P.next_tab, P.next_mask, pack_voxel(vx, vy, vz));
-                if (s2 >= 0) atomicMin(&P.next_tab[s2].minidx, j);
+                if (s2 >= 0) ds_min_index(P.next_tab, s2, j);
                 else atomicOr(P.err, E_TABLE_FULL);
             } else {
                 atomicOr(P.err, E_RANGE);
@@ -689,7 +808,16 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, const double *in, c
             const unsigned long long key = pack_voxel(vx, vy, vz);
             uint32_t s = hash_key(key, m.mask);
             for (uint32_t probes = 0; probes <= m.mask; ++probes) {
-                const unsigned long long old = atomicCAS(&m.slots[s].key, kKeyEmpty, key);
+                unsigned long long old = m.slots[s].key;  // read before CAS (keys are stable here)
+                if (old == key) {
+                    slot = (int)s;
+                    break;
+                }
+                if (old != kKeyEmpty) {
+                    s = (s + 1) & m.mask;  // other key or tombstone
+                    continue;
+                }
+                old = atomicCAS(&m.slots[s].key, kKeyEmpty, key);
                 if (old == kKeyEmpty) {
                     atomicAdd(&m.ctr[C_USED], 1);
                     slot = (int)s;
@@ -706,7 +834,7 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, const double *in, c
             atomicOr(&m.ctr[C_ERR], E_RANGE);
         }
         slot_of[i] = slot;
-        next[i] = (slot >= 0) ? atomicExch(&m.slots[slot].head, i) : -2;
+        next[i] = (slot >= 0) ? atomicExch(&m.heads[slot], i) : -2;
     }
 }
 
@@ -729,8 +857,8 @@ __global__ __launch_bounds__(256) void k_map_apply(MapView m, const int *n_ptr, 
         if (next[i] != -1) continue;  // only the point that opened the list (its tail) leads
         const int slot = slot_of[i];
         Slot *sl = m.slots + slot;
-        const int head = sl->head;
-        sl->head = -1;
+        const int head = m.heads[slot];
+        m.heads[slot] = -1;
         int b = sl->block;
         BlockHdr *hdr;
         if (b < 0) {  // new voxel (VoxelHashMap.cpp:112-116)
@@ -748,33 +876,59 @@ __global__ __launch_bounds__(256) void k_map_apply(MapView m, const int *n_ptr, 
         } else {
             hdr = block_hdr(m, b);
         }
-        double *pts = block_pts(m, b);
+        double2 *pxy = block_xy(m, b);
+        double *pz = block_z(m, b);
         int cnt = hdr->count;
-        // walk the list in ascending point index: repeatedly pick the smallest index > last
-        int last = -1;
-        while (cnt < m.max_points) {  // :104 a full voxel rejects everything that follows
-            int cur = 0x7FFFFFFF;
-            for (int j = head; j >= 0; j = next[j])
-                if (j > last && j < cur) cur = j;
-            if (cur == 0x7FFFFFFF) break;
-            last = cur;
-            const double px = world[3 * cur], py = world[3 * cur + 1], pz = world[3 * cur + 2];
+        // visit the list in ascending point index (= the reference's arrival order).  Common case:
+        // one pass over the chain into a small local array, insertion sort, then apply; a voxel
+        // that received more than kMaxLocal points falls back to repeated selection.
+        constexpr int kMaxLocal = 32;
+        int idx[kMaxLocal];
+        int L = 0;
+        for (int j = head; j >= 0; j = next[j]) {
+            if (L < kMaxLocal) idx[L] = j;
+            ++L;
+        }
+        auto try_add = [&](int cur) {
+            const double px = world[3 * cur], py = world[3 * cur + 1], pz_new = world[3 * cur + 2];
             bool too_close = false;
             for (int k = 0; k < cnt; ++k) {  // :105-108 (norm < map_resolution, strict)
-                const double dx = pts[3 * k] - px, dy = pts[3 * k + 1] - py, dz = pts[3 * k + 2] - pz;
+                const double dx = pxy[k].x - px, dy = pxy[k].y - py, dz = pz[k] - pz_new;
                 if (sqrt((dx * dx + dy * dy) + dz * dz) < m.map_resolution) {
                     too_close = true;
                     break;
                 }
             }
             if (!too_close) {
-                pts[3 * cnt] = px;
-                pts[3 * cnt + 1] = py;
-                pts[3 * cnt + 2] = pz;
+                pxy[cnt] = make_double2(px, py);
+                pz[cnt] = pz_new;
                 ++cnt;
+            }
+        };
+        if (L <= kMaxLocal) {
+            for (int a = 1; a < L; ++a) {
+                const int v = idx[a];
+                int c = a - 1;
+                while (c >= 0 && idx[c] > v) {
+                    idx[c + 1] = idx[c];
+                    --c;
+                }
+                idx[c + 1] = v;
+            }
+            for (int a = 0; a < L && cnt < m.max_points; ++a) try_add(idx[a]);  // :104 full voxel rejects the rest
+        } else {
+            int last = -1;
+            while (cnt < m.max_points) {
+                int cur = 0x7FFFFFFF;
+                for (int j = head; j >= 0; j = next[j])
+                    if (j > last && j < cur) cur = j;
+                if (cur == 0x7FFFFFFF) break;
+                last = cur;
+                try_add(cur);
             }
         }
         hdr->count = cnt;
+        sl->count = cnt;
     }
 }
 
@@ -793,12 +947,13 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
         BlockHdr *hdr = block_hdr(m, b);
         if (hdr->count <= 0) continue;
-        const double *pt = block_pts(m, b);
-        const double dx = pt[0] - ox, dy = pt[1] - oy, dz = pt[2] - oz;
+        const double2 p0 = block_xy(m, b)[0];
+        const double dx = p0.x - ox, dy = p0.y - oy, dz = block_z(m, b)[0] - oz;
         if ((dx * dx + dy * dy) + dz * dz >= md2) {
             Slot *sl = m.slots + hdr->slot;
             sl->key = kKeyTomb;
             sl->block = -1;
+            sl->count = 0;
             hdr->count = 0;
             const int k = atomicAdd(&m.ctr[C_NFREE], 1);
             m.free_ids[k] = b;
@@ -826,6 +981,7 @@ __global__ __launch_bounds__(256) void k_map_rehash(MapView m) {
             s = (s + 1) & m.mask;
         }
         m.slots[s].block = b;
+        m.slots[s].count = hdr->count;
         hdr->slot = (int)s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -132,6 +132,14 @@ class KissICP:
         _cabi.check(_cabi.lib().kicp_pipeline_icp_timing(self._h, C.byref(ms), C.byref(launches), C.byref(iters), C.byref(nbytes), int(reset)))
         return {"total_ms": ms.value, "launches": launches.value, "iterations": iters.value, "algorithmic_bytes": nbytes.value}
 
+    def icp_profile(self):
+        """shader-clock cycles of the last ICP launch's phases (workgroup 0) and workgroups used"""
+        cyc = (C.c_uint64 * 4)()
+        wg = C.c_int(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_icp_profile(self._h, cyc, C.byref(wg)))
+        names = ("associate_accumulate", "reduce_publish", "gather", "solve_update")
+        return {"workgroups": wg.value, **{n: int(c) for n, c in zip(names, cyc)}}
+
     def stream(self):
         s = C.c_void_p()
         _cabi.check(_cabi.lib().kicp_pipeline_stream(self._h, C.byref(s)))
