@@ -885,10 +885,9 @@ __global__ __launch_bounds__(256) void k_map_apply(MapView m, const int *n_ptr, 
         constexpr int kMaxLocal = 32;
         int idx[kMaxLocal];
         int L = 0;
-        for (int j = head; j >= 0; j = next[j]) {
-            if (L < kMaxLocal) idx[L] = j;
-            ++L;
-        }
+        int walk = head;
+        for (; walk >= 0 && L < kMaxLocal; walk = next[walk]) idx[L++] = walk;
+        const bool overflow = (walk >= 0);  // more than kMaxLocal new points in this voxel
         auto try_add = [&](int cur) {
             const double px = world[3 * cur], py = world[3 * cur + 1], pz_new = world[3 * cur + 2];
             bool too_close = false;
@@ -905,7 +904,7 @@ __global__ __launch_bounds__(256) void k_map_apply(MapView m, const int *n_ptr, 
                 ++cnt;
             }
         };
-        if (L <= kMaxLocal) {
+        if (!overflow) {
             for (int a = 1; a < L; ++a) {
                 const int v = idx[a];
                 int c = a - 1;
