@@ -95,6 +95,18 @@ static int icp_launch_blocks() { return kIcpMaxBlocks; }
 static void icp_fill_policy(IcpParams &P) {
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 2);
+    // LDS budget for the candidate regions: what is left of 160 KiB after the fixed part, split
+    // over 8 * points_per_group regions, rounded down to a multiple of 32 candidates
+    long cap = options().icp_cand_cap;
+    if (cap < 0) {
+        const long budget = 156 * 1024 - (long)icp_fixed_smem(icp_launch_blocks());
+        const long regions = (long)kIcpGroupsPerBlock * P.points_per_group;
+        cap = (budget / regions - (long)sizeof(IcpRegionMeta)) / 24;
+        cap = (cap / 32) * 32;
+        if (cap > 1024) cap = 1024;
+        if (cap < 0) cap = 0;
+    }
+    P.cand_cap = (int)cap;
 }
 
 }  // namespace kicp
@@ -474,6 +486,10 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
         return KICP_ERR_HIP;
     }
     int s = r->state.reserve(sizeof(PipeState));
+    if (s == KICP_OK && icp_prepare() != 0) {
+        set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
+        s = KICP_ERR_HIP;
+    }
     if (s == KICP_OK) s = r->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
     if (s != KICP_OK) {
         kicp_registration_destroy(r);
@@ -951,6 +967,10 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
         s = map_create_on_stream(cfg->voxel_size, cfg->max_range, (unsigned)cfg->max_points_per_voxel, device_id,
                                  p->stream, &p->map);
     if (s == KICP_OK) s = p->state.reserve(sizeof(PipeState));
+    if (s == KICP_OK && icp_prepare() != 0) {
+        set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
+        s = KICP_ERR_HIP;
+    }
     if (s == KICP_OK) s = p->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
     if (s != KICP_OK) {
         if (s == KICP_ERR_HIP) set_error("pipeline resource creation failed");
@@ -1175,6 +1195,18 @@ int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgro
     return KICP_OK;
 }
 
+int kicp_pipeline_icp_iteration_profile(kicp_pipeline *p, uint32_t *out, int cap_iters, int *n_iters) {
+    if (!p || !n_iters || (!out && cap_iters > 0)) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    int n = h.icp_iterations < kIcpProfIters ? h.icp_iterations : kIcpProfIters;
+    *n_iters = n;
+    if (n > cap_iters) n = cap_iters;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 6; ++j) out[i * 6 + j] = h.prof_iter[i][j];
+    return KICP_OK;
+}
+
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream) {
     if (!p || !stream) return KICP_ERR_INVALID_ARG;
     *stream = (void *)p->stream;
@@ -1262,6 +1294,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_points_per_group")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;
         options().icp_points_per_group = value;
+    } else if (!strcmp(name, "icp_cand_cap")) {
+        options().icp_cand_cap = value;
     } else if (!strcmp(name, "icp_timing")) {
         options().icp_timing = value;
     } else {

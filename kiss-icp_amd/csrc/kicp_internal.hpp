@@ -86,6 +86,8 @@ __device__ __forceinline__ double *block_z(const MapView &m, int b) {
     return reinterpret_cast<double *>(m.blocks + (size_t)b * m.stride + m.z_off);
 }
 
+constexpr int kIcpProfIters = 24;
+
 // Per-pipeline state that never leaves the device between frames
 // (pipeline/KissICP.hpp:87-95 + core/Threshold.hpp:44-50).
 struct PipeState {
@@ -107,13 +109,36 @@ struct PipeState {
     // shader-clock cycles spent by workgroup 0 in the phases of the last ICP launch:
     // [0] association+accumulate, [1] workgroup reduce+publish, [2] gather, [3] solve+update
     unsigned long long prof[4];
+    // the first kIcpProfIters iterations of the last launch, 10 ns ticks: workgroup 0's
+    // {associate, publish, gather, solve}, the slowest group's associate time over ALL workgroups,
+    // and the number of polling passes workgroup 0's thread 0 needed in the gather
+    unsigned prof_iter[kIcpProfIters][6];
 };
 
-constexpr int kIcpSums = 18;  // 16 normal-equation scalars + correspondence count + examined count
+constexpr int kIcpSums = 19;  // 16 normal-equation scalars + correspondence count + examined count
+                              // + one profiling slot (association ticks, max-reduced)
+constexpr int kIcpTickSlot = 18;
 constexpr int kIcpThreads = 256;
 constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 probe lanes)
 constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;
 constexpr int kIcpMaxBlocks = 256;
+
+// LDS region of one (round, group) query of the persistent ICP kernel
+struct IcpRegionMeta {
+    double s[3];  // running transformed source point
+    int v[3];     // voxel the candidate list was built for
+    int E;        // candidates staged (= map points examined)
+    int valid;    // list complete (E <= capacity)
+    int pad;
+};
+static_assert(sizeof(IcpRegionMeta) % 16 == 0, "keep the candidate arrays 16-byte aligned");
+
+// bytes of the fixed part of k_icp's dynamic LDS (reduction scratch + exchange words), 16-byte rounded
+__host__ __device__ inline size_t icp_fixed_smem(int grid_blocks) {
+    const size_t b = (size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpSums + 8 * kIcpSums) * sizeof(double) + 8 +
+                     (size_t)grid_blocks * 2 * kIcpSums * sizeof(unsigned);
+    return (b + 15) & ~(size_t)15;
+}
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
@@ -132,6 +157,7 @@ struct IcpParams {
     int points_per_group;  // target points per 32-lane group and iteration (sets how many
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
+    int cand_cap;          // candidates per LDS region (0 disables LDS staging)
 };
 
 // ---- host-side objects ------------------------------------------------------------------------
@@ -157,6 +183,7 @@ const char *get_error();
 struct Options {
     long icp_blocks = 0;
     long icp_points_per_group = 2;
+    long icp_cand_cap = -1;  // < 0: size the LDS candidate regions automatically; 0: no LDS staging
     long icp_timing = 1;
 };
 Options &options();

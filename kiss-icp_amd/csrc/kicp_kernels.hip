@@ -97,9 +97,13 @@ constexpr ShiftCodes kShift = make_shift_codes();
 // number of map points examined.
 constexpr int kChunk = 9;
 
+//   FILL: additionally stage the candidates, packed in (shift, index) order, into an LDS region
+//   {x[cap], y[cap], z[cap]} so later ICP iterations of the same query never leave the CU.
+template <bool FILL>
 __device__ __forceinline__ double group_closest_neighbor(const MapView &m, double sx, double sy,
                                                          double sz, int lane, double nn[3],
-                                                         int &examined, int &range_err) {
+                                                         int &examined, int &range_err,
+                                                         double *cand = nullptr, int cap = 0) {
     const int vx = voxel_coord(sx, m.voxel_size);
     const int vy = voxel_coord(sy, m.voxel_size);
     const int vz = voxel_coord(sz, m.voxel_size);
@@ -118,6 +122,16 @@ __device__ __forceinline__ double group_closest_neighbor(const MapView &m, doubl
     // hit mask of this group (the wave holds two groups)
     const unsigned long long ball = __ballot(blk >= 0);
     unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
+    int offs = 0;  // exclusive prefix of the point counts in shift order = candidate base index
+    if (FILL) {
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int o = __shfl_up(incl, off, 32);
+            if (lane >= off) incl += o;
+        }
+        offs = incl - cnt;
+    }
     double best = DBL_MAX;
     double bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
@@ -132,7 +146,8 @@ __device__ __forceinline__ double group_closest_neighbor(const MapView &m, doubl
             hits &= hits - 1;  // (0 & -1) == 0
             const int bj = __shfl(blk, j & 31, 32);
             const int cj = __shfl(cnt, j & 31, 32);
-            jj[u] = j;
+            const int oj = FILL ? __shfl(offs, j & 31, 32) : 0;
+            jj[u] = FILL ? oj : j;  // candidate base (FILL) or shift index: both order the voxels
             ld[u] = (j >= 0) && (lane < cj);
             if (ld[u]) {
                 xy[u] = block_xy(m, bj)[lane];
@@ -149,7 +164,15 @@ __device__ __forceinline__ double group_closest_neighbor(const MapView &m, doubl
                     bx = xy[u].x;
                     by = xy[u].y;
                     bz = zz[u];
-                    bkey = (jj[u] << 12) | lane;
+                    bkey = FILL ? (jj[u] + lane) : ((jj[u] << 12) | lane);
+                }
+                if (FILL) {
+                    const int c = jj[u] + lane;
+                    if (c < cap) {
+                        cand[c] = xy[u].x;
+                        cand[cap + c] = xy[u].y;
+                        cand[2 * cap + c] = zz[u];
+                    }
                 }
             }
         }
@@ -238,9 +261,46 @@ __device__ __forceinline__ double group_closest_neighbor_wide(const MapView &m, 
     return gbest;
 }
 
+// GetClosestNeighbor over candidates already staged in LDS by a previous iteration (same voxel
+// neighbourhood): 32 lanes stride over the packed list; the candidate index is the tie-break key.
+__device__ __forceinline__ double group_closest_neighbor_lds(const double *cand, int cap, int E, double sx,
+                                                             double sy, double sz, int lane, double nn[3]) {
+    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF;
+    for (int c = lane; c < E; c += 32) {
+        const double x = cand[c], y = cand[cap + c], z = cand[2 * cap + c];
+        const double dx = x - sx, dy = y - sy, dz = z - sz;
+        const double d = (dx * dx + dy * dy) + dz * dz;
+        if (d < best) {
+            best = d;
+            bx = x;
+            by = y;
+            bz = z;
+            bkey = c;
+        }
+    }
+    double gbest = best;
+    int gkey = bkey, glane = lane;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(gbest, off, 32);
+        const int ok = __shfl_xor(gkey, off, 32);
+        const int ol = __shfl_xor(glane, off, 32);
+        if (ob < gbest || (ob == gbest && ok < gkey)) {
+            gbest = ob;
+            gkey = ok;
+            glane = ol;
+        }
+    }
+    nn[0] = __shfl(bx, glane, 32);
+    nn[1] = __shfl(by, glane, 32);
+    nn[2] = __shfl(bz, glane, 32);
+    return gbest;
+}
+
 __device__ __forceinline__ double closest_neighbor_any(const MapView &m, double sx, double sy, double sz,
                                                        int lane, double nn[3], int &examined, int &range_err) {
-    if (m.max_points <= 32) return group_closest_neighbor(m, sx, sy, sz, lane, nn, examined, range_err);
+    if (m.max_points <= 32) return group_closest_neighbor<false>(m, sx, sy, sz, lane, nn, examined, range_err);
     return group_closest_neighbor_wide(m, sx, sy, sz, lane, nn, examined, range_err);
 }
 
@@ -288,7 +348,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     double *sh_tot = sh_part + kIcpGroupsPerBlock * kIcpSums;                // [kIcpSums]
     double *sh_p8 = sh_tot + kIcpSums;                                       // [8][kIcpSums]
     int *sh_failp = reinterpret_cast<int *>(sh_p8 + 8 * kIcpSums);          // [2] (8 bytes)
-    unsigned *sh_words = reinterpret_cast<unsigned *>(sh_failp + 2);        // [G][2*kIcpSums]
+    unsigned *sh_words = reinterpret_cast<unsigned *>(sh_failp + 2);        // [gridDim.x][2*kIcpSums]
+    // per (round, group) candidate regions: meta {s[3] running source point; v[3] voxel; E; valid}
+    // + candidates {x[cap], y[cap], z[cap]}
+    const int n_regions = kIcpGroupsPerBlock * P.points_per_group;
+    const int cap_q = P.cand_cap;
+    char *region_base = smem + icp_fixed_smem((int)gridDim.x);
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
     // shift its base off 8/16-byte alignment)
 
@@ -307,6 +372,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if ((int)blockIdx.x >= G) return;
     const unsigned epoch_base = st->epoch_base;
     unsigned long long t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
+    unsigned gather_passes = 0;
 
     SE3 guess;
     double max_dist, ks;
@@ -339,19 +405,63 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
-        const double *src = (it == 0) ? P.frame : P.work;
-        for (int p = blockIdx.x * kIcpGroupsPerBlock + grp; p < n; p += G * kIcpGroupsPerBlock) {
-            const double pin[3] = {src[3 * p], src[3 * p + 1], src[3 * p + 2]};
+        int round = 0;
+        for (int p = blockIdx.x * kIcpGroupsPerBlock + grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
+            const int region = round * kIcpGroupsPerBlock + grp;
+            const bool has_region = (round < P.points_per_group) && cap_q > 0 && m.max_points <= 32 && region < n_regions;
+            IcpRegionMeta *meta = reinterpret_cast<IcpRegionMeta *>(region_base) + region;
+            double *cand = reinterpret_cast<double *>(region_base + (size_t)n_regions * sizeof(IcpRegionMeta)) +
+                           (size_t)region * 3 * cap_q;
+            double pin[3];
+            if (it > 0 && has_region) {  // running source point lives in LDS
+                pin[0] = meta->s[0];
+                pin[1] = meta->s[1];
+                pin[2] = meta->s[2];
+            } else {
+                const double *src = (it == 0) ? P.frame : P.work;
+                pin[0] = src[3 * p];
+                pin[1] = src[3 * p + 1];
+                pin[2] = src[3 * p + 2];
+            }
             double s[3];
             se3_act(est, pin, s);
+            const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size),
+                      vz = voxel_coord(s[2], m.voxel_size);
+            bool cached = false;
+            int E = 0;
+            if (has_region && it > 0) {
+                cached = meta->valid && meta->v[0] == vx && meta->v[1] == vy && meta->v[2] == vz;
+                E = meta->E;
+            }
             if (lane == 0) {
-                P.work[3 * p] = s[0];
-                P.work[3 * p + 1] = s[1];
-                P.work[3 * p + 2] = s[2];
+                if (has_region) {
+                    meta->s[0] = s[0];
+                    meta->s[1] = s[1];
+                    meta->s[2] = s[2];
+                } else {
+                    P.work[3 * p] = s[0];
+                    P.work[3 * p + 1] = s[1];
+                    P.work[3 * p + 2] = s[2];
+                }
             }
             double nn[3];
             int ex;
-            const double d2 = closest_neighbor_any(m, s[0], s[1], s[2], lane, nn, ex, range_err);
+            double d2;
+            if (cached) {
+                d2 = group_closest_neighbor_lds(cand, cap_q, E, s[0], s[1], s[2], lane, nn);
+                ex = E;
+            } else if (has_region) {
+                d2 = group_closest_neighbor<true>(m, s[0], s[1], s[2], lane, nn, ex, range_err, cand, cap_q);
+                if (lane == 0) {
+                    meta->v[0] = vx;
+                    meta->v[1] = vy;
+                    meta->v[2] = vz;
+                    meta->E = ex;
+                    meta->valid = (ex <= cap_q);
+                }
+            } else {
+                d2 = closest_neighbor_any(m, s[0], s[1], s[2], lane, nn, ex, range_err);
+            }
             if (lane == 0) {
                 acc[17] += (double)ex;
                 if (d2 < DBL_MAX && sqrt(d2) < max_dist) {
@@ -382,6 +492,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
         const unsigned long long c1 = wall_clock64();
+        acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < kIcpSums; ++k) sh_part[grp * kIcpSums + k] = acc[k];
@@ -393,7 +504,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             const int k = tid >> 1;
             double v = 0.0;
 #pragma unroll
-            for (int g = 0; g < kIcpGroupsPerBlock; ++g) v += sh_part[g * kIcpSums + k];
+            for (int g = 0; g < kIcpGroupsPerBlock; ++g) {
+                const double pv = sh_part[g * kIcpSums + k];
+                v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+            }
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
             granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
@@ -404,6 +518,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             const int nwords = G * 2 * kIcpSums;
             unsigned spins = 0;
             for (;;) {
+                ++gather_passes;
                 bool ok = true;
                 for (int w = tid; w < nwords; w += kIcpThreads) {
                     const unsigned long long x = granule_load(gran + w);
@@ -432,7 +547,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             for (int b = b0; b < b1; ++b) {
                 const unsigned lo = sh_words[(b * kIcpSums + k) * 2];
                 const unsigned hi = sh_words[(b * kIcpSums + k) * 2 + 1];
-                v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                const double pv = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
             }
             sh_p8[part * kIcpSums + k] = v;
         }
@@ -440,7 +556,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         if (tid < kIcpSums) {
             double v = 0.0;
 #pragma unroll
-            for (int part = 0; part < 8; ++part) v += sh_p8[part * kIcpSums + tid];
+            for (int part = 0; part < 8; ++part) {
+                const double pv = sh_p8[part * kIcpSums + tid];
+                v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+            }
             sh_tot[tid] = v;
         }
         __syncthreads();
@@ -489,6 +608,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         t_publish += c2 - c1;
         t_gather += c3 - c2;
         t_solve += c4 - c3;
+        if (blockIdx.x == 0 && tid == 0 && it < kIcpProfIters) {
+            unsigned *r = st->prof_iter[it];
+            r[0] = (unsigned)(c1 - c0);
+            r[1] = (unsigned)(c2 - c1);
+            r[2] = (unsigned)(c3 - c2);
+            r[3] = (unsigned)(c4 - c3);
+            r[4] = (unsigned)S[kIcpTickSlot];  // slowest group's association time, any workgroup
+            r[5] = gather_passes;
+        }
+        gather_passes = 0;
         if (sqrt(nrm) < P.conv) {
             converged = 1;
             break;
@@ -1010,14 +1139,24 @@ static inline int grid_for(long n, int threads, int cap) {
     return (int)g;
 }
 
-size_t icp_smem_bytes(int G) {
-    return (size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpSums + 8 * kIcpSums) * sizeof(double) + 8 +
-           (size_t)G * 2 * kIcpSums * sizeof(unsigned);
+size_t icp_smem_bytes(int G, int points_per_group, int cand_cap) {
+    const size_t regions = (size_t)kIcpGroupsPerBlock * points_per_group;
+    return icp_fixed_smem(G) + regions * sizeof(IcpRegionMeta) + regions * 3 * (size_t)cand_cap * sizeof(double);
 }
 size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums; }
 
+int icp_prepare() {
+    // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute)
+    static bool done = false;
+    if (done) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+    return 0;
+}
 void launch_icp(const IcpParams &P, int G, hipStream_t s) {
-    hipLaunchKernelGGL(k_icp, dim3(G), dim3(kIcpThreads), icp_smem_bytes(G), s, P);
+    hipLaunchKernelGGL(k_icp, dim3(G), dim3(kIcpThreads), icp_smem_bytes(G, P.points_per_group, P.cand_cap), s, P);
 }
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s) {

@@ -140,6 +140,14 @@ class KissICP:
         names = ("associate_accumulate", "reduce_publish", "gather", "solve_update")
         return {"workgroups": wg.value, **{n: int(c) for n, c in zip(names, cyc)}}
 
+    def icp_iteration_profile(self):
+        """(n_iters, 6) uint32, 10 ns ticks: wg0 {associate, publish, gather, solve}, slowest group's
+        associate over all workgroups, gather polling passes"""
+        buf = np.zeros((24, 6), dtype=np.uint32)
+        n = C.c_int(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_icp_iteration_profile(self._h, _cabi.ptr(buf), 24, C.byref(n)))
+        return buf[: n.value]
+
     def stream(self):
         s = C.c_void_p()
         _cabi.check(_cabi.lib().kicp_pipeline_stream(self._h, C.byref(s)))
