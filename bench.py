@@ -164,7 +164,6 @@ def main():
         "ms_per_icp_iter": icp["total_ms"] / max(1, icp["iterations"]),
         "ms_per_frame_host_synced": sync_latency_ms,
         "async_equals_synced_trajectory": same_traj,
-        "icp_last_launch_phase_cycles": pipe.icp_profile(),
     }
     # roofline of the dominant kernel (k_icp): algorithmic bytes of AlignPointsToMap
     # (per iteration N_src*(24+24) + N_src*27*16 + E*24 + 336) / device time

@@ -227,7 +227,11 @@ int kicp_device_synchronize(int device_id);
  *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src
  *                     on the device: ceil(N_src / (8 * icp_points_per_group)), at most 256)
  *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 2)
+ *   "icp_cand_target" candidates an LDS-staged neighbourhood should hold at least (default 256;
+ *                     0 = never stage candidate voxels in LDS)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
+ *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
+ *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)
  * ---------------------------------------------------------------------------------------- */
 int kicp_set_option(const char *name, long value);
 

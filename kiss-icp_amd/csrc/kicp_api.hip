@@ -95,18 +95,7 @@ static int icp_launch_blocks() { return kIcpMaxBlocks; }
 static void icp_fill_policy(IcpParams &P) {
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 2);
-    // LDS budget for the candidate regions: what is left of 160 KiB after the fixed part, split
-    // over 8 * points_per_group regions, rounded down to a multiple of 32 candidates
-    long cap = options().icp_cand_cap;
-    if (cap < 0) {
-        const long budget = 156 * 1024 - (long)icp_fixed_smem(icp_launch_blocks());
-        const long regions = (long)kIcpGroupsPerBlock * P.points_per_group;
-        cap = (budget / regions - (long)sizeof(IcpRegionMeta)) / 24;
-        cap = (cap / 32) * 32;
-        if (cap > 1024) cap = 1024;
-        if (cap < 0) cap = 0;
-    }
-    P.cand_cap = (int)cap;
+    P.cand_target = (int)options().icp_cand_target;
 }
 
 }  // namespace kicp
@@ -560,7 +549,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
     P.granules = r->granules.as<unsigned long long>();
     P.spin_limit = kSpinLimit;
     KICP_HIP(hipEventRecord(r->ev0, r->stream));
-    launch_icp(P, G, r->stream);
+    launch_icp(P, G, options().icp_profile != 0, r->stream);
     KICP_HIP(hipGetLastError());
     KICP_HIP(hipEventRecord(r->ev1, r->stream));
     PipeState h;
@@ -897,7 +886,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     const int slot = p->in_flight;
     const bool timing = options().icp_timing != 0 && p->ev_ok;
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][0], s));
-    launch_icp(I, G, s);
+    launch_icp(I, G, options().icp_profile != 0, s);
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][1], s));
 
     // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
@@ -1294,8 +1283,11 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_points_per_group")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;
         options().icp_points_per_group = value;
-    } else if (!strcmp(name, "icp_cand_cap")) {
-        options().icp_cand_cap = value;
+    } else if (!strcmp(name, "icp_cand_target")) {
+        if (value < 0 || value > 27 * 32) return KICP_ERR_INVALID_ARG;
+        options().icp_cand_target = value;
+    } else if (!strcmp(name, "icp_profile")) {
+        options().icp_profile = value;
     } else if (!strcmp(name, "icp_timing")) {
         options().icp_timing = value;
     } else {

@@ -157,7 +157,8 @@ struct IcpParams {
     int points_per_group;  // target points per 32-lane group and iteration (sets how many
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
-    int cand_cap;          // candidates per LDS region (0 disables LDS staging)
+    int cand_target;       // candidates an LDS region should hold at least (0 disables LDS staging)
+    int lds_bytes;         // dynamic LDS of the launch (set by launch_icp)
 };
 
 // ---- host-side objects ------------------------------------------------------------------------
@@ -183,7 +184,8 @@ const char *get_error();
 struct Options {
     long icp_blocks = 0;
     long icp_points_per_group = 2;
-    long icp_cand_cap = -1;  // < 0: size the LDS candidate regions automatically; 0: no LDS staging
+    long icp_cand_target = 256;  // candidates an LDS region should hold at least; 0: no LDS staging
+    long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
 };
 Options &options();

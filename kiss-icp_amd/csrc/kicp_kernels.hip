@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void k_closest_neighbor(MapView m, const doubl
 // and every workgroup solves the same 6x6 system redundantly: dx = LDLT(JTJ).solve(-JTr),
 // est = exp(dx), T_icp = est * T_icp, stop when |dx| < convergence_criterion (:156-163).
 // ------------------------------------------------------------------------------------------
+template <bool PROF>
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sh_part = reinterpret_cast<double *>(smem);                     // [8][kIcpSums]
@@ -349,11 +350,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     double *sh_p8 = sh_tot + kIcpSums;                                       // [8][kIcpSums]
     int *sh_failp = reinterpret_cast<int *>(sh_p8 + 8 * kIcpSums);          // [2] (8 bytes)
     unsigned *sh_words = reinterpret_cast<unsigned *>(sh_failp + 2);        // [gridDim.x][2*kIcpSums]
-    // per (round, group) candidate regions: meta {s[3] running source point; v[3] voxel; E; valid}
-    // + candidates {x[cap], y[cap], z[cap]}
-    const int n_regions = kIcpGroupsPerBlock * P.points_per_group;
-    const int cap_q = P.cand_cap;
-    char *region_base = smem + icp_fixed_smem((int)gridDim.x);
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
     // shift its base off 8/16-byte alignment)
 
@@ -370,6 +366,23 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                : (n + kIcpGroupsPerBlock * P.points_per_group - 1) / (kIcpGroupsPerBlock * P.points_per_group);
     G = max(1, min(G, (int)gridDim.x));
     if ((int)blockIdx.x >= G) return;
+    // per (round, group) candidate regions: meta {s[3] running source point; v[3] voxel; E; valid}
+    // + candidates {x[cap], y[cap], z[cap]}.  The exchange scratch is sized by G, the rest of the
+    // workgroup's LDS is split over the rounds a group walks per iteration (as many of them as
+    // still leave P.cand_target candidates per region).
+    const int rounds = (n + G * kIcpGroupsPerBlock - 1) / (G * kIcpGroupsPerBlock);
+    char *region_base = smem + icp_fixed_smem(G);
+    int cached_rounds = 0, cap_q = 0;
+    if (P.cand_target > 0 && m.max_points <= 32) {
+        const int budget = P.lds_bytes - (int)icp_fixed_smem(G);
+        const int per_region_min = (int)sizeof(IcpRegionMeta) + 24 * P.cand_target;
+        cached_rounds = max(0, min(rounds, budget / (kIcpGroupsPerBlock * per_region_min)));
+        if (cached_rounds > 0) {
+            cap_q = (budget / (kIcpGroupsPerBlock * cached_rounds) - (int)sizeof(IcpRegionMeta)) / 24;
+            cap_q = min(cap_q & ~31, 27 * 32);
+        }
+    }
+    const int n_regions = kIcpGroupsPerBlock * cached_rounds;
     const unsigned epoch_base = st->epoch_base;
     unsigned long long t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
     unsigned gather_passes = 0;
@@ -401,14 +414,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 
     const int max_iters = map_empty ? 0 : P.max_iters;
     for (int it = 0; it < max_iters; ++it) {
-        const unsigned long long c0 = wall_clock64();
+        const unsigned long long c0 = PROF ? wall_clock64() : 0ull;
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
         int round = 0;
         for (int p = blockIdx.x * kIcpGroupsPerBlock + grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
             const int region = round * kIcpGroupsPerBlock + grp;
-            const bool has_region = (round < P.points_per_group) && cap_q > 0 && m.max_points <= 32 && region < n_regions;
+            const bool has_region = round < cached_rounds;
             IcpRegionMeta *meta = reinterpret_cast<IcpRegionMeta *>(region_base) + region;
             double *cand = reinterpret_cast<double *>(region_base + (size_t)n_regions * sizeof(IcpRegionMeta)) +
                            (size_t)region * 3 * cap_q;
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
-        const unsigned long long c1 = wall_clock64();
+        const unsigned long long c1 = PROF ? wall_clock64() : 0ull;
         acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
         if (lane == 0) {
 #pragma unroll
@@ -513,26 +526,39 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
         }
         // ---- gather every workgroup's partial (bounded spin) --------------------------------
-        const unsigned long long c2 = wall_clock64();
+        const unsigned long long c2 = PROF ? wall_clock64() : 0ull;
         {
+            // every thread fetches its own words, kGatherChunk loads in flight, and re-polls only
+            // the ones whose tag has not arrived yet (bounded)
+            constexpr int kGatherChunk = 8;
             const int nwords = G * 2 * kIcpSums;
-            unsigned spins = 0;
-            for (;;) {
-                ++gather_passes;
-                bool ok = true;
-                for (int w = tid; w < nwords; w += kIcpThreads) {
-                    const unsigned long long x = granule_load(gran + w);
-                    ok = ok && ((unsigned)(x >> 32) == epoch);
-                    sh_words[w] = (unsigned)x;
+            bool fail = false;
+            for (int w0 = tid; w0 < nwords && !fail; w0 += kGatherChunk * kIcpThreads) {
+                unsigned long long x[kGatherChunk];
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u) {
+                    const int w = w0 + u * kIcpThreads;
+                    x[u] = (w < nwords) ? granule_load(gran + w) : ((unsigned long long)epoch << 32);
                 }
-                if (ok) break;
-                if (++spins > P.spin_limit ||
-                    (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT)) {
-                    sh_failp[0] = 1;
-                    break;
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u) {
+                    const int w = w0 + u * kIcpThreads;
+                    unsigned spins = 0;
+                    while ((unsigned)(x[u] >> 32) != epoch) {
+                        if (PROF) ++gather_passes;
+                        if (++spins > P.spin_limit ||
+                            ((spins & 255u) == 0 &&
+                             (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
+                            fail = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        x[u] = granule_load(gran + w);
+                    }
+                    if (w < nwords) sh_words[w] = (unsigned)x[u];
                 }
-                __builtin_amdgcn_s_sleep(2);
             }
+            if (fail) sh_failp[0] = 1;
         }
         __syncthreads();
         if (sh_failp[0]) {
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         __syncthreads();
         // ---- every thread solves the same system (uniform, no broadcast needed) ------------
-        const unsigned long long c3 = wall_clock64();
+        const unsigned long long c3 = PROF ? wall_clock64() : 0ull;
         double S[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) S[k] = sh_tot[k];
@@ -603,12 +629,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         double nrm = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) nrm += dx[i] * dx[i];
-        const unsigned long long c4 = wall_clock64();
+        const unsigned long long c4 = PROF ? wall_clock64() : 0ull;
         t_assoc += c1 - c0;
         t_publish += c2 - c1;
         t_gather += c3 - c2;
         t_solve += c4 - c3;
-        if (blockIdx.x == 0 && tid == 0 && it < kIcpProfIters) {
+        if (PROF && blockIdx.x == 0 && tid == 0 && it < kIcpProfIters) {
             unsigned *r = st->prof_iter[it];
             r[0] = (unsigned)(c1 - c0);
             r[1] = (unsigned)(c2 - c1);
@@ -978,85 +1004,147 @@ __device__ __forceinline__ int pool_alloc(const MapView &m) {
     return (b < m.blocks_cap) ? b : -1;
 }
 
+// serial application of one voxel's list by a single lane (voxels that hold or receive more
+// points than a 32-lane group can keep in registers)
+__device__ void map_apply_voxel_serial(const MapView &m, int slot, int head, int b, const double *world,
+                                       const int *next) {
+    Slot *sl = m.slots + slot;
+    BlockHdr *hdr = block_hdr(m, b);
+    double2 *pxy = block_xy(m, b);
+    double *pz = block_z(m, b);
+    int cnt = hdr->count;
+    int last = -1;
+    while (cnt < m.max_points) {  // :104 a full voxel rejects the rest
+        int cur = 0x7FFFFFFF;    // next list entry in ascending point index (= arrival order)
+        for (int j = head; j >= 0; j = next[j])
+            if (j > last && j < cur) cur = j;
+        if (cur == 0x7FFFFFFF) break;
+        last = cur;
+        const double px = world[3 * cur], py = world[3 * cur + 1], pz_new = world[3 * cur + 2];
+        bool too_close = false;
+        for (int k = 0; k < cnt; ++k) {  // :105-108 (norm < map_resolution, strict)
+            const double dx = pxy[k].x - px, dy = pxy[k].y - py, dz = pz[k] - pz_new;
+            if (sqrt((dx * dx + dy * dy) + dz * dz) < m.map_resolution) {
+                too_close = true;
+                break;
+            }
+        }
+        if (!too_close) {
+            pxy[cnt] = make_double2(px, py);
+            pz[cnt] = pz_new;
+            ++cnt;
+        }
+    }
+    hdr->count = cnt;
+    sl->count = cnt;
+}
+
+// k_map_apply: a 32-lane group owns a tile of kApplyTile consecutive new points and serves the
+// voxel lists opened by them (the opener of a list is its tail: next == -1).  Per voxel: lane k
+// holds stored point k in registers, the new points of the list are ranked by point index
+// (= the reference's arrival order) and offered one after the other; a point is appended (to lane
+// `count`) iff the voxel is not full and no stored point -- including the ones appended a moment
+// ago -- is closer than map_resolution (VoxelHashMap.cpp:103-110).  One memory round trip for the
+// stored points, one for the new points, instead of a dependent load per comparison.
+constexpr int kApplyTile = 8;
 __global__ __launch_bounds__(256) void k_map_apply(MapView m, const int *n_ptr, int n_imm,
                                                    const double *world, const int *slot_of,
                                                    const int *next) {
     const int n = count_of(n_ptr, n_imm);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (next[i] != -1) continue;  // only the point that opened the list (its tail) leads
-        const int slot = slot_of[i];
-        Slot *sl = m.slots + slot;
-        const int head = m.heads[slot];
-        m.heads[slot] = -1;
-        int b = sl->block;
-        BlockHdr *hdr;
-        if (b < 0) {  // new voxel (VoxelHashMap.cpp:112-116)
-            b = pool_alloc(m);
-            if (b < 0) {
-                atomicOr(&m.ctr[C_ERR], E_POOL_FULL);
+    const int lane = threadIdx.x & 31;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int ngrp = (gridDim.x * blockDim.x) >> 5;
+    const int ntiles = (n + kApplyTile - 1) / kApplyTile;
+    const int half_shift = threadIdx.x & 32;  // this group's half of the 64-bit wave ballot
+    // wave-uniform trip count: the two groups of a wave walk tiles grp and grp + 1 in lock step
+    for (int tile = grp; (tile & ~1) < ntiles; tile += ngrp) {
+        const int i = tile * kApplyTile + lane;
+        int my_slot = -1;
+        if (lane < kApplyTile && i < n && next[i] == -1) my_slot = slot_of[i];
+        unsigned leaders = (unsigned)(__ballot(my_slot >= 0) >> half_shift);
+        while (__ballot(leaders != 0) != 0ull) {
+            const bool active = leaders != 0;
+            const int l = active ? (__ffs(leaders) - 1) : 0;
+            leaders &= leaders - 1;
+            const int slot = __shfl(my_slot, l, 32);
+            if (!active) continue;  // (the other group of the wave still has voxels to serve)
+            Slot *sl = m.slots + slot;
+            const int head = m.heads[slot];
+            int b = sl->block;
+            int cnt = 0;
+            if (b < 0) {  // new voxel (VoxelHashMap.cpp:112-116)
+                if (lane == 0) {
+                    b = pool_alloc(m);
+                    if (b >= 0) {
+                        BlockHdr *hdr = block_hdr(m, b);
+                        hdr->key = sl->key;
+                        hdr->slot = slot;
+                        hdr->count = 0;
+                        sl->block = b;
+                        atomicAdd(&m.ctr[C_LIVE], 1);
+                    } else {
+                        atomicOr(&m.ctr[C_ERR], E_POOL_FULL);
+                    }
+                }
+                b = __shfl(b, 0, 32);
+            } else {
+                cnt = sl->count;
+            }
+            if (lane == 0) m.heads[slot] = -1;
+            if (b < 0) continue;
+            // the list, one entry per lane (walked by every lane: uniform loads)
+            int my_idx = 0x7FFFFFFF, L = 0, walk = head;
+            for (; walk >= 0 && L < 32; walk = next[walk], ++L)
+                if (lane == L) my_idx = walk;
+            if (walk >= 0 || m.max_points > 32) {  // long list or wide voxel: serial fallback
+                if (lane == 0) map_apply_voxel_serial(m, slot, head, b, world, next);
                 continue;
             }
-            sl->block = b;
-            hdr = block_hdr(m, b);
-            hdr->key = sl->key;
-            hdr->slot = slot;
-            hdr->count = 0;
-            atomicAdd(&m.ctr[C_LIVE], 1);
-        } else {
-            hdr = block_hdr(m, b);
-        }
-        double2 *pxy = block_xy(m, b);
-        double *pz = block_z(m, b);
-        int cnt = hdr->count;
-        // visit the list in ascending point index (= the reference's arrival order).  Common case:
-        // one pass over the chain into a small local array, insertion sort, then apply; a voxel
-        // that received more than kMaxLocal points falls back to repeated selection.
-        constexpr int kMaxLocal = 32;
-        int idx[kMaxLocal];
-        int L = 0;
-        int walk = head;
-        for (; walk >= 0 && L < kMaxLocal; walk = next[walk]) idx[L++] = walk;
-        const bool overflow = (walk >= 0);  // more than kMaxLocal new points in this voxel
-        auto try_add = [&](int cur) {
-            const double px = world[3 * cur], py = world[3 * cur + 1], pz_new = world[3 * cur + 2];
-            bool too_close = false;
-            for (int k = 0; k < cnt; ++k) {  // :105-108 (norm < map_resolution, strict)
-                const double dx = pxy[k].x - px, dy = pxy[k].y - py, dz = pz[k] - pz_new;
-                if (sqrt((dx * dx + dy * dy) + dz * dz) < m.map_resolution) {
-                    too_close = true;
-                    break;
+            double2 *pxy = block_xy(m, b);
+            double *pz = block_z(m, b);
+            double ex = 0.0, ey = 0.0, ez = 0.0;  // stored point `lane`
+            if (lane < cnt) {
+                const double2 xy = pxy[lane];
+                ex = xy.x;
+                ey = xy.y;
+                ez = pz[lane];
+            }
+            double nx = 0.0, ny = 0.0, nz = 0.0;  // new point held by this lane
+            if (lane < L) {
+                nx = world[3 * my_idx];
+                ny = world[3 * my_idx + 1];
+                nz = world[3 * my_idx + 2];
+            }
+            int rank = 0;  // position of this lane's point in ascending point index
+            for (int j = 0; j < L; ++j) rank += (__shfl(my_idx, j, 32) < my_idx) ? 1 : 0;
+            const int cnt0 = cnt;
+            for (int r = 0; r < L && cnt < m.max_points; ++r) {  // :104 a full voxel rejects the rest
+                const unsigned who = (unsigned)(__ballot(lane < L && rank == r) >> half_shift);
+                const int src = __ffs(who) - 1;
+                const double qx = __shfl(nx, src, 32), qy = __shfl(ny, src, 32), qz = __shfl(nz, src, 32);
+                bool close = false;
+                if (lane < cnt) {  // :105-108 (norm < map_resolution, strict)
+                    const double dx = ex - qx, dy = ey - qy, dz = ez - qz;
+                    close = sqrt((dx * dx + dy * dy) + dz * dz) < m.map_resolution;
+                }
+                if (((unsigned)(__ballot(close) >> half_shift)) == 0u) {
+                    if (lane == cnt) {
+                        ex = qx;
+                        ey = qy;
+                        ez = qz;
+                    }
+                    ++cnt;
                 }
             }
-            if (!too_close) {
-                pxy[cnt] = make_double2(px, py);
-                pz[cnt] = pz_new;
-                ++cnt;
+            if (lane >= cnt0 && lane < cnt) {
+                pxy[lane] = make_double2(ex, ey);
+                pz[lane] = ez;
             }
-        };
-        if (!overflow) {
-            for (int a = 1; a < L; ++a) {
-                const int v = idx[a];
-                int c = a - 1;
-                while (c >= 0 && idx[c] > v) {
-                    idx[c + 1] = idx[c];
-                    --c;
-                }
-                idx[c + 1] = v;
-            }
-            for (int a = 0; a < L && cnt < m.max_points; ++a) try_add(idx[a]);  // :104 full voxel rejects the rest
-        } else {
-            int last = -1;
-            while (cnt < m.max_points) {
-                int cur = 0x7FFFFFFF;
-                for (int j = head; j >= 0; j = next[j])
-                    if (j > last && j < cur) cur = j;
-                if (cur == 0x7FFFFFFF) break;
-                last = cur;
-                try_add(cur);
+            if (lane == 0) {
+                block_hdr(m, b)->count = cnt;
+                sl->count = cnt;
             }
         }
-        hdr->count = cnt;
-        sl->count = cnt;
     }
 }
 
@@ -1139,24 +1227,29 @@ static inline int grid_for(long n, int threads, int cap) {
     return (int)g;
 }
 
-size_t icp_smem_bytes(int G, int points_per_group, int cand_cap) {
-    const size_t regions = (size_t)kIcpGroupsPerBlock * points_per_group;
-    return icp_fixed_smem(G) + regions * sizeof(IcpRegionMeta) + regions * 3 * (size_t)cand_cap * sizeof(double);
-}
 size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums; }
+
+constexpr int kIcpLdsBytes = 160 * 1024;  // one workgroup per CU owns the whole LDS
 
 int icp_prepare() {
     // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute)
     static bool done = false;
     if (done) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
     if (e != hipSuccess) return (int)e;
     done = true;
     return 0;
 }
-void launch_icp(const IcpParams &P, int G, hipStream_t s) {
-    hipLaunchKernelGGL(k_icp, dim3(G), dim3(kIcpThreads), icp_smem_bytes(G, P.points_per_group, P.cand_cap), s, P);
+void launch_icp(IcpParams P, int G, bool profile, hipStream_t s) {
+    P.lds_bytes = kIcpLdsBytes;
+    if (profile)
+        hipLaunchKernelGGL(k_icp<true>, dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+    else
+        hipLaunchKernelGGL(k_icp<false>, dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
 }
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s) {
@@ -1189,8 +1282,9 @@ void launch_map_link(const MapView &m, const double *in, const int *n_ptr, int n
 }
 void launch_map_apply(const MapView &m, const int *n_ptr, int n_imm, int n_max, const double *world,
                       const int *slot_of, const int *next, hipStream_t s) {
-    hipLaunchKernelGGL(k_map_apply, dim3(grid_for(n_max, 256, 2048)), dim3(256), 0, s, m, n_ptr, n_imm, world,
-                       slot_of, next);
+    // one 32-lane group per tile of kApplyTile points
+    hipLaunchKernelGGL(k_map_apply, dim3(grid_for(((long)n_max + kApplyTile - 1) / kApplyTile * 32, 256, 2048)), dim3(256), 0,
+                       s, m, n_ptr, n_imm, world, slot_of, next);
 }
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
                       const double origin[3], PipeState *reset_state, hipStream_t s) {

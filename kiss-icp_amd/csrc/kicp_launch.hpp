@@ -48,10 +48,9 @@ struct DsParams {
     int *err;
 };
 
-size_t icp_smem_bytes(int G, int points_per_group, int cand_cap);
 int icp_prepare();
 size_t icp_granule_words(int G);
-void launch_icp(const IcpParams &P, int G, hipStream_t s);
+void launch_icp(IcpParams P, int G, bool profile, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s);
 void launch_ts_minmax(const double *ts, int n_ts, PipeState *st, hipStream_t s);

@@ -242,7 +242,7 @@ KICP_HD SE3 se3_exp(const double a[6]) {
     SE3 out;
     const double w[3] = {a[3], a[4], a[5]};
     const double theta_sq = sqnorm3(w[0], w[1], w[2]);
-    double imag, real, theta;
+    double imag, real, theta, sh = 0.0, ch = 1.0;
     if (theta_sq < kSophusEps * kSophusEps) {
         theta = 0.0;
         const double theta_po4 = theta_sq * theta_sq;
@@ -250,9 +250,9 @@ KICP_HD SE3 se3_exp(const double a[6]) {
         real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
     } else {
         theta = sqrt(theta_sq);
-        const double half = 0.5 * theta;
-        imag = sin(half) / theta;
-        real = cos(half);
+        sincos(0.5 * theta, &sh, &ch);  // one range reduction serves all four trig values below
+        imag = sh / theta;
+        real = ch;
     }
     out.q[0] = imag * w[0];
     out.q[1] = imag * w[1];
@@ -264,9 +264,14 @@ KICP_HD SE3 se3_exp(const double a[6]) {
     if (theta < kSophusEps) {
         quat_to_R(out.q, V);
     } else {
+        // Sophus: (1 - cos(theta)) / theta^2 and (theta - sin(theta)) / theta^3.  cos(theta) and
+        // sin(theta) come from the half angle (cos = 1 - 2 sin^2(theta/2), sin = 2 sin cos) and are
+        // rounded to double before the subtraction, like the library calls they replace.
         const double theta2 = theta * theta;
-        const double c1 = (1.0 - cos(theta)) / theta2;
-        const double c2 = (theta - sin(theta)) / (theta2 * theta);
+        const double cos_t = 1.0 - 2.0 * sh * sh;
+        const double sin_t = 2.0 * sh * ch;
+        const double c1 = (1.0 - cos_t) / theta2;
+        const double c2 = (theta - sin_t) / (theta2 * theta);
 #pragma unroll
         for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * Om[i] + c2 * Om2[i];
     }

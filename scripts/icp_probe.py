@@ -7,6 +7,7 @@ from kiss_icp_amd.config import load_config
 from kiss_icp_amd.datasets import kitti_like
 from kiss_icp_amd.kiss_icp import KissICP
 opts = dict(a.split('=') for a in sys.argv[1:])
+opts.setdefault('icp_profile', '1')
 for k, v in opts.items():
     _cabi.set_option(k, int(v))
 nf = 14

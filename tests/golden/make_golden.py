@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Generates the fixtures in tests/golden/ -- TEST INFRASTRUCTURE.
+
+The reference (PRBonn/kiss-icp v1.2.3) holds no golden vectors for the registration path and cannot
+be built or imported in this environment (its hot path is C++ behind pybind; Eigen / Sophus /
+robin-map / TBB are fetched from the network at configure time).  These fixtures are therefore
+produced by the CPU oracle (oracle/kiss_oracle.c) AFTER it has been cross-checked against the
+independent naive restatement tests/naive_ref.py on the very same inputs (asserted below), and they
+pin both: tests/test_oracle.py re-derives them on CPU, tests/test_gpu_parity.py compares the HIP
+path with them on the GPU box (where neither /root/reference nor a second implementation exist).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "kiss-icp_amd", "python"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import naive_ref as N  # noqa: E402
+from helpers import make_pose, pose_error, random_cloud, sort_rows  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def downsample():
+    rng = np.random.default_rng(101)
+    pts = random_cloud(rng, 3000, extent=12.0, z_extent=2.0)
+    out = {"points": pts}
+    for v, key in ((0.5, "out_050"), (1.5, "out_150")):
+        o = O.voxel_down_sample(pts, v)
+        assert np.array_equal(o, N.voxel_downsample(pts, v))
+        out[key] = o
+    np.savez_compressed(os.path.join(HERE, "downsample.npz"), **out)
+
+
+def map_nn():
+    rng = np.random.default_rng(102)
+    om, nm = O.VoxelHashMap(1.0, 30.0, 20), N.VoxelHashMap(1.0, 30.0, 20)
+    out = {"n_updates": 4}
+    for k in range(4):
+        pts = random_cloud(rng, 1200, extent=14.0, z_extent=2.0)
+        T = make_pose((6.0 * k, 0.7 * k, 0.0), (0.0, 0.0, 0.08 * k))
+        om.update(pts, T)
+        nm.update(pts, T)
+        out[f"pts_{k}"], out[f"pose_{k}"] = pts, T
+    cloud = sort_rows(om.point_cloud())
+    np.testing.assert_allclose(cloud, sort_rows(nm.point_cloud()), rtol=0, atol=1e-12)
+    q = random_cloud(rng, 400, extent=40.0, z_extent=3.0)
+    q[:, 0] += 9.0
+    nn = np.array([om.closest_neighbor(x)[0] for x in q])
+    dd = np.array([om.closest_neighbor(x)[1] for x in q])
+    for x, a, b in zip(q, nn, dd):
+        na, nb = nm.closest_neighbor(x)
+        assert abs(nb - b) <= 1e-12 * max(1.0, min(b, 1e3)) and np.allclose(na, a, rtol=0, atol=1e-12)
+    out.update(cloud_sorted=cloud, queries=q, nn=nn, dist=dd)
+    np.savez_compressed(os.path.join(HERE, "map_nn.npz"), **out)
+
+
+def align():
+    rng = np.random.default_rng(103)
+    world = np.concatenate([
+        np.stack([rng.uniform(-9, 9, 1200), rng.uniform(-9, 9, 1200), rng.normal(0, 0.01, 1200)], axis=1),
+        np.stack([np.full(600, 7.0) + rng.normal(0, 0.01, 600), rng.uniform(-9, 9, 600), rng.uniform(0, 4, 600)], axis=1),
+        np.stack([rng.uniform(-9, 9, 600), np.full(600, -6.0) + rng.normal(0, 0.01, 600), rng.uniform(0, 4, 600)], axis=1),
+    ])
+    om, nm = O.VoxelHashMap(1.0, 100.0, 20), N.VoxelHashMap(1.0, 100.0, 20)
+    om.add_points(world)
+    nm.add_points(world)
+    T_true = make_pose((0.3, -0.2, 0.04), (0.01, -0.015, 0.04))
+    frame = (world[rng.choice(len(world), 300, replace=False)] - T_true[:3, 3]) @ T_true[:3, :3]
+    guess = make_pose((0.05, 0.0, 0.0), (0.0, 0.0, 0.005))
+    reg = O.Registration(500, 1e-4, 1)
+    T = reg.align_points_to_map(frame, om, guess, 3.0, 1.0)
+    Tn, it = N.align_points_to_map(frame, nm, guess, 3.0, 1.0)
+    assert it == reg.last_stats["iterations"], (it, reg.last_stats)
+    dt, dr = pose_error(T, Tn)
+    assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+    np.savez_compressed(os.path.join(HERE, "align.npz"), world=world, frame=frame, guess=guess, max_dist=3.0, kernel=1.0,
+                        T=T, iterations=reg.last_stats["iterations"])
+
+
+def sequence():
+    from kiss_icp_amd.datasets import kitti_like
+
+    seed, n_frames, beams, az = 5, 12, 16, 200
+    ds = kitti_like(seed=seed, n_frames=n_frames, beams=beams, azimuth_steps=az)
+    ko, kn = O.KissICP(deskew=0, max_num_threads=1), N.KissICP(deskew=False)
+    out = {"seed": seed, "n_frames": n_frames, "beams": beams, "azimuth_steps": az}
+    poses, iters = [], []
+    for i in range(n_frames):
+        pts, ts = ds[i]
+        ko.register_frame(pts, ts)
+        kn.register_frame(pts, ts)
+        dt, dr = pose_error(ko.last_pose, kn.last_pose)
+        assert dt < 1e-9 and dr < 1e-9, (i, dt, dr)
+        out[f"scan_{i}"] = pts
+        poses.append(ko.last_pose)
+        iters.append(ko.last_stats()["iterations"])
+    out["poses"] = np.array(poses)
+    out["iterations"] = np.array(iters)
+    np.savez_compressed(os.path.join(HERE, "sequence.npz"), **out)
+
+
+if __name__ == "__main__":
+    downsample()
+    map_nn()
+    align()
+    sequence()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
