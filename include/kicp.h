@@ -225,10 +225,10 @@ int kicp_device_synchronize(int device_id);
 /* ------------------------------------------------------------------------------------------
  * tuning knobs (process-wide; read when a handle is created).  Unknown names are an error.
  *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src
- *                     on the device: ceil(N_src / (8 * icp_points_per_group)), at most 256)
- *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 2)
- *   "icp_cand_target" candidates an LDS-staged neighbourhood should hold at least (default 256;
- *                     0 = never stage candidate voxels in LDS)
+ *                     on the device: ceil(N_src / (16 * icp_points_per_group)), at most 256)
+ *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 1)
+ *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
+ *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
  *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
  *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)

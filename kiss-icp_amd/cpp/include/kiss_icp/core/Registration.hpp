@@ -1,0 +1,37 @@
+// Registration.hpp -- mirrors cpp/kiss_icp/core/Registration.hpp:33-45 of PRBonn/kiss-icp v1.2.3.
+#pragma once
+
+#include <vector>
+
+#include "Linalg.hpp"
+#include "VoxelHashMap.hpp"
+
+struct kicp_registration;
+
+namespace kiss_icp {
+
+struct Registration {
+    explicit Registration(int max_num_iteration, double convergence_criterion, int max_num_threads);
+    Registration(int max_num_iteration, double convergence_criterion, int max_num_threads, int device_id);
+    ~Registration();
+    Registration(const Registration &) = delete;
+    Registration &operator=(const Registration &) = delete;
+
+    Sophus::SE3d AlignPointsToMap(const std::vector<Eigen::Vector3d> &frame,
+                                  const VoxelHashMap &voxel_map,
+                                  const Sophus::SE3d &initial_guess,
+                                  const double max_correspondence_distance,
+                                  const double kernel_scale);
+
+    int max_num_iterations_;
+    double convergence_criterion_;
+    int max_num_threads_;  // kept for signature compatibility; the device schedules itself
+
+    // statistics of the last call (iterations executed, correspondences, map points examined)
+    int last_iterations_ = 0;
+    bool last_converged_ = false;
+    unsigned long long last_points_examined_ = 0;
+
+    kicp_registration *handle_ = nullptr;
+};
+}  // namespace kiss_icp

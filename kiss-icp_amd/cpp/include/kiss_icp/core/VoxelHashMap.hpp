@@ -1,0 +1,49 @@
+// VoxelHashMap.hpp -- mirrors cpp/kiss_icp/core/VoxelHashMap.hpp:38-57 of PRBonn/kiss-icp v1.2.3.
+// Same constructor and methods; the map itself lives in HBM behind a kicp_map handle
+// (include/kicp.h) instead of a tsl::robin_map member.
+#pragma once
+
+#include <tuple>
+#include <vector>
+
+#include "Linalg.hpp"
+#include "VoxelUtils.hpp"
+
+struct kicp_map;
+
+namespace kiss_icp {
+struct VoxelHashMap {
+    explicit VoxelHashMap(double voxel_size, double max_distance, unsigned int max_points_per_voxel);
+    VoxelHashMap(double voxel_size, double max_distance, unsigned int max_points_per_voxel, int device_id);
+    ~VoxelHashMap();
+    VoxelHashMap(const VoxelHashMap &) = delete;  // one owner per device map
+    VoxelHashMap &operator=(const VoxelHashMap &) = delete;
+    VoxelHashMap(VoxelHashMap &&other) noexcept;
+
+    void Clear();
+    bool Empty() const;
+    void Update(const std::vector<Eigen::Vector3d> &points, const Eigen::Vector3d &origin);
+    void Update(const std::vector<Eigen::Vector3d> &points, const Sophus::SE3d &pose);
+    void AddPoints(const std::vector<Eigen::Vector3d> &points);
+    void RemovePointsFarFromLocation(const Eigen::Vector3d &origin);
+    std::vector<Eigen::Vector3d> Pointcloud() const;
+    std::tuple<Eigen::Vector3d, double> GetClosestNeighbor(const Eigen::Vector3d &query) const;
+    /// batched form of GetClosestNeighbor (one kernel launch for all queries)
+    std::vector<std::tuple<Eigen::Vector3d, double>> GetClosestNeighbors(
+        const std::vector<Eigen::Vector3d> &queries) const;
+    std::size_t NumVoxels() const;
+
+    double voxel_size_;
+    double max_distance_;
+    unsigned int max_points_per_voxel_;
+
+    // the device map; `owned_` is false for the view returned by pipeline::KissICP::VoxelMap()
+    kicp_map *handle_ = nullptr;
+    bool owned_ = true;
+    static VoxelHashMap Borrow(kicp_map *handle, double voxel_size, double max_distance,
+                               unsigned int max_points_per_voxel);
+
+private:
+    VoxelHashMap() = default;
+};
+}  // namespace kiss_icp

@@ -1,0 +1,39 @@
+// VoxelUtils.hpp -- mirrors cpp/kiss_icp/core/VoxelUtils.hpp:24-51 of PRBonn/kiss-icp v1.2.3.
+// PointToVoxel and the Voxel hash are plain host arithmetic; VoxelDownsample runs on the GPU
+// (kicp_voxel_downsample, include/kicp.h).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+#include "Linalg.hpp"
+
+namespace kiss_icp {
+
+using Voxel = Eigen::Vector3i;
+inline Voxel PointToVoxel(const Eigen::Vector3d &point, const double voxel_size) {
+    return Voxel(static_cast<int>(std::floor(point.x() / voxel_size)),
+                 static_cast<int>(std::floor(point.y() / voxel_size)),
+                 static_cast<int>(std::floor(point.z() / voxel_size)));
+}
+
+/// Voxelize a point cloud keeping the original coordinates (first point of every voxel; output in
+/// ascending input order -- the reference's order is its hash map's bucket order, unspecified)
+std::vector<Eigen::Vector3d> VoxelDownsample(const std::vector<Eigen::Vector3d> &frame,
+                                             const double voxel_size);
+
+/// device used by the free functions and by objects created without an explicit device (default 0)
+void SetDefaultDevice(int device_id);
+int DefaultDevice();
+
+}  // namespace kiss_icp
+
+template <>
+struct std::hash<kiss_icp::Voxel> {
+    std::size_t operator()(const kiss_icp::Voxel &voxel) const {
+        const uint32_t *vec = reinterpret_cast<const uint32_t *>(voxel.data());
+        return (vec[0] * 73856093 ^ vec[1] * 19349669 ^ vec[2] * 83492791);
+    }
+};

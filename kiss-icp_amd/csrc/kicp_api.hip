@@ -94,8 +94,8 @@ static int err_bits_to_status(int bits) {
 static int icp_launch_blocks() { return kIcpMaxBlocks; }
 static void icp_fill_policy(IcpParams &P) {
     P.force_blocks = (int)options().icp_blocks;
-    P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 2);
-    P.cand_target = (int)options().icp_cand_target;
+    P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 1);
+    P.use_lds = options().icp_use_lds != 0;
 }
 
 }  // namespace kicp
@@ -115,6 +115,7 @@ MapView kicp_map::view() const {
     v.blocks_cap = blocks_cap;
     v.ctr = ctr.as<int>();
     v.free_ids = free_ids.as<int>();
+    v.free_cap = blocks_cap;
     v.heads = heads.as<int>();
     v.z_off = kBlockHeader + 16 * (int)max_points;
     v.voxel_size = voxel_size;
@@ -128,6 +129,31 @@ int kicp_map::refresh_counters() {
     KICP_HIP(hipStreamSynchronize(stream));
     used_ub = h_ctr[C_USED];
     bump_ub = h_ctr[C_BUMP] < blocks_cap ? h_ctr[C_BUMP] : blocks_cap;
+    return KICP_OK;
+}
+
+int kicp_map::scratch_reserve(size_t n_max, InsertScratch &sc) {
+    if (n_max == 0) n_max = 1;
+    KICP_TRY(world.reserve(n_max * 3 * sizeof(double)));
+    KICP_TRY(next.reserve(n_max * sizeof(int)));
+    KICP_TRY(rec_slot.reserve(n_max * sizeof(int)));
+    KICP_TRY(rec_list.reserve(n_max * kRecList * sizeof(int)));
+    // idle state of a record: count 0, head -1 (every insert leaves its records idle again)
+    if (rec_count.bytes < n_max * sizeof(int)) {
+        KICP_TRY(rec_count.reserve(n_max * sizeof(int)));
+        KICP_HIP(hipMemsetAsync(rec_count.p, 0, rec_count.bytes, stream));
+    }
+    if (rec_head.bytes < n_max * sizeof(int)) {
+        KICP_TRY(rec_head.reserve(n_max * sizeof(int)));
+        KICP_HIP(hipMemsetAsync(rec_head.p, 0xFF, rec_head.bytes, stream));
+    }
+    sc.world = world.as<double>();
+    sc.next = next.as<int>();
+    sc.rec_slot = rec_slot.as<int>();
+    sc.rec_count = rec_count.as<int>();
+    sc.rec_head = rec_head.as<int>();
+    sc.rec_list = rec_list.as<int>();
+    sc.parity = (int)(insert_seq++ & 1u);
     return KICP_OK;
 }
 
@@ -191,7 +217,24 @@ int kicp_map::ensure_capacity(size_t incoming) {
         const size_t old_bytes = (size_t)blocks_cap * stride;
         KICP_TRY(blocks.reserve(want * stride + 64, true, stream));
         KICP_HIP(hipMemsetAsync(blocks.as<char>() + old_bytes, 0, want * stride + 64 - old_bytes, stream));
-        KICP_TRY(free_ids.reserve(want * sizeof(int), true, stream));
+        // the free-block ring is indexed modulo its capacity: re-linearise the live entries
+        // [head, pend) at the front of the larger ring (h_ctr was refreshed above)
+        {
+            unsigned head = (unsigned)h_ctr[C_FHEAD];
+            const unsigned tail = (unsigned)h_ctr[C_FTAIL], pend = (unsigned)h_ctr[C_FPEND];
+            if ((int)(tail - head) < 0) head = tail;
+            const size_t count = (size_t)(pend - head);
+            std::vector<int> old_ring((size_t)blocks_cap), lin(count ? count : 1);
+            KICP_HIP(hipMemcpyAsync(old_ring.data(), free_ids.p, (size_t)blocks_cap * sizeof(int), hipMemcpyDeviceToHost, stream));
+            KICP_HIP(hipStreamSynchronize(stream));
+            for (size_t i = 0; i < count; ++i) lin[i] = old_ring[(head + (unsigned)i) % (unsigned)blocks_cap];
+            KICP_TRY(free_ids.reserve(want * sizeof(int)));
+            if (count) KICP_HIP(hipMemcpyAsync(free_ids.p, lin.data(), count * sizeof(int), hipMemcpyHostToDevice, stream));
+            const int cur[3] = {0, (int)count, (int)count};
+            KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FHEAD, &cur[0], sizeof(int), hipMemcpyHostToDevice, stream));
+            KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FTAIL, &cur[1], 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+            KICP_HIP(hipStreamSynchronize(stream));
+        }
         blocks_cap = (int)want;
     }
     return KICP_OK;
@@ -273,8 +316,11 @@ int kicp_map_destroy(kicp_map *m) {
     m->ctr.release();
     m->pts_in.release();
     m->world.release();
-    m->slot_of.release();
     m->next.release();
+    m->rec_slot.release();
+    m->rec_count.release();
+    m->rec_head.release();
+    m->rec_list.release();
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return KICP_OK;
@@ -323,14 +369,11 @@ static int map_insert_device(kicp_map *m, const double *d_in, const int *n_ptr, 
     // AddPoints on points already in HBM (shared by the standalone calls and the pipeline)
     if (n_max == 0) return KICP_OK;
     KICP_TRY(m->ensure_capacity(n_max));
-    KICP_TRY(m->world.reserve(n_max * 3 * sizeof(double)));
-    KICP_TRY(m->slot_of.reserve(n_max * sizeof(int)));
-    KICP_TRY(m->next.reserve(n_max * sizeof(int)));
+    InsertScratch sc;
+    KICP_TRY(m->scratch_reserve(n_max, sc));
     const MapView v = m->view();
-    launch_map_link(v, d_in, n_ptr, n_imm, (int)n_max, state, use_pose, m->world.as<double>(),
-                    m->slot_of.as<int>(), m->next.as<int>(), m->stream);
-    launch_map_apply(v, n_ptr, n_imm, (int)n_max, m->world.as<double>(), m->slot_of.as<int>(),
-                     m->next.as<int>(), m->stream);
+    launch_map_link(v, sc, d_in, n_ptr, n_imm, (int)n_max, state, use_pose, m->stream);
+    launch_map_apply(v, sc, (int)n_max, m->stream);
     KICP_HIP(hipGetLastError());
     m->used_ub += (long)n_max;
     m->bump_ub += (long)n_max;
@@ -359,7 +402,7 @@ int kicp_map_add_points(kicp_map *m, const double *xyz, size_t n) {
 int kicp_map_remove_far(kicp_map *m, const double origin[3]) {
     if (!m || !origin) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(m->device));
-    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, m->stream);
+    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -369,7 +412,7 @@ int kicp_map_update_origin(kicp_map *m, const double *xyz, size_t n, const doubl
     KICP_HIP(hipSetDevice(m->device));
     KICP_TRY(map_upload(m, xyz, n));
     KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, nullptr, 0));
-    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, m->stream);
+    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -386,7 +429,7 @@ int kicp_map_update_pose(kicp_map *m, const double *xyz, size_t n, const double 
     KICP_HIP(hipMemcpyAsync(&ms->new_pose, &T, sizeof T, hipMemcpyHostToDevice, m->stream));
     KICP_TRY(map_upload(m, xyz, n));
     KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, ms, 1));
-    launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, m->stream);
+    launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -734,18 +777,20 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
 // ==============================================================================================
 // pipeline::KissICP
 // ==============================================================================================
-struct FrameRecord {
-    PipeState st;
+struct FrameRecord {  // the first kRecWords words mirror the device layout [map counters | PipeState]
     int map_ctr[C_COUNT];
+    PipeState st;
     uint64_t n_raw;
 };
+static_assert(offsetof(FrameRecord, st) == sizeof(int) * C_COUNT, "PipeState sits right behind the map counters");
+constexpr int kRecWords = (int)((sizeof(int) * C_COUNT + sizeof(PipeState)) / sizeof(unsigned));
 
 struct kicp_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
     kicp_config cfg;
     kicp_map *map = nullptr;
-    DevBuf state, raw, ts, tmp, pre, fd, src, work, slot1, slot2, tab1, tab2, counts, granules;
+    DevBuf raw, ts, tmp, pre, fd, src, work, slot1, slot2, tab1, tab2, counts, granules;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -763,6 +808,10 @@ struct kicp_pipeline {
     uint64_t icp_launches = 0, icp_iters = 0, icp_bytes = 0;
     std::vector<double> pending_poses;  // row-major 4x4 per frame completed by the last sync
 };
+
+// The pipeline's PipeState is the one behind its map's counters, so that one contiguous block
+// [map counters | PipeState] is the whole per-frame record.
+static PipeState *pipe_state(kicp_pipeline *p) { return map_mini_state(p->map); }
 
 static int pipe_reserve(kicp_pipeline *p, size_t n) {
     if (n <= p->cap_points) return KICP_OK;
@@ -801,7 +850,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     kicp_map *m = p->map;
     KICP_TRY(m->ensure_capacity(n));
     hipStream_t s = p->stream;
-    PipeState *st = p->state.as<PipeState>();
+    PipeState *st = pipe_state(p);
     const int nblk = (int)((p->cap_points + 1023) / 1024 + 1);
     int *cnt0 = p->counts.as<int>(), *cnt1 = cnt0 + nblk, *cnt2 = cnt1 + nblk;
     const int n_i = (int)n;
@@ -890,24 +939,19 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][1], s));
 
     // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
-    KICP_TRY(m->world.reserve(p->cap_points * 3 * sizeof(double)));
-    KICP_TRY(m->slot_of.reserve(p->cap_points * sizeof(int)));
-    KICP_TRY(m->next.reserve(p->cap_points * sizeof(int)));
+    InsertScratch sc;
+    KICP_TRY(m->scratch_reserve(p->cap_points, sc));
     const MapView v = m->view();
-    launch_map_link(v, p->fd.as<double>(), &st->n_fd, 0, n_i, st, 1, m->world.as<double>(),
-                    m->slot_of.as<int>(), m->next.as<int>(), s);
-    launch_map_apply(v, &st->n_fd, 0, n_i, m->world.as<double>(), m->slot_of.as<int>(), m->next.as<int>(), s);
+    launch_map_link(v, sc, p->fd.as<double>(), &st->n_fd, 0, n_i, st, 1, s);
+    launch_map_apply(v, sc, n_i, s);
     m->used_ub += (long)n;
     m->bump_ub += (long)n;
     if (m->bump_ub > m->blocks_cap) m->bump_ub = m->blocks_cap;
-    launch_map_prune(v, m->bump_ub, st, 1, nullptr, st, s);
-    KICP_HIP(hipGetLastError());
-
-    // --- frame record -> pinned host ring ---------------------------------------------------------
+    // --- ... and the frame record, written by the kernel itself into the pinned host ring ---------
     FrameRecord *rec = p->ring + slot;
     rec->n_raw = n;
-    KICP_HIP(hipMemcpyAsync(&rec->st, st, sizeof(PipeState), hipMemcpyDeviceToHost, s));
-    KICP_HIP(hipMemcpyAsync(rec->map_ctr, m->ctr.p, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, s));
+    launch_map_prune(v, m->bump_ub, st, 1, nullptr, st, reinterpret_cast<unsigned *>(rec), kRecWords, s);
+    KICP_HIP(hipGetLastError());
     p->in_flight++;
     return KICP_OK;
 }
@@ -955,7 +999,6 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     if (s == KICP_OK)
         s = map_create_on_stream(cfg->voxel_size, cfg->max_range, (unsigned)cfg->max_points_per_voxel, device_id,
                                  p->stream, &p->map);
-    if (s == KICP_OK) s = p->state.reserve(sizeof(PipeState));
     if (s == KICP_OK && icp_prepare() != 0) {
         set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
         s = KICP_ERR_HIP;
@@ -968,7 +1011,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     }
     PipeState st;
     init_state(st, cfg->initial_threshold);
-    KICP_HIP(hipMemcpyAsync(p->state.p, &st, sizeof st, hipMemcpyHostToDevice, p->stream));
+    KICP_HIP(hipMemcpyAsync(pipe_state(p), &st, sizeof st, hipMemcpyHostToDevice, p->stream));
     KICP_HIP(hipMemsetAsync(p->granules.p, 0, p->granules.bytes, p->stream));
     KICP_HIP(hipStreamSynchronize(p->stream));
     memset(&p->last, 0, sizeof p->last);
@@ -982,7 +1025,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->map) kicp_map_destroy(p->map);
-    for (DevBuf *b : {&p->state, &p->raw, &p->ts, &p->tmp, &p->pre, &p->fd, &p->src, &p->work, &p->slot1,
+    for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd, &p->src, &p->work, &p->slot1,
                       &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules})
         b->release();
     if (p->ev_ok)
@@ -1029,7 +1072,7 @@ int kicp_pipeline_sync(kicp_pipeline *p) {
     }
     p->in_flight = 0;
     if (err_bits) {
-        PipeState *st = p->state.as<PipeState>();
+        PipeState *st = pipe_state(p);
         int zero = 0;
         KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
         KICP_HIP(hipMemcpy(p->map->ctr.as<int>() + C_ERR, &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -1090,7 +1133,7 @@ static int pipe_set_se3(kicp_pipeline *p, const double T[16], bool delta) {
         return KICP_ERR_INVALID_ARG;
     }
     if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
-    PipeState *st = p->state.as<PipeState>();
+    PipeState *st = pipe_state(p);
     KICP_HIP(hipMemcpy(delta ? &st->last_delta : &st->last_pose, &x, sizeof x, hipMemcpyHostToDevice));
     (delta ? p->last.st.last_delta : p->last.st.last_pose) = x;
     return KICP_OK;
@@ -1283,9 +1326,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_points_per_group")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;
         options().icp_points_per_group = value;
-    } else if (!strcmp(name, "icp_cand_target")) {
-        if (value < 0 || value > 27 * 32) return KICP_ERR_INVALID_ARG;
-        options().icp_cand_target = value;
+    } else if (!strcmp(name, "icp_use_lds")) {
+        options().icp_use_lds = value;
     } else if (!strcmp(name, "icp_profile")) {
         options().icp_profile = value;
     } else if (!strcmp(name, "icp_timing")) {

@@ -12,7 +12,7 @@
 //                  16-byte and one 8-byte load, both coalesced across the group -- instead of the
 //                  reference's std::vector pointer chase.  count == 0 marks a free block.
 //     heads[C]   : per-slot list head used only while inserting a frame.
-//     free_ids[] : stack of recycled block ids;  ctr[] : device counters.
+//     free_ids[] : queue (ring) of recycled block ids;  ctr[] : device counters.
 //   Frame clouds : row-major xyz f64 (the reference's std::vector<Eigen::Vector3d> layout).
 #pragma once
 
@@ -49,13 +49,19 @@ struct BlockHdr {
 
 enum MapCtr {
     C_BUMP = 0,   // blocks ever carved from the pool (high-water mark)
-    C_NFREE = 1,  // entries on the free stack
+    C_FHEAD = 1,  // free-block queue: pop cursor (may overshoot C_FTAIL during an insert; k_map_link clamps)
     C_LIVE = 2,   // live voxels
     C_TOMB = 3,   // tombstoned slots
     C_USED = 4,   // slots ever claimed since the last rehash (live + tombstones)
     C_ERR = 5,    // sticky error bits (ErrBits)
     C_NPTS = 6,   // scratch: point count of the last pointcloud query
-    C_COUNT = 8
+    C_TOUCHED0 = 8,  // voxel records opened by the running insert (two words used alternately:
+    C_TOUCHED1 = 9,  //   an insert counts in one and re-arms the other for the next insert)
+    C_FTAIL = 10,    // free-block queue: end of the entries an insert may pop
+    C_FPEND = 11,    // free-block queue: push cursor of RemovePointsFarFromLocation (merged into
+                     //   C_FTAIL by the next k_map_link)
+    C_DONE = 12,     // workgroups of k_map_prune that have finished (the last one writes the frame record)
+    C_COUNT = 16
 };
 
 enum ErrBits { E_RANGE = 1, E_TABLE_FULL = 2, E_POOL_FULL = 4, E_TIMEOUT = 8 };
@@ -68,8 +74,9 @@ struct MapView {
     int max_points;
     int blocks_cap;
     int *ctr;
-    int *free_ids;
-    int *heads;  // per-slot insertion list heads (-1 when idle)
+    int *free_ids;  // ring of recycled block ids, indexed modulo free_cap by the C_F* cursors
+    int free_cap;
+    int *heads;  // per-slot id of the voxel record opened by the running insert (-1 when idle)
     int z_off;   // byte offset of the z array inside a block = 32 + 16 * max_points
     double voxel_size;
     double max_distance;
@@ -85,6 +92,20 @@ __device__ __forceinline__ double2 *block_xy(const MapView &m, int b) {
 __device__ __forceinline__ double *block_z(const MapView &m, int b) {
     return reinterpret_cast<double *>(m.blocks + (size_t)b * m.stride + m.z_off);
 }
+
+// Scratch of one AddPoints call (sized by the number of incoming points).  k_map_link opens one
+// "voxel record" per touched voxel and files every incoming point under its voxel's record;
+// k_map_apply then serves one record per 32-lane group.
+constexpr int kRecList = 32;  // point indices kept per record (more -> serial fallback via the chain)
+struct InsertScratch {
+    double *world;  // incoming points in the map frame
+    int *next;      // per point: next point of the same voxel (chain, newest first; fallback only)
+    int *rec_slot;  // per record: hash slot of its voxel (-1: record lost its race, empty)
+    int *rec_count; // per record: incoming points filed (0 when idle)
+    int *rec_head;  // per record: chain head (-1 when idle)
+    int *rec_list;  // per record: the first kRecList point indices, unordered
+    int parity;     // which C_TOUCHED word this insert counts in
+};
 
 constexpr int kIcpProfIters = 24;
 
@@ -118,27 +139,34 @@ struct PipeState {
 constexpr int kIcpSums = 19;  // 16 normal-equation scalars + correspondence count + examined count
                               // + one profiling slot (association ticks, max-reduced)
 constexpr int kIcpTickSlot = 18;
-constexpr int kIcpThreads = 256;
+constexpr int kIcpThreads = 512;
 constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 probe lanes)
-constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;
+constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;  // 16
+constexpr int kIcpSolveThreads = 256;  // waves 0..3 (one per SIMD) solve the 6x6 system, the rest wait
+constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gather of one scalar
 constexpr int kIcpMaxBlocks = 256;
+constexpr int kIcpMaxCachedRounds = 4;  // rounds of a group whose neighbourhood may be staged in LDS
+constexpr int kIcpLdsBytes = 160 * 1024;  // one workgroup per CU owns the whole LDS
 
-// LDS region of one (round, group) query of the persistent ICP kernel
+// LDS record of one (round, group) query of the persistent ICP kernel
 struct IcpRegionMeta {
     double s[3];  // running transformed source point
-    int v[3];     // voxel the candidate list was built for
-    int E;        // candidates staged (= map points examined)
-    int valid;    // list complete (E <= capacity)
-    int pad;
+    int v[3];     // centre voxel of the staged window
+    int E;        // points staged in the window
+    int base;     // first double of the region inside the candidate pool
+    int cap;      // doubles the region owns
+    int valid;    // window complete
+    signed char lo[3], hi[3];  // window extent per axis, in voxels relative to v (-2..-1, 1..2)
+    char pad[6];
 };
-static_assert(sizeof(IcpRegionMeta) % 16 == 0, "keep the candidate arrays 16-byte aligned");
+static_assert(sizeof(IcpRegionMeta) == 64, "keep the candidate pool 16-byte aligned");
 
-// bytes of the fixed part of k_icp's dynamic LDS (reduction scratch + exchange words), 16-byte rounded
-__host__ __device__ inline size_t icp_fixed_smem(int grid_blocks) {
-    const size_t b = (size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpSums + 8 * kIcpSums) * sizeof(double) + 8 +
-                     (size_t)grid_blocks * 2 * kIcpSums * sizeof(unsigned);
-    return (b + 15) & ~(size_t)15;
-}
+// fixed part of k_icp's dynamic LDS, in bytes (the candidate pool takes the rest)
+constexpr size_t kIcpFixedLds =
+    ((size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpParts * kIcpSums + kIcpSums + 8) * sizeof(double) +  // sums + est
+     8 * sizeof(int) +                                                                                   // control words
+     (size_t)kIcpGroupsPerBlock * 64 * 8 +                                                               // window cells
+     (size_t)kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) + 15) & ~(size_t)15;
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
@@ -157,8 +185,7 @@ struct IcpParams {
     int points_per_group;  // target points per 32-lane group and iteration (sets how many
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
-    int cand_target;       // candidates an LDS region should hold at least (0 disables LDS staging)
-    int lds_bytes;         // dynamic LDS of the launch (set by launch_icp)
+    int use_lds;           // stage candidate voxels in LDS (0 disables)
 };
 
 // ---- host-side objects ------------------------------------------------------------------------
@@ -183,8 +210,8 @@ const char *get_error();
 
 struct Options {
     long icp_blocks = 0;
-    long icp_points_per_group = 2;
-    long icp_cand_target = 256;  // candidates an LDS region should hold at least; 0: no LDS staging
+    long icp_points_per_group = 1;
+    long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
 };
@@ -221,7 +248,9 @@ struct kicp_map {
     long used_ub = 0, bump_ub = 0;
     int h_ctr[kicp::C_COUNT] = {0};
     // scratch of add_points
-    kicp::DevBuf pts_in, world, slot_of, next;
+    kicp::DevBuf pts_in, world, next, rec_slot, rec_count, rec_head, rec_list;
+    unsigned insert_seq = 0;
+    int scratch_reserve(size_t n_max, kicp::InsertScratch &sc);  // sizes the buffers, picks the parity
     kicp::MapView view() const;
     int ensure_capacity(size_t incoming_points);
     int refresh_counters();  // D2H of ctr (synchronises the stream)

@@ -84,70 +84,124 @@ constexpr ShiftCodes make_shift_codes() {
 }
 constexpr ShiftCodes kShift = make_shift_codes();
 
+// Inverse of the table above: position of the shift (ox, oy, oz) in [-1, 1]^3 in the reference's
+// order, indexed by code = (ox + 1) * 9 + (oy + 1) * 3 + (oz + 1); 5 bits per entry, 12 per word.
+struct ShiftOrder {
+    unsigned long long w[3];
+};
+constexpr ShiftOrder make_shift_order() {
+    ShiftOrder o{{0, 0, 0}};
+    for (int i = 0; i < 27; ++i) {
+        const int ox = (int)((kShift.x >> (2 * i)) & 3) - 1, oy = (int)((kShift.y >> (2 * i)) & 3) - 1,
+                  oz = (int)((kShift.z >> (2 * i)) & 3) - 1;
+        const int code = (ox + 1) * 9 + (oy + 1) * 3 + (oz + 1);
+        o.w[code / 12] |= (unsigned long long)i << (5 * (code % 12));
+    }
+    return o;
+}
+constexpr ShiftOrder kOrder = make_shift_order();
+__device__ __forceinline__ int shift_order(int code) {
+    const unsigned long long w = code < 12 ? kOrder.w[0] : (code < 24 ? kOrder.w[1] : kOrder.w[2]);
+    const int k = code < 12 ? code : (code < 24 ? code - 12 : code - 24);
+    return (int)((w >> (5 * k)) & 31);
+}
+
 // GetClosestNeighbor for one query, cooperatively by a 32-lane group (two groups per wave):
-//   1. lane j < 27 probes voxel (v + shift_j): one 16-byte slot load gives block id + point count;
-//   2. the hit voxels are visited in shift order, kChunk at a time: for each, lane i < count loads
-//      point i (one 16-byte xy load + one 8-byte z load, coalesced over the group); all loads of a
-//      chunk are issued before the first distance is computed, so a chunk costs one memory round
-//      trip instead of one per point;
-//   3. every lane keeps its best (squared distance, shift j, index i); a 5-step xor-shuffle takes
+//   1. probe27: lane j < 27 probes voxel (v + shift_j): one 16-byte slot load gives block id + point
+//      count; the exclusive prefix of the counts in shift order numbers the candidates;
+//   2. scan_hits: the hit voxels are visited in shift order, kChunk at a time: for each, lane
+//      i < count loads point i (one 16-byte xy load + one 8-byte z load, coalesced over the group);
+//      all loads of a chunk are issued before the first distance is computed, so a chunk costs one
+//      memory round trip instead of one per point;
+//   3. every lane keeps its best (squared distance, candidate number); a 5-step xor-shuffle takes
 //      the lexicographic minimum = the reference's strict '<' in shift order and, inside a voxel,
 //      std::min_element's first minimum.
-// Returns the squared distance (DBL_MAX when the neighbourhood is empty), the neighbour, and the
-// number of map points examined.
 constexpr int kChunk = 9;
 
-//   FILL: additionally stage the candidates, packed in (shift, index) order, into an LDS region
-//   {x[cap], y[cap], z[cap]} so later ICP iterations of the same query never leave the CU.
-template <bool FILL>
-__device__ __forceinline__ double group_closest_neighbor(const MapView &m, double sx, double sy,
-                                                         double sz, int lane, double nn[3],
-                                                         int &examined, int &range_err,
-                                                         double *cand = nullptr, int cap = 0) {
+struct Probe {
+    int blk;   // block id of this lane's voxel or -1
+    int cnt;   // points stored in it
+    int offs;  // candidates in front of it (shift order)
+    int E;     // candidates in the whole neighbourhood (uniform over the group)
+};
+
+__device__ __forceinline__ Probe probe27(const MapView &m, double sx, double sy, double sz, int lane,
+                                         int &range_err) {
     const int vx = voxel_coord(sx, m.voxel_size);
     const int vy = voxel_coord(sy, m.voxel_size);
     const int vz = voxel_coord(sz, m.voxel_size);
-    int blk = -1, cnt = 0;
+    Probe pr;
+    pr.blk = -1;
+    pr.cnt = 0;
     if (lane < 27) {
         const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
         const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
         const int qz = vz + (int)((kShift.z >> (2 * lane)) & 3) - 1;
         if (voxel_in_range(qx, qy, qz)) {
-            blk = map_find(m, pack_voxel(qx, qy, qz), cnt);
-            if (blk < 0) cnt = 0;
+            pr.blk = map_find(m, pack_voxel(qx, qy, qz), pr.cnt);
+            if (pr.blk < 0) pr.cnt = 0;
         } else {
             range_err = 1;
         }
     }
-    // hit mask of this group (the wave holds two groups)
-    const unsigned long long ball = __ballot(blk >= 0);
-    unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
-    int offs = 0;  // exclusive prefix of the point counts in shift order = candidate base index
-    if (FILL) {
-        int incl = cnt;
+    int incl = pr.cnt;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const int o = __shfl_up(incl, off, 32);
-            if (lane >= off) incl += o;
-        }
-        offs = incl - cnt;
+    for (int off = 1; off < 32; off <<= 1) {
+        const int o = __shfl_up(incl, off, 32);
+        if (lane >= off) incl += o;
     }
+    pr.offs = incl - pr.cnt;
+    pr.E = __shfl(incl, 31, 32);
+    return pr;
+}
+
+// lexicographic min over (distance, candidate number) inside the 32-lane group; returns the
+// squared distance and the winner's coordinates in nn
+__device__ __forceinline__ double group_argmin(double best, int bkey, double bx, double by, double bz, int lane,
+                                               double nn[3]) {
+    double gbest = best;
+    int gkey = bkey, glane = lane;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(gbest, off, 32);
+        const int ok = __shfl_xor(gkey, off, 32);
+        const int ol = __shfl_xor(glane, off, 32);
+        if (ob < gbest || (ob == gbest && ok < gkey)) {
+            gbest = ob;
+            gkey = ok;
+            glane = ol;
+        }
+    }
+    nn[0] = __shfl(bx, glane, 32);
+    nn[1] = __shfl(by, glane, 32);
+    nn[2] = __shfl(bz, glane, 32);
+    return gbest;
+}
+
+//   FILL: additionally stage the candidates, packed in (shift, index) order, into an LDS region
+//   {x[stride], y[stride], z[stride]} so later ICP iterations of the same query never leave the CU.
+// Returns the squared distance (DBL_MAX when the neighbourhood is empty) and the neighbour.
+template <bool FILL>
+__device__ __forceinline__ double scan_hits(const MapView &m, const Probe &pr, double sx, double sy, double sz,
+                                            int lane, double nn[3], double *cand = nullptr, int stride = 0) {
+    // hit mask of this group (the wave holds two groups)
+    const unsigned long long ball = __ballot(pr.blk >= 0);
+    unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
     double best = DBL_MAX;
     double bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
     while (__ballot(hits != 0) != 0ull) {  // wave-uniform trip count
         double2 xy[kChunk];
         double zz[kChunk];
-        int jj[kChunk];
+        int cb[kChunk];
         bool ld[kChunk];
 #pragma unroll
         for (int u = 0; u < kChunk; ++u) {
             const int j = hits ? (__ffs(hits) - 1) : -1;
             hits &= hits - 1;  // (0 & -1) == 0
-            const int bj = __shfl(blk, j & 31, 32);
-            const int cj = __shfl(cnt, j & 31, 32);
-            const int oj = FILL ? __shfl(offs, j & 31, 32) : 0;
-            jj[u] = FILL ? oj : j;  // candidate base (FILL) or shift index: both order the voxels
+            const int bj = __shfl(pr.blk, j & 31, 32);
+            const int cj = __shfl(pr.cnt, j & 31, 32);
+            cb[u] = __shfl(pr.offs, j & 31, 32);  // candidate number of the voxel's first point
             ld[u] = (j >= 0) && (lane < cj);
             if (ld[u]) {
                 xy[u] = block_xy(m, bj)[lane];
@@ -159,116 +213,57 @@ __device__ __forceinline__ double group_closest_neighbor(const MapView &m, doubl
             if (ld[u]) {
                 const double dx = xy[u].x - sx, dy = xy[u].y - sy, dz = zz[u] - sz;
                 const double d = (dx * dx + dy * dy) + dz * dz;
-                if (d < best) {  // shifts arrive in increasing j: strict '<' keeps the earliest
+                const int c = cb[u] + lane;
+                if (d < best) {  // voxels arrive in shift order: strict '<' keeps the earliest
                     best = d;
                     bx = xy[u].x;
                     by = xy[u].y;
                     bz = zz[u];
-                    bkey = FILL ? (jj[u] + lane) : ((jj[u] << 12) | lane);
+                    bkey = c;
                 }
                 if (FILL) {
-                    const int c = jj[u] + lane;
-                    if (c < cap) {
-                        cand[c] = xy[u].x;
-                        cand[cap + c] = xy[u].y;
-                        cand[2 * cap + c] = zz[u];
-                    }
+                    cand[c] = xy[u].x;
+                    cand[stride + c] = xy[u].y;
+                    cand[2 * stride + c] = zz[u];
                 }
             }
         }
     }
-    // lexicographic min over (distance, shift, index) inside the 32-lane group
-    double gbest = best;
-    int gkey = bkey, glane = lane;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(gbest, off, 32);
-        const int ok = __shfl_xor(gkey, off, 32);
-        const int ol = __shfl_xor(glane, off, 32);
-        if (ob < gbest || (ob == gbest && ok < gkey)) {
-            gbest = ob;
-            gkey = ok;
-            glane = ol;
-        }
-    }
-    nn[0] = __shfl(bx, glane, 32);
-    nn[1] = __shfl(by, glane, 32);
-    nn[2] = __shfl(bz, glane, 32);
-    int ex = cnt;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) ex += __shfl_xor(ex, off, 32);
-    examined = ex;
-    return gbest;
+    return group_argmin(best, bkey, bx, by, bz, lane, nn);
 }
 
-// Same search for voxels that hold more than 32 points (max_points_per_voxel > 32): every lane
-// strides over the voxel's points.  Rare configuration, kept simple.
-__device__ __forceinline__ double group_closest_neighbor_wide(const MapView &m, double sx, double sy,
-                                                              double sz, int lane, double nn[3],
-                                                              int &examined, int &range_err) {
-    const int vx = voxel_coord(sx, m.voxel_size);
-    const int vy = voxel_coord(sy, m.voxel_size);
-    const int vz = voxel_coord(sz, m.voxel_size);
+// Same search for voxels that hold more than 32 points (max_points_per_voxel > 32): every probe
+// lane strides over its voxel's points.  Rare configuration, kept simple.
+__device__ __forceinline__ double scan_hits_wide(const MapView &m, const Probe &pr, double sx, double sy,
+                                                 double sz, int lane, double nn[3]) {
     double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
-    int bkey = 0x7FFFFFFF, cnt = 0;
-    if (lane < 27) {
-        const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
-        const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
-        const int qz = vz + (int)((kShift.z >> (2 * lane)) & 3) - 1;
-        if (voxel_in_range(qx, qy, qz)) {
-            const int b = map_find(m, pack_voxel(qx, qy, qz), cnt);
-            if (b >= 0) {
-                const double2 *xy = block_xy(m, b);
-                const double *z = block_z(m, b);
-                for (int k = 0; k < cnt; ++k) {
-                    const double dx = xy[k].x - sx, dy = xy[k].y - sy, dz = z[k] - sz;
-                    const double d = (dx * dx + dy * dy) + dz * dz;
-                    if (d < best) {
-                        best = d;
-                        bx = xy[k].x;
-                        by = xy[k].y;
-                        bz = z[k];
-                    }
-                }
-                bkey = lane;
-            } else {
-                cnt = 0;
+    int bkey = 0x7FFFFFFF;
+    if (pr.blk >= 0) {
+        const double2 *xy = block_xy(m, pr.blk);
+        const double *z = block_z(m, pr.blk);
+        for (int k = 0; k < pr.cnt; ++k) {
+            const double dx = xy[k].x - sx, dy = xy[k].y - sy, dz = z[k] - sz;
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            if (d < best) {
+                best = d;
+                bx = xy[k].x;
+                by = xy[k].y;
+                bz = z[k];
             }
-        } else {
-            range_err = 1;
         }
+        bkey = lane;
     }
-    double gbest = best;
-    int gkey = bkey, glane = lane;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(gbest, off, 32);
-        const int ok = __shfl_xor(gkey, off, 32);
-        const int ol = __shfl_xor(glane, off, 32);
-        if (ob < gbest || (ob == gbest && ok < gkey)) {
-            gbest = ob;
-            gkey = ok;
-            glane = ol;
-        }
-    }
-    nn[0] = __shfl(bx, glane, 32);
-    nn[1] = __shfl(by, glane, 32);
-    nn[2] = __shfl(bz, glane, 32);
-    int ex = cnt;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) ex += __shfl_xor(ex, off, 32);
-    examined = ex;
-    return gbest;
+    return group_argmin(best, bkey, bx, by, bz, lane, nn);
 }
 
 // GetClosestNeighbor over candidates already staged in LDS by a previous iteration (same voxel
-// neighbourhood): 32 lanes stride over the packed list; the candidate index is the tie-break key.
-__device__ __forceinline__ double group_closest_neighbor_lds(const double *cand, int cap, int E, double sx,
-                                                             double sy, double sz, int lane, double nn[3]) {
+// neighbourhood): 32 lanes stride over the packed list; the candidate number is the tie-break key.
+__device__ __forceinline__ double scan_lds(const double *cand, int stride, int E, double sx, double sy,
+                                           double sz, int lane, double nn[3]) {
     double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
     for (int c = lane; c < E; c += 32) {
-        const double x = cand[c], y = cand[cap + c], z = cand[2 * cap + c];
+        const double x = cand[c], y = cand[stride + c], z = cand[2 * stride + c];
         const double dx = x - sx, dy = y - sy, dz = z - sz;
         const double d = (dx * dx + dy * dy) + dz * dz;
         if (d < best) {
@@ -279,29 +274,262 @@ __device__ __forceinline__ double group_closest_neighbor_lds(const double *cand,
             bkey = c;
         }
     }
-    double gbest = best;
-    int gkey = bkey, glane = lane;
+    return group_argmin(best, bkey, bx, by, bz, lane, nn);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-staged neighbourhoods of the ICP kernel.
+//
+// A query's 27-voxel neighbourhood is copied once into an LDS region and reused by the following
+// ICP iterations (the map does not change during AlignPointsToMap).  The source point moves a
+// little every iteration and sooner or later crosses a voxel face; re-fetching from HBM then costs
+// three dependent memory round trips, and with thousands of queries SOME query crosses in nearly
+// every iteration -- and every workgroup waits for the slowest one.  So the staged window is
+// widened by one voxel layer on every side the query is close to (within kWindowMargin of the
+// face): 3..4 voxels per axis.  Each staged point carries a tag {voxel offset from the window's
+// centre voxel, index inside its voxel}; a scan for a query now in voxel v' visits exactly the
+// candidates whose voxel lies in [v'-1, v'+1]^3 -- the reference's 27 voxels, no more -- and breaks
+// distance ties by (position of the voxel in the reference's shift table, index in the voxel) like
+// the reference's nested strict '<' loops (VoxelHashMap.cpp:46-70).
+// ------------------------------------------------------------------------------------------
+constexpr double kWindowMargin = 0.125;  // fraction of a voxel
+constexpr int kFillChunk = 9;            // voxels whose points are in flight together during a fill
+
+// first probe of two independent keys issued together, then each chain resolved
+__device__ __forceinline__ void map_find_pair(const MapView &m, bool ok0, unsigned long long key0, bool ok1,
+                                              unsigned long long key1, int &blk0, int &cnt0, int &blk1,
+                                              int &cnt1) {
+    uint32_t s0 = hash_key(key0, m.mask), s1 = hash_key(key1, m.mask);
+    Slot a, b;
+    a.key = b.key = kKeyEmpty;
+    a.block = b.block = -1;
+    a.count = b.count = 0;
+    if (ok0) a = load_slot(m.slots + s0);
+    if (ok1) b = load_slot(m.slots + s1);
+    blk0 = blk1 = -1;
+    cnt0 = cnt1 = 0;
+    for (uint32_t probes = 0; ok0 && probes <= m.mask; ++probes) {
+        if (a.key == key0) {
+            blk0 = a.block;
+            cnt0 = a.count;
+            break;
+        }
+        if (a.key == kKeyEmpty) break;
+        s0 = (s0 + 1) & m.mask;
+        a = load_slot(m.slots + s0);
+    }
+    for (uint32_t probes = 0; ok1 && probes <= m.mask; ++probes) {
+        if (b.key == key1) {
+            blk1 = b.block;
+            cnt1 = b.count;
+            break;
+        }
+        if (b.key == kKeyEmpty) break;
+        s1 = (s1 + 1) & m.mask;
+        b = load_slot(m.slots + s1);
+    }
+    if (blk0 < 0) cnt0 = 0;
+    if (blk1 < 0) cnt1 = 0;
+}
+
+__device__ __forceinline__ void group_lds_sync() {
+    // the 32 lanes of a group are half a wave: LDS traffic between them needs ordering, not a barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int region_doubles(int E) { return 3 * E + (E + 3) / 4; }
+
+// Stage the (widened) neighbourhood of the query s (voxel v) into an LDS region described by *meta;
+// `cells` is this group's scratch of 64 int2.  Returns false when the workgroup's pool is exhausted
+// (the caller then searches HBM directly).  Needs max_points_per_voxel <= 32.
+__device__ __forceinline__ bool window_fill(const MapView &m, const double s[3], const int v[3], int lane,
+                                            int2 *cells, double *pool, int pool_doubles, int *bump,
+                                            IcpRegionMeta *meta, int &range_err) {
+    int lo[3], nn[3];
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(gbest, off, 32);
-        const int ok = __shfl_xor(gkey, off, 32);
-        const int ol = __shfl_xor(glane, off, 32);
-        if (ob < gbest || (ob == gbest && ok < gkey)) {
-            gbest = ob;
-            gkey = ok;
-            glane = ol;
+    for (int a = 0; a < 3; ++a) {
+        const double f = s[a] / m.voxel_size - (double)v[a];  // position inside the voxel, [0, 1)
+        lo[a] = (f < kWindowMargin) ? -2 : -1;
+        const int hi = (f > 1.0 - kWindowMargin) ? 2 : 1;
+        nn[a] = hi - lo[a] + 1;
+    }
+    const int W = nn[0] * nn[1] * nn[2];  // <= 64
+    bool ok[2];
+    unsigned long long key[2];
+    int code[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int w = lane + 32 * h;
+        ok[h] = false;
+        key[h] = 0;
+        code[h] = 0;
+        if (w < W) {
+            const int iz = w % nn[2], t = w / nn[2], iy = t % nn[1], ix = t / nn[1];
+            const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
+            const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
+            code[h] = (ox + 2) | ((oy + 2) << 3) | ((oz + 2) << 6);
+            if (voxel_in_range(qx, qy, qz)) {
+                ok[h] = true;
+                key[h] = pack_voxel(qx, qy, qz);
+            } else if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) {
+                range_err = 1;
+            }
         }
     }
-    nn[0] = __shfl(bx, glane, 32);
-    nn[1] = __shfl(by, glane, 32);
-    nn[2] = __shfl(bz, glane, 32);
-    return gbest;
+    int blk[2], cnt[2];
+    map_find_pair(m, ok[0], key[0], ok[1], key[1], blk[0], cnt[0], blk[1], cnt[1]);
+    // candidate numbering: window order, cells 0..31 first
+    int incl0 = cnt[0], incl1 = cnt[1];
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int o0 = __shfl_up(incl0, off, 32), o1 = __shfl_up(incl1, off, 32);
+        if (lane >= off) {
+            incl0 += o0;
+            incl1 += o1;
+        }
+    }
+    const int tot0 = __shfl(incl0, 31, 32);
+    const int E = tot0 + __shfl(incl1, 31, 32);
+    cells[lane] = make_int2(blk[0], cnt[0] | ((incl0 - cnt[0]) << 6) | (code[0] << 18));
+    cells[lane + 32] = make_int2(blk[1], cnt[1] | ((tot0 + incl1 - cnt[1]) << 6) | (code[1] << 18));
+    // a region of exactly E candidates: reuse the old allocation when it is large enough,
+    // otherwise take a new one from the workgroup's pool (never freed within a launch)
+    const int need = region_doubles(E);
+    int base = meta->base, cap = meta->cap;
+    if (need > cap) {
+        int nb = -1;
+        if (lane == 0) {
+            nb = atomicAdd(bump, need);
+            if (nb + need > pool_doubles) {
+                atomicAdd(bump, -need);
+                nb = -1;
+            }
+        }
+        nb = __shfl(nb, 0, 32);
+        if (nb < 0) {  // pool exhausted: this query searches HBM directly from now on
+            if (lane == 0) {
+                meta->valid = 0;
+                meta->cap = -1;
+            }
+            return false;
+        }
+        base = nb;
+        cap = need;
+    }
+    double *X = pool + base, *Y = X + E, *Z = Y + E;
+    unsigned short *T = reinterpret_cast<unsigned short *>(Z + E);
+    group_lds_sync();  // cells[] visible to the whole group
+    const int half_shift = threadIdx.x & 32;
+    unsigned long long hits = (unsigned long long)(unsigned)(__ballot(blk[0] >= 0) >> half_shift) |
+                              ((unsigned long long)(unsigned)(__ballot(blk[1] >= 0) >> half_shift) << 32);
+    while (hits) {
+        double2 xy[kFillChunk];
+        double zz[kFillChunk];
+        int info[kFillChunk];
+#pragma unroll
+        for (int u = 0; u < kFillChunk; ++u) {
+            info[u] = -1;
+            if (hits) {
+                const int j = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const int2 c = cells[j];
+                if (lane < (c.y & 63)) {
+                    info[u] = c.y;
+                    xy[u] = block_xy(m, c.x)[lane];
+                    zz[u] = block_z(m, c.x)[lane];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFillChunk; ++u) {
+            if (info[u] >= 0) {
+                const int c = ((info[u] >> 6) & 4095) + lane;
+                X[c] = xy[u].x;
+                Y[c] = xy[u].y;
+                Z[c] = zz[u];
+                T[c] = (unsigned short)(((info[u] >> 18) & 511) | (lane << 9));
+            }
+        }
+    }
+    if (lane == 0) {
+        meta->v[0] = v[0];
+        meta->v[1] = v[1];
+        meta->v[2] = v[2];
+        meta->lo[0] = (signed char)lo[0];
+        meta->lo[1] = (signed char)lo[1];
+        meta->lo[2] = (signed char)lo[2];
+        meta->hi[0] = (signed char)(lo[0] + nn[0] - 1);
+        meta->hi[1] = (signed char)(lo[1] + nn[1] - 1);
+        meta->hi[2] = (signed char)(lo[2] + nn[2] - 1);
+        meta->E = E;
+        meta->base = base;
+        meta->cap = cap;
+        meta->valid = 1;
+    }
+    group_lds_sync();  // candidates and meta visible to the whole group
+    return true;
+}
+
+// GetClosestNeighbor over a staged window: the query sits in the voxel at offset (dx, dy, dz) from
+// the window's centre voxel.  Returns the squared distance, the neighbour, and the number of map
+// points in the 27-voxel neighbourhood (= points the reference examines).
+//   FILTER = false: the window is exactly the query's 27 voxels (no widened side, query still in
+//   the centre voxel), every staged point is a candidate and the tags are only read on a new minimum.
+template <bool FILTER>
+__device__ __forceinline__ double scan_window(const double *region, int E, int dx, int dy, int dz, double sx,
+                                              double sy, double sz, int lane, double nn[3], int &examined) {
+    const double *X = region, *Y = X + E, *Z = Y + E;
+    const unsigned short *T = reinterpret_cast<const unsigned short *>(Z + E);
+    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF, inside = 0;
+    for (int c = lane; c < E; c += 32) {
+        int tag = 0, ox = 0, oy = 0, oz = 0;
+        if (FILTER) {
+            tag = T[c];
+            ox = (tag & 7) - 2 - dx;
+            oy = ((tag >> 3) & 7) - 2 - dy;
+            oz = ((tag >> 6) & 7) - 2 - dz;
+            if (!((unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u)) continue;
+            ++inside;
+        }
+        const double x = X[c], y = Y[c], z = Z[c];
+        const double ex = x - sx, ey = y - sy, ez = z - sz;
+        const double d = (ex * ex + ey * ey) + ez * ez;
+        if (d <= best) {
+            if (!FILTER) {
+                tag = T[c];
+                ox = (tag & 7) - 2;
+                oy = ((tag >> 3) & 7) - 2;
+                oz = ((tag >> 6) & 7) - 2;
+            }
+            const int key = (shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)) << 7) | (tag >> 9);
+            if (d < best || key < bkey) {
+                best = d;
+                bx = x;
+                by = y;
+                bz = z;
+                bkey = key;
+            }
+        }
+    }
+    if (FILTER) {
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) inside += __shfl_xor(inside, off, 32);
+        examined = inside;
+    } else {
+        examined = E;
+    }
+    return group_argmin(best, bkey, bx, by, bz, lane, nn);
 }
 
 __device__ __forceinline__ double closest_neighbor_any(const MapView &m, double sx, double sy, double sz,
                                                        int lane, double nn[3], int &examined, int &range_err) {
-    if (m.max_points <= 32) return group_closest_neighbor<false>(m, sx, sy, sz, lane, nn, examined, range_err);
-    return group_closest_neighbor_wide(m, sx, sy, sz, lane, nn, examined, range_err);
+    const Probe pr = probe27(m, sx, sy, sz, lane, range_err);
+    examined = pr.E;
+    if (m.max_points <= 32) return scan_hits<false>(m, pr, sx, sy, sz, lane, nn);
+    return scan_hits_wide(m, pr, sx, sy, sz, lane, nn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,29 +557,47 @@ __global__ __launch_bounds__(256) void k_closest_neighbor(MapView m, const doubl
 // ------------------------------------------------------------------------------------------
 // k_icp: the whole ICP loop of AlignPointsToMap in one persistent launch
 //
-// grid = G workgroups (all co-resident, G <= 256 = one per CU), 256 threads = 8 groups of 32 lanes.
-// Per iteration every group walks its points (fixed assignment, so the running transformed
-// source of a point is always re-read by the lane that wrote it):
+// grid = G workgroups (all co-resident, G <= 256 = one per CU, each owning its CU's 160 KiB of
+// LDS), 512 threads = 16 groups of 32 lanes.  Per iteration every group walks its points (fixed
+// assignment, so the running transformed source of a point is always re-read by the group that
+// wrote it):
 //   s = est * s            TransformPoints of the previous iteration's estimate (Registration.cpp:159;
 //                          est = initial_guess for the first iteration, :147)
-//   (nn, d) = closest neighbour among the 27 voxels, keep iff d < max_dist (strict, :72)
+//   (nn, d) = closest neighbour among the 27 voxels, keep iff d < max_dist (strict, :72).  The
+//             first visit of a voxel neighbourhood copies its candidates into an LDS region
+//             (bump-allocated from the workgroup's pool, exactly E points); as long as the query
+//             stays in the same voxel later iterations scan LDS only.
 //   accumulate the 16 unique scalars of J^T w J and J^T w r with J = [I | -hat(s)], r = s - nn,
 //   w = sigma^2 / (sigma + |r|^2)^2 (:81-98).
 // Workgroup partials are reduced in LDS in a fixed order, published as tagged granules, gathered
-// by EVERY workgroup (one hop, no second broadcast), summed in workgroup order (deterministic),
-// and every workgroup solves the same 6x6 system redundantly: dx = LDLT(JTJ).solve(-JTr),
-// est = exp(dx), T_icp = est * T_icp, stop when |dx| < convergence_criterion (:156-163).
+// by EVERY workgroup (one hop, no second broadcast; 26 threads per scalar, each summing a
+// contiguous range of workgroups, then the 26 range sums in order: deterministic), and every
+// workgroup solves the same 6x6 system redundantly on its first four waves:
+// dx = LDLT(JTJ).solve(-JTr), est = exp(dx), T_icp = est * T_icp, stop when |dx| <
+// convergence_criterion (:156-163).
 // ------------------------------------------------------------------------------------------
+struct IcpShared {  // head of the dynamic LDS (kIcpFixedLds bytes with the region records)
+    double part[kIcpGroupsPerBlock][kIcpSums];
+    double range_sum[kIcpParts][kIcpSums];
+    double tot[kIcpSums];
+    double est[8];  // q[4], t[3], |dx|
+    int fail;
+    int bump;  // doubles handed out from the candidate pool
+    int pad[6];
+    int2 cells[kIcpGroupsPerBlock][64];  // per-group scratch of window_fill
+};
+static_assert(sizeof(IcpShared) + kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) <= kIcpFixedLds,
+              "kIcpFixedLds too small");
+
 template <bool PROF>
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *sh_part = reinterpret_cast<double *>(smem);                     // [8][kIcpSums]
-    double *sh_tot = sh_part + kIcpGroupsPerBlock * kIcpSums;                // [kIcpSums]
-    double *sh_p8 = sh_tot + kIcpSums;                                       // [8][kIcpSums]
-    int *sh_failp = reinterpret_cast<int *>(sh_p8 + 8 * kIcpSums);          // [2] (8 bytes)
-    unsigned *sh_words = reinterpret_cast<unsigned *>(sh_failp + 2);        // [gridDim.x][2*kIcpSums]
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
     // shift its base off 8/16-byte alignment)
+    IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
+    IcpRegionMeta *metas = reinterpret_cast<IcpRegionMeta *>(smem + sizeof(IcpShared));
+    double *pool = reinterpret_cast<double *>(smem + kIcpFixedLds);
+    constexpr int kPoolDoubles = (int)((kIcpLdsBytes - kIcpFixedLds) / sizeof(double));
 
     const int tid = threadIdx.x;
     const int lane = tid & 31;
@@ -366,23 +612,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                : (n + kIcpGroupsPerBlock * P.points_per_group - 1) / (kIcpGroupsPerBlock * P.points_per_group);
     G = max(1, min(G, (int)gridDim.x));
     if ((int)blockIdx.x >= G) return;
-    // per (round, group) candidate regions: meta {s[3] running source point; v[3] voxel; E; valid}
-    // + candidates {x[cap], y[cap], z[cap]}.  The exchange scratch is sized by G, the rest of the
-    // workgroup's LDS is split over the rounds a group walks per iteration (as many of them as
-    // still leave P.cand_target candidates per region).
-    const int rounds = (n + G * kIcpGroupsPerBlock - 1) / (G * kIcpGroupsPerBlock);
-    char *region_base = smem + icp_fixed_smem(G);
-    int cached_rounds = 0, cap_q = 0;
-    if (P.cand_target > 0 && m.max_points <= 32) {
-        const int budget = P.lds_bytes - (int)icp_fixed_smem(G);
-        const int per_region_min = (int)sizeof(IcpRegionMeta) + 24 * P.cand_target;
-        cached_rounds = max(0, min(rounds, budget / (kIcpGroupsPerBlock * per_region_min)));
-        if (cached_rounds > 0) {
-            cap_q = (budget / (kIcpGroupsPerBlock * cached_rounds) - (int)sizeof(IcpRegionMeta)) / 24;
-            cap_q = min(cap_q & ~31, 27 * 32);
-        }
-    }
-    const int n_regions = kIcpGroupsPerBlock * cached_rounds;
+    const int cached_rounds = (P.use_lds && m.max_points <= 32) ? kIcpMaxCachedRounds : 0;
     const unsigned epoch_base = st->epoch_base;
     unsigned long long t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
     unsigned gather_passes = 0;
@@ -402,7 +632,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     }
     const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143
 
-    if (tid == 0) sh_failp[0] = 0;
+    if (tid == 0) {
+        sh.fail = 0;
+        sh.bump = 0;
+    }
+    if (tid < kIcpMaxCachedRounds * kIcpGroupsPerBlock) {
+        metas[tid].valid = 0;
+        metas[tid].cap = 0;
+        metas[tid].base = 0;
+        metas[tid].E = 0;
+    }
     __syncthreads();
 
     SE3 est = guess;
@@ -418,15 +657,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
+        // consecutive source points (neighbours in the scan, hence similar neighbourhood sizes) go to
+        // different workgroups: point p belongs to workgroup p % G, group (p / G) % 16
         int round = 0;
-        for (int p = blockIdx.x * kIcpGroupsPerBlock + grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
-            const int region = round * kIcpGroupsPerBlock + grp;
-            const bool has_region = round < cached_rounds;
-            IcpRegionMeta *meta = reinterpret_cast<IcpRegionMeta *>(region_base) + region;
-            double *cand = reinterpret_cast<double *>(region_base + (size_t)n_regions * sizeof(IcpRegionMeta)) +
-                           (size_t)region * 3 * cap_q;
+        for (int p = blockIdx.x + G * grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
+            const bool has_meta = round < cached_rounds;
+            IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
             double pin[3];
-            if (it > 0 && has_region) {  // running source point lives in LDS
+            if (it > 0 && has_meta) {  // running source point lives in LDS
                 pin[0] = meta->s[0];
                 pin[1] = meta->s[1];
                 pin[2] = meta->s[2];
@@ -440,14 +678,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             se3_act(est, pin, s);
             const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size),
                       vz = voxel_coord(s[2], m.voxel_size);
+            const int v[3] = {vx, vy, vz};
             bool cached = false;
-            int E = 0;
-            if (has_region && it > 0) {
-                cached = meta->valid && meta->v[0] == vx && meta->v[1] == vy && meta->v[2] == vz;
-                E = meta->E;
-            }
+            if (has_meta && meta->valid)  // is the 27-neighbourhood of (vx, vy, vz) inside the staged window?
+                cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
+                         meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
+                         meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
             if (lane == 0) {
-                if (has_region) {
+                if (has_meta) {
                     meta->s[0] = s[0];
                     meta->s[1] = s[1];
                     meta->s[2] = s[2];
@@ -457,26 +695,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     P.work[3 * p + 2] = s[2];
                 }
             }
+            if (!cached && has_meta && meta->cap >= 0)
+                cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
             double nn[3];
-            int ex;
             double d2;
+            int E;
             if (cached) {
-                d2 = group_closest_neighbor_lds(cand, cap_q, E, s[0], s[1], s[2], lane, nn);
-                ex = E;
-            } else if (has_region) {
-                d2 = group_closest_neighbor<true>(m, s[0], s[1], s[2], lane, nn, ex, range_err, cand, cap_q);
-                if (lane == 0) {
-                    meta->v[0] = vx;
-                    meta->v[1] = vy;
-                    meta->v[2] = vz;
-                    meta->E = ex;
-                    meta->valid = (ex <= cap_q);
-                }
+                const int ddx = vx - meta->v[0], ddy = vy - meta->v[1], ddz = vz - meta->v[2];
+                const bool exact27 = meta->lo[0] == -1 && meta->hi[0] == 1 && meta->lo[1] == -1 && meta->hi[1] == 1 &&
+                                     meta->lo[2] == -1 && meta->hi[2] == 1;  // (then ddx = ddy = ddz = 0)
+                d2 = exact27 ? scan_window<false>(pool + meta->base, meta->E, 0, 0, 0, s[0], s[1], s[2], lane, nn, E)
+                             : scan_window<true>(pool + meta->base, meta->E, ddx, ddy, ddz, s[0], s[1], s[2], lane, nn, E);
             } else {
-                d2 = closest_neighbor_any(m, s[0], s[1], s[2], lane, nn, ex, range_err);
+                const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
+                E = pr.E;
+                d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
+                                         : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
             }
             if (lane == 0) {
-                acc[17] += (double)ex;
+                acc[17] += (double)E;
                 if (d2 < DBL_MAX && sqrt(d2) < max_dist) {
                     const double rx = s[0] - nn[0], ry = s[1] - nn[1], rz = s[2] - nn[2];
                     const double r2 = (rx * rx + ry * ry) + rz * rz;
@@ -508,7 +745,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < kIcpSums; ++k) sh_part[grp * kIcpSums + k] = acc[k];
+            for (int k = 0; k < kIcpSums; ++k) sh.part[grp][k] = acc[k];
         }
         __syncthreads();
         const unsigned epoch = epoch_base + (unsigned)it + 1u;
@@ -518,7 +755,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             double v = 0.0;
 #pragma unroll
             for (int g = 0; g < kIcpGroupsPerBlock; ++g) {
-                const double pv = sh_part[g * kIcpSums + k];
+                const double pv = sh.part[g][k];
                 v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
             }
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -527,24 +764,29 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         // ---- gather every workgroup's partial (bounded spin) --------------------------------
         const unsigned long long c2 = PROF ? wall_clock64() : 0ull;
-        {
-            // every thread fetches its own words, kGatherChunk loads in flight, and re-polls only
-            // the ones whose tag has not arrived yet (bounded)
-            constexpr int kGatherChunk = 8;
-            const int nwords = G * 2 * kIcpSums;
+        if (tid < kIcpParts * kIcpSums) {
+            // thread (k, part) sums scalar k over a contiguous range of workgroups, in order;
+            // kGatherChunk workgroups (2 granules each) are in flight at a time and only granules
+            // whose tag has not arrived yet are polled again
+            constexpr int kGatherChunk = 4;
+            const int k = tid % kIcpSums, part = tid / kIcpSums;
+            const int b0 = (G * part) / kIcpParts, b1 = (G * (part + 1)) / kIcpParts;
+            double v = 0.0;
             bool fail = false;
-            for (int w0 = tid; w0 < nwords && !fail; w0 += kGatherChunk * kIcpThreads) {
-                unsigned long long x[kGatherChunk];
+            for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
+                unsigned long long lo[kGatherChunk], hi[kGatherChunk];
 #pragma unroll
                 for (int u = 0; u < kGatherChunk; ++u) {
-                    const int w = w0 + u * kIcpThreads;
-                    x[u] = (w < nwords) ? granule_load(gran + w) : ((unsigned long long)epoch << 32);
+                    const unsigned long long *g = gran + ((size_t)min(b + u, b1 - 1) * kIcpSums + k) * 2;
+                    lo[u] = granule_load(g);
+                    hi[u] = granule_load(g + 1);
                 }
 #pragma unroll
                 for (int u = 0; u < kGatherChunk; ++u) {
-                    const int w = w0 + u * kIcpThreads;
+                    if (b + u >= b1) continue;
+                    const unsigned long long *g = gran + ((size_t)(b + u) * kIcpSums + k) * 2;
                     unsigned spins = 0;
-                    while ((unsigned)(x[u] >> 32) != epoch) {
+                    while ((unsigned)(lo[u] >> 32) != epoch || (unsigned)(hi[u] >> 32) != epoch) {
                         if (PROF) ++gather_passes;
                         if (++spins > P.spin_limit ||
                             ((spins & 255u) == 0 &&
@@ -553,82 +795,95 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
-                        x[u] = granule_load(gran + w);
+                        lo[u] = granule_load(g);
+                        hi[u] = granule_load(g + 1);
                     }
-                    if (w < nwords) sh_words[w] = (unsigned)x[u];
+                    const double pv = __longlong_as_double(
+                        (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
+                    v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
                 }
             }
-            if (fail) sh_failp[0] = 1;
+            sh.range_sum[part][k] = v;
+            if (fail) sh.fail = 1;
         }
         __syncthreads();
-        if (sh_failp[0]) {
+        if (sh.fail) {
             failed = true;
             break;
         }
-        // sum over workgroups: 8 contiguous chunks per scalar, then the 8 chunk sums, both in order
-        if (tid < 8 * kIcpSums) {
-            const int k = tid % kIcpSums, part = tid / kIcpSums;
-            const int b0 = (G * part) / 8, b1 = (G * (part + 1)) / 8;
-            double v = 0.0;
-            for (int b = b0; b < b1; ++b) {
-                const unsigned lo = sh_words[(b * kIcpSums + k) * 2];
-                const unsigned hi = sh_words[(b * kIcpSums + k) * 2 + 1];
-                const double pv = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-                v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-            }
-            sh_p8[part * kIcpSums + k] = v;
-        }
-        __syncthreads();
         if (tid < kIcpSums) {
             double v = 0.0;
 #pragma unroll
-            for (int part = 0; part < 8; ++part) {
-                const double pv = sh_p8[part * kIcpSums + tid];
+            for (int part = 0; part < kIcpParts; ++part) {
+                const double pv = sh.range_sum[part][tid];
                 v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
             }
-            sh_tot[tid] = v;
+            sh.tot[tid] = v;
         }
         __syncthreads();
-        // ---- every thread solves the same system (uniform, no broadcast needed) ------------
+        // ---- waves 0..3 (one per SIMD) solve the same system; the result goes through LDS -----
         const unsigned long long c3 = PROF ? wall_clock64() : 0ull;
-        double S[kIcpSums];
+        double nrm2 = 0.0;
+        if (tid < kIcpSolveThreads) {
+            double S[kIcpSums];
 #pragma unroll
-        for (int k = 0; k < kIcpSums; ++k) S[k] = sh_tot[k];
-        double JTJ[36], nb[6], dx[6];
+            for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
+            double JTJ[36], nb[6], dx[6];
 #pragma unroll
-        for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
-        JTJ[0] = JTJ[7] = JTJ[14] = S[0];
-        // top-right block sum w * (-hat(s)) and its transpose
-        JTJ[0 * 6 + 4] = S[3];
-        JTJ[0 * 6 + 5] = -S[2];
-        JTJ[1 * 6 + 3] = -S[3];
-        JTJ[1 * 6 + 5] = S[1];
-        JTJ[2 * 6 + 3] = S[2];
-        JTJ[2 * 6 + 4] = -S[1];
-        JTJ[4 * 6 + 0] = S[3];
-        JTJ[5 * 6 + 0] = -S[2];
-        JTJ[3 * 6 + 1] = -S[3];
-        JTJ[5 * 6 + 1] = S[1];
-        JTJ[3 * 6 + 2] = S[2];
-        JTJ[4 * 6 + 2] = -S[1];
-        JTJ[3 * 6 + 3] = S[4];
-        JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
-        JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
-        JTJ[4 * 6 + 4] = S[7];
-        JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
-        JTJ[5 * 6 + 5] = S[9];
+            for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+            JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+            // top-right block sum w * (-hat(s)) and its transpose
+            JTJ[0 * 6 + 4] = S[3];
+            JTJ[0 * 6 + 5] = -S[2];
+            JTJ[1 * 6 + 3] = -S[3];
+            JTJ[1 * 6 + 5] = S[1];
+            JTJ[2 * 6 + 3] = S[2];
+            JTJ[2 * 6 + 4] = -S[1];
+            JTJ[4 * 6 + 0] = S[3];
+            JTJ[5 * 6 + 0] = -S[2];
+            JTJ[3 * 6 + 1] = -S[3];
+            JTJ[5 * 6 + 1] = S[1];
+            JTJ[3 * 6 + 2] = S[2];
+            JTJ[4 * 6 + 2] = -S[1];
+            JTJ[3 * 6 + 3] = S[4];
+            JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+            JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+            JTJ[4 * 6 + 4] = S[7];
+            JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+            JTJ[5 * 6 + 5] = S[9];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
-        ldlt6_solve(JTJ, nb, dx);
-        est = se3_exp(dx);
-        T_icp = se3_mul(est, T_icp);
+            for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+            ldlt6_solve(JTJ, nb, dx);
+            est = se3_exp(dx);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
+            if (tid == 0) {
+                sh.est[0] = est.q[0];
+                sh.est[1] = est.q[1];
+                sh.est[2] = est.q[2];
+                sh.est[3] = est.q[3];
+                sh.est[4] = est.t[0];
+                sh.est[5] = est.t[1];
+                sh.est[6] = est.t[2];
+                sh.est[7] = nrm2;
+            }
+            T_icp = se3_mul(est, T_icp);
+            ncorr_last = (unsigned long long)S[16];
+            ncorr_total += ncorr_last;
+            examined_total += (unsigned long long)S[17];
+        }
+        __syncthreads();
+        if (tid >= kIcpSolveThreads) {
+            est.q[0] = sh.est[0];
+            est.q[1] = sh.est[1];
+            est.q[2] = sh.est[2];
+            est.q[3] = sh.est[3];
+            est.t[0] = sh.est[4];
+            est.t[1] = sh.est[5];
+            est.t[2] = sh.est[6];
+            nrm2 = sh.est[7];
+        }
         iterations = it + 1;
-        ncorr_last = (unsigned long long)S[16];
-        ncorr_total += ncorr_last;
-        examined_total += (unsigned long long)S[17];
-        double nrm = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) nrm += dx[i] * dx[i];
         const unsigned long long c4 = PROF ? wall_clock64() : 0ull;
         t_assoc += c1 - c0;
         t_publish += c2 - c1;
@@ -640,11 +895,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             r[1] = (unsigned)(c2 - c1);
             r[2] = (unsigned)(c3 - c2);
             r[3] = (unsigned)(c4 - c3);
-            r[4] = (unsigned)S[kIcpTickSlot];  // slowest group's association time, any workgroup
+            r[4] = (unsigned)sh.tot[kIcpTickSlot];  // slowest group's association time, any workgroup
             r[5] = gather_passes;
         }
         gather_passes = 0;
-        if (sqrt(nrm) < P.conv) {
+        if (sqrt(nrm2) < P.conv) {
             converged = 1;
             break;
         }
@@ -821,9 +1076,56 @@ __device__ __forceinline__ void ds_min_index(DsSlot *tab, int s, int idx) {
     if (tab[s].minidx > idx) atomicMin(&tab[s].minidx, idx);
 }
 
+// Workgroup-level aggregation of downsample claims: the (up to 1024) points of a workgroup are
+// consecutive in the scan, so most of them share a voxel with a neighbour.  They first meet in a
+// small LDS hash (LDS atomics: no HBM traffic, no cross-XCD contention); only one claim and one
+// atomicMin per DISTINCT voxel of the workgroup then go to the table in HBM.
+constexpr int kAggSlots = 2048;
+struct ClaimAgg {
+    unsigned long long key[kAggSlots];
+    int minidx[kAggSlots];
+    int slot[kAggSlots];
+};
+
+// all kScanThreads threads call this; returns the table slot of this thread's voxel (-1: none)
+__device__ __forceinline__ int ds_claim_aggregated(ClaimAgg &agg, DsSlot *tab, uint32_t mask, bool valid,
+                                                   unsigned long long key, int idx, int *err) {
+    for (int e = threadIdx.x; e < kAggSlots; e += kScanThreads) {
+        agg.key[e] = kKeyEmpty;
+        agg.minidx[e] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    int ls = -1;
+    if (valid) {
+        uint32_t h = hash_key(key, kAggSlots - 1);
+        for (int probes = 0; probes < kAggSlots; ++probes) {
+            unsigned long long cur = agg.key[h];
+            if (cur == kKeyEmpty) cur = atomicCAS(&agg.key[h], kKeyEmpty, key);
+            if (cur == kKeyEmpty || cur == key) {
+                ls = (int)h;
+                break;
+            }
+            h = (h + 1) & (kAggSlots - 1);
+        }
+        atomicMin(&agg.minidx[ls], idx);  // 1024 points never fill 2048 slots: ls >= 0
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAggSlots; e += kScanThreads) {
+        const unsigned long long k = agg.key[e];
+        if (k == kKeyEmpty) continue;
+        const int s = ds_claim(tab, mask, k);
+        if (s >= 0) ds_min_index(tab, s, agg.minidx[e]);
+        else atomicOr(err, E_TABLE_FULL);
+        agg.slot[e] = s;
+    }
+    __syncthreads();
+    return valid ? agg.slot[ls] : -1;
+}
+
 // scatter the range-cropped cloud (order preserving) and, fused, stage A of the first
 // VoxelDownsample: claim the voxel and atomicMin the (new) point index into it
 __global__ __launch_bounds__(kScanThreads) void k_pre_scatter(PreParams P) {
+    __shared__ ClaimAgg agg;
     const int n = P.n;
     const int i = blockIdx.x * kScanThreads + threadIdx.x;
     bool keep = false;
@@ -842,19 +1144,19 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_scatter(PreParams P) {
         P.out[3 * j] = p[0];
         P.out[3 * j + 1] = p[1];
         P.out[3 * j + 2] = p[2];
-        if (P.ds_tab) {
+    }
+    if (P.ds_tab) {
+        bool valid = false;
+        unsigned long long key = 0;
+        if (keep) {
             const int vx = voxel_coord(p[0], P.ds_voxel), vy = voxel_coord(p[1], P.ds_voxel),
                       vz = voxel_coord(p[2], P.ds_voxel);
-            int s = -1;
-            if (voxel_in_range(vx, vy, vz)) {
-                s = ds_claim(P.ds_tab, P.ds_mask, pack_voxel(vx, vy, vz));
-                if (s >= 0) ds_min_index(P.ds_tab, s, j);
-                else atomicOr(P.err, E_TABLE_FULL);
-            } else {
-                atomicOr(P.err, E_RANGE);
-            }
-            P.ds_slot_of[j] = s;
+            valid = voxel_in_range(vx, vy, vz);
+            if (valid) key = pack_voxel(vx, vy, vz);
+            else atomicOr(P.err, E_RANGE);
         }
+        const int s = ds_claim_aggregated(agg, P.ds_tab, P.ds_mask, valid, key, j, P.err);
+        if (keep) P.ds_slot_of[j] = s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.n_out = grand;
 }
@@ -932,16 +1234,25 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
 
 // ------------------------------------------------------------------------------------------
 // VoxelHashMap::AddPoints (VoxelHashMap.cpp:97-119), made deterministic on the device:
-//   k_map_link   every new point finds or claims its voxel's slot (CAS on the packed key) and
-//                pushes itself on the slot's per-frame list;
-//   k_map_apply  the point that opened a list walks it in ascending point index and applies the
-//                reference's sequential acceptance rule (voxel full? closer than map_resolution
-//                to a stored point? else append) -- the same result as the serial loop.
+//   k_map_link   every new point finds or claims its voxel's slot (CAS on the packed key), opens or
+//                joins the voxel's record of this insert and files its index there (plus a chain
+//                for voxels that receive more than kRecList points);
+//   k_map_apply  one 32-lane group per record applies the reference's sequential acceptance rule
+//                (voxel full? closer than map_resolution to a stored point? else append) to the
+//                record's points in ascending point index -- the same result as the serial loop.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_map_link(MapView m, const double *in, const int *n_ptr,
-                                                  int n_imm, const PipeState *state, int use_pose,
-                                                  double *world, int *slot_of, int *next) {
+__global__ __launch_bounds__(256) void k_map_link(MapView m, InsertScratch sc, const double *in, const int *n_ptr,
+                                                  int n_imm, const PipeState *state, int use_pose) {
     const int n = count_of(n_ptr, n_imm);
+    int *touched = &m.ctr[C_TOUCHED0 + sc.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        m.ctr[C_TOUCHED0 + (sc.parity ^ 1)] = 0;  // re-arm for the next insert
+        // free-block queue: undo the pop cursor's overshoot of the previous insert, then admit the
+        // blocks recycled since (nothing else touches these words while k_map_link runs)
+        const unsigned head = (unsigned)m.ctr[C_FHEAD], tail = (unsigned)m.ctr[C_FTAIL];
+        if ((int)(tail - head) < 0) m.ctr[C_FHEAD] = (int)tail;
+        m.ctr[C_FTAIL] = m.ctr[C_FPEND];
+    }
     SE3 pose;
     if (use_pose) pose = state->new_pose;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -953,9 +1264,9 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, const double *in, c
             p[1] = o[1];
             p[2] = o[2];
         }
-        world[3 * i] = p[0];
-        world[3 * i + 1] = p[1];
-        world[3 * i + 2] = p[2];
+        sc.world[3 * i] = p[0];
+        sc.world[3 * i + 1] = p[1];
+        sc.world[3 * i + 2] = p[2];
         const int vx = voxel_coord(p[0], m.voxel_size), vy = voxel_coord(p[1], m.voxel_size),
                   vz = voxel_coord(p[2], m.voxel_size);
         int slot = -1;
@@ -988,23 +1299,31 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, const double *in, c
         } else {
             atomicOr(&m.ctr[C_ERR], E_RANGE);
         }
-        slot_of[i] = slot;
-        next[i] = (slot >= 0) ? atomicExch(&m.heads[slot], i) : -2;
+        if (slot < 0) {
+            sc.next[i] = -2;
+            continue;
+        }
+        // the voxel's record of this insert: the first point to arrive opens it.  (A plain read of
+        // heads[] may be stale, but only as "-1": the CAS then returns the true owner.)
+        int t = m.heads[slot];
+        if (t < 0) {
+            const int nt = atomicAdd(touched, 1);
+            const int old = atomicCAS(&m.heads[slot], -1, nt);
+            if (old == -1) {
+                t = nt;
+                sc.rec_slot[nt] = slot;
+            } else {
+                t = old;
+                sc.rec_slot[nt] = -1;  // lost the race: the record stays empty
+            }
+        }
+        const int rank = atomicAdd(&sc.rec_count[t], 1);
+        if (rank < kRecList) sc.rec_list[t * kRecList + rank] = i;
+        sc.next[i] = atomicExch(&sc.rec_head[t], i);
     }
 }
 
-__device__ __forceinline__ int pool_alloc(const MapView &m) {
-    int nf = m.ctr[C_NFREE];
-    while (nf > 0) {
-        const int seen = atomicCAS(&m.ctr[C_NFREE], nf, nf - 1);
-        if (seen == nf) return m.free_ids[nf - 1];
-        nf = seen;
-    }
-    const int b = atomicAdd(&m.ctr[C_BUMP], 1);
-    return (b < m.blocks_cap) ? b : -1;
-}
-
-// serial application of one voxel's list by a single lane (voxels that hold or receive more
+// serial application of one voxel's chain by a single lane (voxels that hold or receive more
 // points than a 32-lane group can keep in registers)
 __device__ void map_apply_voxel_serial(const MapView &m, int slot, int head, int b, const double *world,
                                        const int *next) {
@@ -1015,7 +1334,7 @@ __device__ void map_apply_voxel_serial(const MapView &m, int slot, int head, int
     int cnt = hdr->count;
     int last = -1;
     while (cnt < m.max_points) {  // :104 a full voxel rejects the rest
-        int cur = 0x7FFFFFFF;    // next list entry in ascending point index (= arrival order)
+        int cur = 0x7FFFFFFF;    // next chain entry in ascending point index (= arrival order)
         for (int j = head; j >= 0; j = next[j])
             if (j > last && j < cur) cur = j;
         if (cur == 0x7FFFFFFF) break;
@@ -1039,120 +1358,147 @@ __device__ void map_apply_voxel_serial(const MapView &m, int slot, int head, int
     sl->count = cnt;
 }
 
-// k_map_apply: a 32-lane group owns a tile of kApplyTile consecutive new points and serves the
-// voxel lists opened by them (the opener of a list is its tail: next == -1).  Per voxel: lane k
-// holds stored point k in registers, the new points of the list are ranked by point index
-// (= the reference's arrival order) and offered one after the other; a point is appended (to lane
+// k_map_apply: one 32-lane group per voxel record.  Lane k holds stored point k of the voxel in
+// registers, lane l the l-th incoming point; the incoming points are ranked by point index (= the
+// reference's arrival order) and offered one after the other; a point is appended (to lane
 // `count`) iff the voxel is not full and no stored point -- including the ones appended a moment
-// ago -- is closer than map_resolution (VoxelHashMap.cpp:103-110).  One memory round trip for the
-// stored points, one for the new points, instead of a dependent load per comparison.
-constexpr int kApplyTile = 8;
-__global__ __launch_bounds__(256) void k_map_apply(MapView m, const int *n_ptr, int n_imm,
-                                                   const double *world, const int *slot_of,
-                                                   const int *next) {
-    const int n = count_of(n_ptr, n_imm);
+// ago -- is closer than map_resolution (VoxelHashMap.cpp:103-110).  Every load of a voxel is
+// independent of the others: record -> {slot, list} -> {block, points} is three round trips.
+__global__ __launch_bounds__(256) void k_map_apply(MapView m, InsertScratch sc) {
+    constexpr int kGroups = 256 / 32;
+    __shared__ int sh_need[kGroups];
+    __shared__ int sh_alloc[4];  // queue position, entries available there, bump base, blocks in the pool
     const int lane = threadIdx.x & 31;
-    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int ngrp = (gridDim.x * blockDim.x) >> 5;
-    const int ntiles = (n + kApplyTile - 1) / kApplyTile;
+    const int g = threadIdx.x >> 5;
     const int half_shift = threadIdx.x & 32;  // this group's half of the 64-bit wave ballot
-    // wave-uniform trip count: the two groups of a wave walk tiles grp and grp + 1 in lock step
-    for (int tile = grp; (tile & ~1) < ntiles; tile += ngrp) {
-        const int i = tile * kApplyTile + lane;
-        int my_slot = -1;
-        if (lane < kApplyTile && i < n && next[i] == -1) my_slot = slot_of[i];
-        unsigned leaders = (unsigned)(__ballot(my_slot >= 0) >> half_shift);
-        while (__ballot(leaders != 0) != 0ull) {
-            const bool active = leaders != 0;
-            const int l = active ? (__ffs(leaders) - 1) : 0;
-            leaders &= leaders - 1;
-            const int slot = __shfl(my_slot, l, 32);
-            if (!active) continue;  // (the other group of the wave still has voxels to serve)
-            Slot *sl = m.slots + slot;
-            const int head = m.heads[slot];
-            int b = sl->block;
-            int cnt = 0;
-            if (b < 0) {  // new voxel (VoxelHashMap.cpp:112-116)
-                if (lane == 0) {
-                    b = pool_alloc(m);
-                    if (b >= 0) {
-                        BlockHdr *hdr = block_hdr(m, b);
-                        hdr->key = sl->key;
-                        hdr->slot = slot;
-                        hdr->count = 0;
-                        sl->block = b;
-                        atomicAdd(&m.ctr[C_LIVE], 1);
-                    } else {
-                        atomicOr(&m.ctr[C_ERR], E_POOL_FULL);
-                    }
-                }
-                b = __shfl(b, 0, 32);
-            } else {
-                cnt = sl->count;
+    const int touched = m.ctr[C_TOUCHED0 + sc.parity];
+    // workgroup-uniform trip count: the eight groups of a workgroup allocate their blocks together
+    for (int t0 = blockIdx.x * kGroups; t0 < touched; t0 += gridDim.x * kGroups) {
+        const int t = t0 + g;
+        int slot = -1, L = 0, head = -1, my_idx = 0x7FFFFFFF;
+        if (t < touched) {
+            slot = sc.rec_slot[t];
+            L = sc.rec_count[t];
+            head = sc.rec_head[t];
+            if (lane < L && lane < kRecList) my_idx = sc.rec_list[t * kRecList + lane];
+            if (lane == 0) {  // leave the record idle for the next insert
+                sc.rec_count[t] = 0;
+                sc.rec_head[t] = -1;
             }
+        }
+        Slot *sl = m.slots + max(slot, 0);
+        Slot cur;
+        cur.key = kKeyEmpty;
+        cur.block = -1;
+        cur.count = 0;
+        if (slot >= 0) {
+            cur = load_slot(sl);
             if (lane == 0) m.heads[slot] = -1;
-            if (b < 0) continue;
-            // the list, one entry per lane (walked by every lane: uniform loads)
-            int my_idx = 0x7FFFFFFF, L = 0, walk = head;
-            for (; walk >= 0 && L < 32; walk = next[walk], ++L)
-                if (lane == L) my_idx = walk;
-            if (walk >= 0 || m.max_points > 32) {  // long list or wide voxel: serial fallback
-                if (lane == 0) map_apply_voxel_serial(m, slot, head, b, world, next);
-                continue;
+        }
+        int b = cur.block;
+        int cnt = (b >= 0) ? cur.count : 0;
+        const bool need = slot >= 0 && b < 0;  // new voxel (VoxelHashMap.cpp:112-116)
+        // ---- one allocation per workgroup: recycled blocks first, then fresh ones ------------------
+        if (lane == 0) sh_need[g] = need ? 1 : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+#pragma unroll
+            for (int k = 0; k < kGroups; ++k) total += sh_need[k];
+            int h = 0, avail = 0, bb = 0;
+            if (total > 0) {
+                const unsigned hh = (unsigned)atomicAdd(&m.ctr[C_FHEAD], total);
+                avail = min(max((int)((unsigned)m.ctr[C_FTAIL] - hh), 0), total);
+                h = (int)(hh % (unsigned)m.free_cap);
+                if (total > avail) bb = atomicAdd(&m.ctr[C_BUMP], total - avail);
+                const int fresh_ok = min(max(m.blocks_cap - bb, 0), total - avail);
+                atomicAdd(&m.ctr[C_LIVE], avail + fresh_ok);
+                if (fresh_ok < total - avail) atomicOr(&m.ctr[C_ERR], E_POOL_FULL);
             }
-            double2 *pxy = block_xy(m, b);
-            double *pz = block_z(m, b);
-            double ex = 0.0, ey = 0.0, ez = 0.0;  // stored point `lane`
-            if (lane < cnt) {
-                const double2 xy = pxy[lane];
-                ex = xy.x;
-                ey = xy.y;
-                ez = pz[lane];
+            sh_alloc[0] = h;
+            sh_alloc[1] = avail;
+            sh_alloc[2] = bb;
+        }
+        __syncthreads();
+        if (need) {
+            int k = 0;
+            for (int q = 0; q < g; ++q) k += sh_need[q];
+            if (k < sh_alloc[1]) {
+                b = m.free_ids[(sh_alloc[0] + k) % m.free_cap];
+            } else {
+                b = sh_alloc[2] + (k - sh_alloc[1]);
+                if (b >= m.blocks_cap) b = -1;
             }
-            double nx = 0.0, ny = 0.0, nz = 0.0;  // new point held by this lane
-            if (lane < L) {
-                nx = world[3 * my_idx];
-                ny = world[3 * my_idx + 1];
-                nz = world[3 * my_idx + 2];
+            if (b >= 0 && lane == 0) {
+                BlockHdr *hdr = block_hdr(m, b);
+                hdr->key = cur.key;
+                hdr->slot = slot;
+                hdr->count = 0;
+                sl->block = b;
             }
-            int rank = 0;  // position of this lane's point in ascending point index
-            for (int j = 0; j < L; ++j) rank += (__shfl(my_idx, j, 32) < my_idx) ? 1 : 0;
-            const int cnt0 = cnt;
-            for (int r = 0; r < L && cnt < m.max_points; ++r) {  // :104 a full voxel rejects the rest
-                const unsigned who = (unsigned)(__ballot(lane < L && rank == r) >> half_shift);
-                const int src = __ffs(who) - 1;
-                const double qx = __shfl(nx, src, 32), qy = __shfl(ny, src, 32), qz = __shfl(nz, src, 32);
-                bool close = false;
-                if (lane < cnt) {  // :105-108 (norm < map_resolution, strict)
-                    const double dx = ex - qx, dy = ey - qy, dz = ez - qz;
-                    close = sqrt((dx * dx + dy * dy) + dz * dz) < m.map_resolution;
+        }
+        __syncthreads();  // sh_need / sh_alloc are reused by the next trip
+        if (slot < 0 || b < 0) continue;  // idle group, a record that lost its race, or pool exhausted
+        if (L > kRecList || m.max_points > 32) {  // long list or wide voxel: serial fallback over the chain
+            if (lane == 0) map_apply_voxel_serial(m, slot, head, b, sc.world, sc.next);
+            continue;
+        }
+        double2 *pxy = block_xy(m, b);
+        double *pz = block_z(m, b);
+        double ex = 0.0, ey = 0.0, ez = 0.0;  // stored point `lane`
+        if (lane < cnt) {
+            const double2 xy = pxy[lane];
+            ex = xy.x;
+            ey = xy.y;
+            ez = pz[lane];
+        }
+        double nx = 0.0, ny = 0.0, nz = 0.0;  // incoming point held by this lane
+        if (lane < L) {
+            nx = sc.world[3 * my_idx];
+            ny = sc.world[3 * my_idx + 1];
+            nz = sc.world[3 * my_idx + 2];
+        }
+        int rank = 0;  // position of this lane's point in ascending point index
+        for (int j = 0; j < L; ++j) rank += (__shfl(my_idx, j, 32) < my_idx) ? 1 : 0;
+        const int cnt0 = cnt;
+        for (int r = 0; r < L && cnt < m.max_points; ++r) {  // :104 a full voxel rejects the rest
+            const unsigned who = (unsigned)(__ballot(lane < L && rank == r) >> half_shift);
+            const int src = __ffs(who) - 1;
+            const double qx = __shfl(nx, src, 32), qy = __shfl(ny, src, 32), qz = __shfl(nz, src, 32);
+            bool close = false;
+            if (lane < cnt) {  // :105-108 (norm < map_resolution, strict)
+                const double dx = ex - qx, dy = ey - qy, dz = ez - qz;
+                close = sqrt((dx * dx + dy * dy) + dz * dz) < m.map_resolution;
+            }
+            if (((unsigned)(__ballot(close) >> half_shift)) == 0u) {
+                if (lane == cnt) {
+                    ex = qx;
+                    ey = qy;
+                    ez = qz;
                 }
-                if (((unsigned)(__ballot(close) >> half_shift)) == 0u) {
-                    if (lane == cnt) {
-                        ex = qx;
-                        ey = qy;
-                        ez = qz;
-                    }
-                    ++cnt;
-                }
+                ++cnt;
             }
-            if (lane >= cnt0 && lane < cnt) {
-                pxy[lane] = make_double2(ex, ey);
-                pz[lane] = ez;
-            }
-            if (lane == 0) {
-                block_hdr(m, b)->count = cnt;
-                sl->count = cnt;
-            }
+        }
+        if (lane >= cnt0 && lane < cnt) {
+            pxy[lane] = make_double2(ex, ey);
+            pz[lane] = ez;
+        }
+        if (lane == 0) {
+            block_hdr(m, b)->count = cnt;
+            sl->count = cnt;
         }
     }
 }
 
 // VoxelHashMap::RemovePointsFarFromLocation (VoxelHashMap.cpp:121-132): a voxel dies iff its
 // FIRST point is >= max_distance from the origin.  Tombstone the slot, recycle the block.
+// When host_rec is given (pipeline mode: this is the last kernel of a frame) the workgroup that
+// finishes last copies the map counters and the PipeState behind them -- rec_words 32-bit words,
+// contiguous in HBM -- straight into the frame's slot of the host-pinned ring: no blit kernel.
 __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *state,
                                                    int use_state_origin, double ox, double oy,
-                                                   double oz, PipeState *reset_state) {
+                                                   double oz, PipeState *reset_state, unsigned *host_rec,
+                                                   int rec_words) {
     if (use_state_origin) {
         ox = state->new_pose.t[0];
         oy = state->new_pose.t[1];
@@ -1171,8 +1517,8 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
             sl->block = -1;
             sl->count = 0;
             hdr->count = 0;
-            const int k = atomicAdd(&m.ctr[C_NFREE], 1);
-            m.free_ids[k] = b;
+            const unsigned k = (unsigned)atomicAdd(&m.ctr[C_FPEND], 1);
+            m.free_ids[k % (unsigned)m.free_cap] = b;
             atomicSub(&m.ctr[C_LIVE], 1);
             atomicAdd(&m.ctr[C_TOMB], 1);
         }
@@ -1180,6 +1526,25 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
     if (reset_state && blockIdx.x == 0 && threadIdx.x == 0) {  // re-arm the per-frame words
         reset_state->tmin_bits = ~0ull;
         reset_state->tmax_bits = 0ull;
+    }
+    if (host_rec) {
+        __shared__ int sh_last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();  // this workgroup's counter updates are out before it signs off
+            sh_last = (atomicAdd(&m.ctr[C_DONE], 1) == (int)gridDim.x - 1);
+        }
+        __syncthreads();
+        if (sh_last) {
+            __threadfence();
+            const unsigned *src = reinterpret_cast<const unsigned *>(m.ctr);
+            for (int w = threadIdx.x; w < rec_words; w += blockDim.x) {
+                unsigned v = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w == C_DONE) v = 0;
+                host_rec[w] = v;
+            }
+            if (threadIdx.x == 0) m.ctr[C_DONE] = 0;
+        }
     }
 }
 
@@ -1229,8 +1594,6 @@ static inline int grid_for(long n, int threads, int cap) {
 
 size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums; }
 
-constexpr int kIcpLdsBytes = 160 * 1024;  // one workgroup per CU owns the whole LDS
-
 int icp_prepare() {
     // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute)
     static bool done = false;
@@ -1245,7 +1608,6 @@ int icp_prepare() {
     return 0;
 }
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s) {
-    P.lds_bytes = kIcpLdsBytes;
     if (profile)
         hipLaunchKernelGGL(k_icp<true>, dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
     else
@@ -1274,23 +1636,21 @@ void launch_ds_flags(const DsParams &P, hipStream_t s) {
 void launch_ds_scatter(const DsParams &P, hipStream_t s) {
     hipLaunchKernelGGL(k_ds_scatter, dim3(grid_for(P.n_max, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
 }
-void launch_map_link(const MapView &m, const double *in, const int *n_ptr, int n_imm, int n_max,
-                     const PipeState *state, int use_pose, double *world, int *slot_of, int *next,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(k_map_link, dim3(grid_for(n_max, 256, 2048)), dim3(256), 0, s, m, in, n_ptr, n_imm,
-                       state, use_pose, world, slot_of, next);
+void launch_map_link(const MapView &m, const InsertScratch &sc, const double *in, const int *n_ptr, int n_imm,
+                     int n_max, const PipeState *state, int use_pose, hipStream_t s) {
+    hipLaunchKernelGGL(k_map_link, dim3(grid_for(n_max, 256, 2048)), dim3(256), 0, s, m, sc, in, n_ptr, n_imm, state,
+                       use_pose);
 }
-void launch_map_apply(const MapView &m, const int *n_ptr, int n_imm, int n_max, const double *world,
-                      const int *slot_of, const int *next, hipStream_t s) {
-    // one 32-lane group per tile of kApplyTile points
-    hipLaunchKernelGGL(k_map_apply, dim3(grid_for(((long)n_max + kApplyTile - 1) / kApplyTile * 32, 256, 2048)), dim3(256), 0,
-                       s, m, n_ptr, n_imm, world, slot_of, next);
+void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipStream_t s) {
+    // one 32-lane group per voxel record (at most one record per incoming point)
+    hipLaunchKernelGGL(k_map_apply, dim3(grid_for((long)n_max * 32, 256, 2048)), dim3(256), 0, s, m, sc);
 }
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
-                      const double origin[3], PipeState *reset_state, hipStream_t s) {
+                      const double origin[3], PipeState *reset_state, unsigned *host_rec, int rec_words,
+                      hipStream_t s) {
     hipLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 2048)), dim3(256), 0, s, m, state,
                        use_state_origin, origin ? origin[0] : 0.0, origin ? origin[1] : 0.0,
-                       origin ? origin[2] : 0.0, reset_state);
+                       origin ? origin[2] : 0.0, reset_state, host_rec, rec_words);
 }
 void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s) {
     hipLaunchKernelGGL(k_map_rehash, dim3(grid_for(bump_ub, 256, 2048)), dim3(256), 0, s, m);

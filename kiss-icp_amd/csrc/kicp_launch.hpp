@@ -59,13 +59,12 @@ void launch_pre_scatter(const PreParams &P, hipStream_t s);
 void launch_ds_claim(const DsParams &P, hipStream_t s);
 void launch_ds_flags(const DsParams &P, hipStream_t s);
 void launch_ds_scatter(const DsParams &P, hipStream_t s);
-void launch_map_link(const MapView &m, const double *in, const int *n_ptr, int n_imm, int n_max,
-                     const PipeState *state, int use_pose, double *world, int *slot_of, int *next,
-                     hipStream_t s);
-void launch_map_apply(const MapView &m, const int *n_ptr, int n_imm, int n_max, const double *world,
-                      const int *slot_of, const int *next, hipStream_t s);
+void launch_map_link(const MapView &m, const InsertScratch &sc, const double *in, const int *n_ptr, int n_imm,
+                     int n_max, const PipeState *state, int use_pose, hipStream_t s);
+void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipStream_t s);
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
-                      const double origin[3], PipeState *reset_state, hipStream_t s);
+                      const double origin[3], PipeState *reset_state, unsigned *host_rec, int rec_words,
+                      hipStream_t s);
 void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s);
 void launch_map_count_points(const MapView &m, long bump_ub, hipStream_t s);
 

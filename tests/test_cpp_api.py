@@ -1,0 +1,140 @@
+"""The C++ drop-in surface and the reference-named pybind module.
+
+CPU: both build, the pybind module imports and exposes the reference's names / kwargs
+(python/kiss_icp/pybind/kiss_icp_pybind.cpp:48-144).  GPU: the C++ test program
+(tests/cpp/test_cpp_api.cpp, HIP path vs the oracle) passes, and the reference's own Python
+composition (python/kiss_icp/kiss_icp.py:43-80 restated over the pybind module's classes) tracks the
+oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "kiss-icp_amd", "cpp")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "kiss-icp_amd", "csrc")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CPP], stdout=subprocess.DEVNULL)
+    if CPP not in sys.path:
+        sys.path.insert(0, CPP)
+    import kiss_icp_pybind
+
+    return kiss_icp_pybind
+
+
+def test_pybind_surface_matches_reference_names(built):
+    m = built
+    for name in ("_Vector3dVector", "_VoxelHashMap", "_Preprocessor", "_Registration", "_AdaptiveThreshold",
+                 "_voxel_down_sample", "_correct_kitti_scan"):
+        assert hasattr(m, name), name
+    for meth in ("_clear", "_empty", "_update", "_add_points", "_remove_far_away_points", "_point_cloud"):
+        assert hasattr(m._VoxelHashMap, meth), meth
+    assert hasattr(m._Registration, "_align_points_to_map")
+    assert "max_correspondance_distance" in m._Registration._align_points_to_map.__doc__  # the reference's spelling
+    assert hasattr(m._Preprocessor, "_preprocess")
+    assert hasattr(m._AdaptiveThreshold, "_compute_threshold") and hasattr(m._AdaptiveThreshold, "_update_model_deviation")
+
+
+def test_vector3dvector_semantics(built):
+    a = np.arange(12, dtype=np.float64).reshape(4, 3)
+    v = built._Vector3dVector(a)
+    assert len(v) == 4 and bool(v)
+    assert np.array_equal(np.asarray(v), a)  # buffer protocol, zero-copy view of the vector
+    assert not built._Vector3dVector(np.zeros((0, 3)))
+    v32 = built._Vector3dVector(a.astype(np.float32))  # forcecast like the reference
+    assert np.array_equal(np.asarray(v32), a)
+    with pytest.raises(Exception):
+        built._Vector3dVector(np.zeros((4, 2)))
+
+
+def test_host_side_pieces_need_no_gpu(built):
+    # AdaptiveThreshold is O(1) host arithmetic (core/Threshold.cpp:38-49)
+    from oracle import oracle as O
+
+    t, o = built._AdaptiveThreshold(2.0, 0.1, 100.0), O.AdaptiveThreshold(2.0, 0.1, 100.0)
+    assert t._compute_threshold() == 2.0
+    rng = np.random.default_rng(0)
+    from helpers import make_pose
+
+    for _ in range(20):
+        dev = make_pose(rng.normal(scale=0.3, size=3), rng.normal(scale=0.01, size=3))
+        t._update_model_deviation(dev)
+        o.update_model_deviation(dev)
+        assert t._compute_threshold() == pytest.approx(o.get_threshold(), rel=1e-12)
+    with pytest.raises(ValueError):
+        t._update_model_deviation(np.diag([2.0, 1, 1, 1]))  # not a rigid transform
+    # _correct_kitti_scan: rotation by 0.205 deg about pt x e_z (kiss_icp_pybind.cpp:127-138)
+    pts = rng.normal(size=(100, 3)) * 20
+    out = np.asarray(built._correct_kitti_scan(built._Vector3dVector(pts)))
+    from scipy.spatial.transform import Rotation
+
+    for p, q in zip(pts, out):
+        axis = np.cross(p, [0.0, 0.0, 1.0])
+        want = Rotation.from_rotvec(axis / np.linalg.norm(axis) * np.deg2rad(0.205)).apply(p)
+        np.testing.assert_allclose(q, want, rtol=0, atol=1e-12)
+
+
+def test_no_gpu_is_a_loud_error_in_cpp_too(built):
+    from kiss_icp_amd import _cabi
+
+    if _cabi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError) as e:
+        built._VoxelHashMap(1.0, 100.0, 20)
+    assert "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_cpp_program_against_oracle(gpu, built):
+    r = subprocess.run([os.path.join(CPP, "test_cpp_api")], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_python_composition_on_pybind_module(gpu, built):
+    """python/kiss_icp/kiss_icp.py:43-80 line for line, on kiss_icp_pybind's classes"""
+    from helpers import pose_error
+    from kiss_icp_amd.datasets import kitti_like
+    from oracle import oracle as O
+
+    m = built
+    V = m._Vector3dVector
+    pre = m._Preprocessor(100.0, 0.0, False, 0)
+    reg = m._Registration(500, 1e-4, 0)
+    vmap = m._VoxelHashMap(1.0, 100.0, 20)
+    thr = m._AdaptiveThreshold(2.0, 0.1, 100.0)
+    last_pose, last_delta = np.eye(4), np.eye(4)
+    ko = O.KissICP(deskew=0)
+    ds = kitti_like(seed=2, n_frames=6, beams=32, azimuth_steps=512)
+    for i in range(6):
+        pts, ts = ds[i]
+        frame = np.asarray(pre._preprocess(V(pts), ts, last_delta))
+        fd = np.asarray(m._voxel_down_sample(V(frame), 0.5))
+        source = np.asarray(m._voxel_down_sample(V(fd), 1.5))
+        sigma = thr._compute_threshold()
+        guess = last_pose @ last_delta
+        new_pose = reg._align_points_to_map(points=V(source), voxel_map=vmap, initial_guess=guess,
+                                            max_correspondance_distance=3 * sigma, kernel=sigma)
+        thr._update_model_deviation(np.linalg.inv(guess) @ new_pose)
+        vmap._update(V(fd), new_pose)
+        last_delta = np.linalg.inv(last_pose) @ new_pose
+        last_pose = new_pose
+        ko.register_frame(pts, ts)
+        dt, dr = pose_error(ko.last_pose, last_pose)
+        assert dt < 1e-6 and dr < 1e-6, (i, dt, dr)
+    # and the fused pipeline class
+    cfg = m._KISSConfig()
+    cfg.deskew = False
+    k = m._KissICP(cfg)
+    for i in range(6):
+        k._register_frame(V(ds[i][0]), [])
+    dt, dr = pose_error(ko.last_pose, k._pose())
+    assert dt < 1e-7 and dr < 1e-7

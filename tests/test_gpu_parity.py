@@ -346,3 +346,107 @@ def test_pipeline_async_device_frames_match_sync(gpu, O):
     for i, s in enumerate(scans):
         ks.register_frame(s)
         assert np.array_equal(ks.last_pose, poses_async[i]), i
+
+
+# ---- committed golden fixtures (tests/golden/, made by tests/golden/make_golden.py) ----------------------
+def _golden(name):
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    return np.load(path)
+
+
+def test_golden_downsample_gpu(gpu):
+    from kiss_icp_amd.voxelization import voxel_down_sample
+
+    g = _golden("downsample.npz")
+    assert np.array_equal(voxel_down_sample(g["points"], 0.5), g["out_050"])
+    assert np.array_equal(voxel_down_sample(g["points"], 1.5), g["out_150"])
+
+
+def test_golden_map_and_neighbors_gpu(gpu):
+    from kiss_icp_amd.mapping import VoxelHashMap
+
+    g = _golden("map_nn.npz")
+    m = VoxelHashMap(1.0, 30.0, 20)
+    for k in range(int(g["n_updates"])):
+        m.update(g[f"pts_{k}"], g[f"pose_{k}"])
+    np.testing.assert_allclose(sort_rows(m.point_cloud()), g["cloud_sorted"], rtol=0, atol=1e-12)
+    nn, dist = m.closest_neighbor(g["queries"])
+    np.testing.assert_allclose(nn, g["nn"], rtol=0, atol=1e-12)
+    found = g["dist"] < 1e300
+    np.testing.assert_allclose(dist[found], g["dist"][found], rtol=0, atol=1e-12)
+    assert np.array_equal(dist[~found], g["dist"][~found])
+
+
+def test_golden_align_gpu(gpu):
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    g = _golden("align.npz")
+    m = VoxelHashMap(1.0, 100.0, 20)
+    m.add_points(g["world"])
+    reg = Registration(500, 1e-4)
+    T = reg.align_points_to_map(g["frame"], m, g["guess"], float(g["max_dist"]), float(g["kernel"]))
+    assert reg.last_stats["iterations"] == int(g["iterations"])
+    dt, dr = pose_error(g["T"], T)
+    assert dt < TIGHT and dr < TIGHT, (dt, dr)
+
+
+def test_golden_sequence_gpu(gpu):
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.kiss_icp import KissICP
+
+    g = _golden("sequence.npz")
+    k = KissICP(load_config(deskew=False))
+    for i in range(int(g["n_frames"])):
+        k.register_frame(g[f"scan_{i}"])
+        dt, dr = pose_error(g["poses"][i], k.last_pose)
+        assert dt < TIGHT and dr < TIGHT, (i, dt, dr)
+        assert k.last_stats()["icp"]["iterations"] == int(g["iterations"][i])
+
+
+# ---- full-size, size-independent properties (no oracle needed) --------------------------------------------
+def test_downsample_properties_at_full_size(gpu):
+    """1M points: idempotence, one survivor per voxel, survivors are a subsequence of the input"""
+    from kiss_icp_amd.voxelization import voxel_down_sample
+
+    rng = np.random.default_rng(77)
+    pts = random_cloud(rng, 1_000_000, extent=80.0, z_extent=6.0)
+    for v in (0.5, 1.5):
+        out = voxel_down_sample(pts, v)
+        vox = np.floor(out / v).astype(np.int64)
+        assert len(np.unique(vox, axis=0)) == len(out)  # one point per voxel
+        assert len(out) == len(np.unique(np.floor(pts / v).astype(np.int64), axis=0))  # every voxel kept
+        assert np.array_equal(voxel_down_sample(out, v), out)  # idempotent
+        # keep-first: each survivor is the first input point of its voxel
+        keys = np.floor(pts / v).astype(np.int64)
+        _, first = np.unique(keys, axis=0, return_index=True)
+        assert np.array_equal(out, pts[np.sort(first)])
+
+
+def test_map_properties_at_full_size(gpu):
+    """a 300k-point insert: per-voxel cap and spacing invariants, idempotent re-insert, NN of a stored
+    point is itself at distance 0"""
+    from kiss_icp_amd.mapping import VoxelHashMap
+
+    rng = np.random.default_rng(78)
+    pts = random_cloud(rng, 300_000, extent=60.0, z_extent=3.0)
+    m = VoxelHashMap(1.0, 100.0, 20)
+    m.add_points(pts)
+    cloud = m.point_cloud()
+    keys = np.floor(cloud).astype(np.int64)
+    _, counts = np.unique(keys, axis=0, return_counts=True)
+    assert counts.max() <= 20 and m.num_voxels() == len(counts)
+    nv, npts = m.num_voxels(), len(cloud)
+    m.add_points(cloud)  # every stored point is closer than map_resolution to itself: nothing changes
+    assert (m.num_voxels(), len(m.point_cloud())) == (nv, npts)
+    sel = cloud[rng.choice(len(cloud), 5000, replace=False)]
+    nn, dist = m.closest_neighbor(sel)
+    assert np.array_equal(nn, sel) and not dist.any()
+    # spacing rule inside a voxel: pairwise distances >= sqrt(v^2 / max_points)
+    order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+    ck, cp = keys[order], cloud[order]
+    same = np.all(ck[1:] == ck[:-1], axis=1)
+    d = np.linalg.norm(cp[1:] - cp[:-1], axis=1)[same]
+    assert d.min() >= np.sqrt(1.0 / 20.0)
