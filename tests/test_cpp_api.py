@@ -21,6 +21,7 @@ def built():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "kiss-icp_amd", "csrc")], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", CPP], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     if CPP not in sys.path:
         sys.path.insert(0, CPP)
     import kiss_icp_pybind
@@ -92,7 +93,7 @@ def test_no_gpu_is_a_loud_error_in_cpp_too(built):
 
 @pytest.mark.gpu
 def test_cpp_program_against_oracle(gpu, built):
-    r = subprocess.run([os.path.join(CPP, "test_cpp_api")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_cpp_api")], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
