@@ -209,6 +209,13 @@ int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgro
  * iteration in 10 ns ticks: workgroup 0's {associate, publish, gather, solve}, the slowest
  * 32-lane group's associate time over all workgroups, gather polling passes of workgroup 0 */
 int kicp_pipeline_icp_iteration_profile(kicp_pipeline *p, uint32_t *out, int cap_iters, int *n_iters);
+/* per-GROUP records of the LAST ICP launch ("icp_profile" = 1 only): for each of the first *n_iters
+ * iterations and each of the *n_groups 32-lane groups, 4 uint32: {wait-in | transform+window test << 16,
+ * window fill | scan << 16} in 10 ns ticks, {staged points | examined points << 16}, path (0 staged
+ * 27-voxel window, 1 staged widened window, 2 window staged in this iteration, 3 direct HBM search).
+ * out must hold n_iters * n_groups * 4 words (cap_words) */
+int kicp_pipeline_icp_group_profile(kicp_pipeline *p, uint32_t *out, size_t cap_words, int *n_iters,
+                                    int *n_groups);
 /* the HIP stream (hipStream_t) the pipeline launches on, as an opaque pointer */
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
 

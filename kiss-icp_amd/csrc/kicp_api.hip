@@ -790,7 +790,7 @@ struct kicp_pipeline {
     hipStream_t stream = nullptr;
     kicp_config cfg;
     kicp_map *map = nullptr;
-    DevBuf raw, ts, tmp, pre, fd, src, work, slot1, slot2, tab1, tab2, counts, granules;
+    DevBuf raw, ts, tmp, pre, fd, src, work, slot1, slot2, tab1, tab2, counts, granules, prof_groups;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -932,6 +932,10 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     I.conv = c.convergence_criterion;
     I.granules = p->granules.as<unsigned long long>();
     I.spin_limit = kSpinLimit;
+    if (options().icp_profile != 0) {
+        KICP_TRY(p->prof_groups.reserve(kIcpGroupProfileWords * sizeof(unsigned)));
+        I.prof_groups = p->prof_groups.as<unsigned>();
+    }
     const int slot = p->in_flight;
     const bool timing = options().icp_timing != 0 && p->ev_ok;
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][0], s));
@@ -1026,7 +1030,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd, &p->src, &p->work, &p->slot1,
-                      &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules})
+                      &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups})
         b->release();
     if (p->ev_ok)
         for (int i = 0; i < kicp_pipeline::kRing; ++i)
@@ -1236,6 +1240,24 @@ int kicp_pipeline_icp_iteration_profile(kicp_pipeline *p, uint32_t *out, int cap
     if (n > cap_iters) n = cap_iters;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < 6; ++j) out[i * 6 + j] = h.prof_iter[i][j];
+    return KICP_OK;
+}
+
+int kicp_pipeline_icp_group_profile(kicp_pipeline *p, uint32_t *out, size_t cap_words, int *n_iters, int *n_groups) {
+    if (!p || !out || !n_iters || !n_groups) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    *n_iters = *n_groups = 0;
+    if (!p->have_last || !p->prof_groups.p) return KICP_OK;
+    const int iters = p->last.st.icp_iterations < kIcpProfIters ? p->last.st.icp_iterations : kIcpProfIters;
+    const int groups = p->last.st.icp_blocks_used * kIcpGroupsPerBlock;
+    if ((size_t)iters * groups * 4 > cap_words) return KICP_ERR_INVALID_ARG;
+    for (int it = 0; it < iters; ++it)
+        KICP_HIP(hipMemcpy(out + (size_t)it * groups * 4,
+                           p->prof_groups.as<unsigned>() + (size_t)it * kIcpMaxBlocks * kIcpGroupsPerBlock * 4,
+                           (size_t)groups * 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    *n_iters = iters;
+    *n_groups = groups;
     return KICP_OK;
 }
 

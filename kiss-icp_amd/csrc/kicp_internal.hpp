@@ -147,6 +147,7 @@ constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gathe
 constexpr int kIcpMaxBlocks = 256;
 constexpr int kIcpMaxCachedRounds = 4;  // rounds of a group whose neighbourhood may be staged in LDS
 constexpr int kIcpLdsBytes = 160 * 1024;  // one workgroup per CU owns the whole LDS
+constexpr size_t kIcpGroupProfileWords = (size_t)kIcpProfIters * kIcpMaxBlocks * kIcpGroupsPerBlock * 4;
 
 // LDS record of one (round, group) query of the persistent ICP kernel
 struct IcpRegionMeta {
@@ -186,6 +187,7 @@ struct IcpParams {
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
     int use_lds;           // stage candidate voxels in LDS (0 disables)
+    unsigned *prof_groups;  // profiling variant only: [kIcpProfIters][256 * 16][4] per-group records, or nullptr
 };
 
 // ---- host-side objects ------------------------------------------------------------------------

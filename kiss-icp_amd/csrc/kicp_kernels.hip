@@ -369,7 +369,7 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
             const int iz = w % nn[2], t = w / nn[2], iy = t % nn[1], ix = t / nn[1];
             const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
             const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
-            code[h] = (ox + 2) | ((oy + 2) << 3) | ((oz + 2) << 6);
+            code[h] = w;  // cell number in window order (x-major, z fastest)
             if (voxel_in_range(qx, qy, qz)) {
                 ok[h] = true;
                 key[h] = pack_voxel(qx, qy, qz);
@@ -449,7 +449,7 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
                 X[c] = xy[u].x;
                 Y[c] = xy[u].y;
                 Z[c] = zz[u];
-                T[c] = (unsigned short)(((info[u] >> 18) & 511) | (lane << 9));
+                T[c] = (unsigned short)(((info[u] >> 18) & 63) | (lane << 6));  // {cell, index in voxel}
             }
         }
     }
@@ -472,56 +472,107 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
     return true;
 }
 
-// GetClosestNeighbor over a staged window: the query sits in the voxel at offset (dx, dy, dz) from
-// the window's centre voxel.  Returns the squared distance, the neighbour, and the number of map
-// points in the 27-voxel neighbourhood (= points the reference examines).
-//   FILTER = false: the window is exactly the query's 27 voxels (no widened side, query still in
-//   the centre voxel), every staged point is a candidate and the tags are only read on a new minimum.
+// ---- scan of a staged window ---------------------------------------------------------------------
+// A staged point carries the tag {cell of its voxel in the window (6 bits), index inside the voxel
+// (5 bits)}.  The query sits in the voxel at offset d = (dx, dy, dz) from the window's centre voxel;
+// its candidates are the points whose cell lies in [d-1, d+1]^3 -- the reference's 27 voxels.
+struct WindowGeom {
+    int lo0, lo1, lo2;  // window extent (voxels relative to the centre voxel), low corner
+    int n1, n2;         // cells along y and z (3 or 4)
+    int dx, dy, dz;     // query voxel relative to the centre voxel
+};
+__device__ __forceinline__ int div34(int w, int n) { return n == 4 ? (w >> 2) : ((w * 43) >> 7); }  // w < 128
+// position of cell w's voxel in the reference's shift table (VoxelHashMap.cpp:35-41), seen from the query
+__device__ __forceinline__ int cell_shift_order(int w, const WindowGeom &g) {
+    const int t = div34(w, g.n2), iz = w - t * g.n2;
+    const int ix = div34(t, g.n1), iy = t - ix * g.n1;
+    const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
+    return shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1));
+}
+__device__ __forceinline__ int tag_order_key(int tag, const WindowGeom &g) {
+    return (cell_shift_order(tag & 63, g) << 5) | ((tag >> 6) & 31);
+}
+
+// Returns the squared distance (DBL_MAX: no candidate), the neighbour, and the number of map points
+// in the query's 27-voxel neighbourhood (= points the reference examines).  Four candidates per
+// lane are in flight per trip (all LDS reads issued before the first use), no divergent control
+// flow on the common path: the reference's tie rules (strict '<' in shift order, then
+// std::min_element's first minimum) only cost anything when two distances are EQUAL.
+//   FILTER = false: the window is exactly the query's 27 voxels (no widened side, d = 0).
 template <bool FILTER>
-__device__ __forceinline__ double scan_window(const double *region, int E, int dx, int dy, int dz, double sx,
+__device__ __forceinline__ double scan_window(const double *region, int E, int W, const WindowGeom &g, double sx,
                                               double sy, double sz, int lane, double nn[3], int &examined) {
+    constexpr int U = 4;
     const double *X = region, *Y = X + E, *Z = Y + E;
     const unsigned short *T = reinterpret_cast<const unsigned short *>(Z + E);
-    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
-    int bkey = 0x7FFFFFFF, inside = 0;
-    for (int c = lane; c < E; c += 32) {
-        int tag = 0, ox = 0, oy = 0, oz = 0;
-        if (FILTER) {
-            tag = T[c];
-            ox = (tag & 7) - 2 - dx;
-            oy = ((tag >> 3) & 7) - 2 - dy;
-            oz = ((tag >> 6) & 7) - 2 - dz;
-            if (!((unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u)) continue;
-            ++inside;
-        }
-        const double x = X[c], y = Y[c], z = Z[c];
-        const double ex = x - sx, ey = y - sy, ez = z - sz;
-        const double d = (ex * ex + ey * ey) + ez * ez;
-        if (d <= best) {
-            if (!FILTER) {
-                tag = T[c];
-                ox = (tag & 7) - 2;
-                oy = ((tag >> 3) & 7) - 2;
-                oz = ((tag >> 6) & 7) - 2;
-            }
-            const int key = (shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)) << 7) | (tag >> 9);
-            if (d < best || key < bkey) {
-                best = d;
-                bx = x;
-                by = y;
-                bz = z;
-                bkey = key;
-            }
-        }
-    }
-    if (FILTER) {
+    const int half_shift = threadIdx.x & 32;
+    unsigned long long inmask = ~0ull;
+    if (FILTER) {  // which cells of the window belong to the query's 27 voxels: lane j answers for cells j, j + 32
+        bool in[2];
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) inside += __shfl_xor(inside, off, 32);
-        examined = inside;
-    } else {
-        examined = E;
+        for (int h = 0; h < 2; ++h) {
+            const int w = lane + 32 * h;
+            const int t = div34(w, g.n2), iz = w - t * g.n2;
+            const int ix = div34(t, g.n1), iy = t - ix * g.n1;
+            const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
+            in[h] = w < W && (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
+        }
+        inmask = (unsigned long long)(unsigned)(__ballot(in[0]) >> half_shift) |
+                 ((unsigned long long)(unsigned)(__ballot(in[1]) >> half_shift) << 32);
     }
-    return group_argmin(best, bkey, bx, by, bz, lane, nn);
+    double best = DBL_MAX;
+    int bc = -1, btag = 0, inside = 0;
+    for (int c0 = lane; __ballot(c0 < E) != 0ull; c0 += 32 * U) {  // wave-uniform trip count (ballots inside)
+        int tag[U];
+        double x[U], y[U], z[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 32 * u;
+            ok[u] = c < E;
+            const int cc = ok[u] ? c : 0;
+            tag[u] = ok[u] ? (int)T[cc] : 0;
+            x[u] = X[cc];
+            y[u] = Y[cc];
+            z[u] = Z[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool v = ok[u] && (!FILTER || ((inmask >> (tag[u] & 63)) & 1ull));
+            if (FILTER) inside += __popc((unsigned)(__ballot(v) >> half_shift));
+            const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
+            const double d = (ex * ex + ey * ey) + ez * ez;
+            if (v && d <= best) {
+                bool take = d < best;
+                if (!take) take = tag_order_key(tag[u], g) < tag_order_key(btag, g);  // exact tie (rare)
+                if (take) {
+                    best = d;
+                    bc = c0 + 32 * u;
+                    btag = tag[u];
+                }
+            }
+        }
+    }
+    examined = FILTER ? inside : E;
+    // lexicographic min over (distance, reference order) across the 32 lanes; the winner's
+    // coordinates are then read back from LDS by every lane (same address: broadcast)
+    int bkey = bc >= 0 ? tag_order_key(btag, g) : 0x7FFFFFFF;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 32);
+        const int ok2 = __shfl_xor(bkey, off, 32);
+        const int oc = __shfl_xor(bc, off, 32);
+        if (ob < best || (ob == best && ok2 < bkey)) {
+            best = ob;
+            bkey = ok2;
+            bc = oc;
+        }
+    }
+    const int rc = bc >= 0 ? bc : 0;
+    nn[0] = E > 0 ? X[rc] : 0.0;
+    nn[1] = E > 0 ? Y[rc] : 0.0;
+    nn[2] = E > 0 ? Z[rc] : 0.0;
+    return best;
 }
 
 __device__ __forceinline__ double closest_neighbor_any(const MapView &m, double sx, double sy, double sz,
@@ -663,6 +714,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         for (int p = blockIdx.x + G * grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
             const bool has_meta = round < cached_rounds;
             IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
+            const unsigned long long ta = PROF ? wall_clock64() : 0ull;
             double pin[3];
             if (it > 0 && has_meta) {  // running source point lives in LDS
                 pin[0] = meta->s[0];
@@ -695,22 +747,46 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     P.work[3 * p + 2] = s[2];
                 }
             }
-            if (!cached && has_meta && meta->cap >= 0)
+            int path = cached ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
+            const unsigned long long tb = PROF ? wall_clock64() : 0ull;
+            if (!cached && has_meta && meta->cap >= 0) {
                 cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
+                if (cached) path = 2;
+            }
+            const unsigned long long tc = PROF ? wall_clock64() : 0ull;
             double nn[3];
             double d2;
             int E;
             if (cached) {
-                const int ddx = vx - meta->v[0], ddy = vy - meta->v[1], ddz = vz - meta->v[2];
-                const bool exact27 = meta->lo[0] == -1 && meta->hi[0] == 1 && meta->lo[1] == -1 && meta->hi[1] == 1 &&
-                                     meta->lo[2] == -1 && meta->hi[2] == 1;  // (then ddx = ddy = ddz = 0)
-                d2 = exact27 ? scan_window<false>(pool + meta->base, meta->E, 0, 0, 0, s[0], s[1], s[2], lane, nn, E)
-                             : scan_window<true>(pool + meta->base, meta->E, ddx, ddy, ddz, s[0], s[1], s[2], lane, nn, E);
+                WindowGeom g;
+                g.lo0 = meta->lo[0];
+                g.lo1 = meta->lo[1];
+                g.lo2 = meta->lo[2];
+                const int n0 = meta->hi[0] - g.lo0 + 1;
+                g.n1 = meta->hi[1] - g.lo1 + 1;
+                g.n2 = meta->hi[2] - g.lo2 + 1;
+                g.dx = vx - meta->v[0];
+                g.dy = vy - meta->v[1];
+                g.dz = vz - meta->v[2];
+                const int W = n0 * g.n1 * g.n2;
+                d2 = (W == 27) ? scan_window<false>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E)
+                               : scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
+                if (path == 0 && W != 27) path = 1;
             } else {
                 const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
                 E = pr.E;
                 d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
                                          : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
+            }
+            const unsigned long long td = PROF ? wall_clock64() : 0ull;
+            if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && round == 0) {
+                // per-group record of this iteration (10 ns ticks): where the group's time went
+                unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
+                                               (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+                r[0] = (unsigned)(ta - c0) | ((unsigned)(tb - ta) << 16);   // wait-in, transform + window test
+                r[1] = (unsigned)(tc - tb) | ((unsigned)(td - tc) << 16);   // window fill, scan
+                r[2] = (unsigned)(has_meta ? meta->E : 0) | ((unsigned)E << 16);  // staged points, examined
+                r[3] = (unsigned)path;
             }
             if (lane == 0) {
                 acc[17] += (double)E;

@@ -20,3 +20,19 @@ print(opts, k.icp_profile(), 'n_src', k.last_stats()['n_source'])
 print(' it  assoc publish gather solve | max_assoc passes   (us)')
 for i, r in enumerate(prof):
     print('%3d %6.2f %6.2f %6.2f %6.2f | %6.2f %4d' % (i, r[0] / 100, r[1] / 100, r[2] / 100, r[3] / 100, r[4] / 100, r[5]))
+
+gp = k.icp_group_profile()
+if gp.size:
+    names = ('wait-in', 'xform', 'fill', 'scan')
+    for it in (0, 1, min(6, gp.shape[0] - 1), gp.shape[0] - 1):
+        g = gp[it]
+        tot = g[:, 0:4].sum(axis=1)
+        print('iteration %d: groups %d  paths %s' % (it, g.shape[0], np.bincount(g[:, 6], minlength=4).tolist()))
+        for j, nm in enumerate(names):
+            print('   %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (
+                nm, g[:, j].mean() / 100, np.percentile(g[:, j], 50) / 100, np.percentile(g[:, j], 99) / 100, g[:, j].max() / 100))
+        print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (g[:, 4].mean(), g[:, 4].max(), g[:, 5].mean(), g[:, 5].max()))
+        worst = np.argsort(-tot)[:6]
+        for w in worst:
+            print('   slow group %4d (wg %3d): wait %5.2f xform %5.2f fill %5.2f scan %5.2f us staged %4d examined %4d path %d' % (
+                w, w // 16, g[w, 0] / 100, g[w, 1] / 100, g[w, 2] / 100, g[w, 3] / 100, g[w, 4], g[w, 5], g[w, 6]))

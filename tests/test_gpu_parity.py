@@ -215,6 +215,33 @@ def test_align_points_to_map_matches_oracle(gpu, O, blocks):
         _cabi.set_option("icp_blocks", 0)
 
 
+@pytest.mark.parametrize("offset", [(0.125, 0.125, 0.125), (0.0625, 0.125, 0.125), (0.9375, 0.125, 0.0625)])
+def test_align_exact_ties_follow_the_reference_order(gpu, O, offset):
+    """lattice map, queries exactly between lattice points: several candidates at EXACTLY the same
+    distance, in different voxels.  The reference keeps the first one in (shift-table, in-voxel)
+    order (strict '<', VoxelHashMap.cpp:55-63); a different choice changes the residuals and the
+    pose.  Offsets inside 1/8 voxel of a face exercise the widened (filtered) staged windows."""
+    from kiss_icp_amd.registration import Registration
+
+    g, o = _maps(O)
+    ax = np.arange(-6.0, 6.0, 0.25)
+    lattice = np.stack(np.meshgrid(ax, ax, np.arange(-1.0, 1.0, 0.25), indexing="ij"), axis=-1).reshape(-1, 3)
+    lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]  # which 20 of a voxel's 64 survive
+    g.add_points(lattice)
+    o.add_points(lattice)
+    qa = np.arange(-4.0, 4.0, 0.5)
+    src = np.stack(np.meshgrid(qa, qa, np.array([-0.5, 0.0]), indexing="ij"), axis=-1).reshape(-1, 3) + np.array(offset)
+    for guess in (np.eye(4), make_pose((0.5, -0.25, 0.0))):  # both keep the queries on exact binary fractions
+        for iters in (1, 4):
+            rg, ro = Registration(iters, 1e-12), O.Registration(iters, 1e-12)
+            Tg = rg.align_points_to_map(src, g, guess, 3.0, 1.0)
+            To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
+            dt, dr = pose_error(To, Tg)
+            assert dt < 1e-10 and dr < 1e-10, (offset, iters, dt, dr)
+            assert rg.last_stats["n_corr_last"] == ro.last_stats["n_corr_last"]
+            assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
+
+
 def test_align_degenerate_cases(gpu, O):
     from kiss_icp_amd.registration import Registration
 
