@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--icp-blocks", type=int, default=0)
     ap.add_argument("--icp-ppg", type=int, default=0, help="icp_points_per_group option")
+    ap.add_argument("--opt", action="append", default=[], help="name=value tuning option (kicp_set_option)")
     return ap.parse_args()
 
 
@@ -95,6 +96,9 @@ def main():
         _cabi.set_option("icp_blocks", args.icp_blocks)
     if args.icp_ppg:
         _cabi.set_option("icp_points_per_group", args.icp_ppg)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        _cabi.set_option(name, int(value))
 
     W, K = args.warmup, args.steps
     ds, cfg_over, workload_name = make_dataset(args.workload, multistream.stream_seed(args.seed, rank), W + K)

@@ -237,6 +237,7 @@ int kicp_device_synchronize(int device_id);
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
+ *   "map_apply_threads"  workgroup size of the AddPoints apply kernel: 256, 512 (default) or 1024
  *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
  *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)
  * ---------------------------------------------------------------------------------------- */

@@ -1354,6 +1354,9 @@ int kicp_set_option(const char *name, long value) {
         options().icp_profile = value;
     } else if (!strcmp(name, "icp_timing")) {
         options().icp_timing = value;
+    } else if (!strcmp(name, "map_apply_threads")) {
+        if (value != 256 && value != 512 && value != 1024) return KICP_ERR_INVALID_ARG;
+        options().map_apply_threads = value;
     } else {
         set_error("unknown option '%s'", name);
         return KICP_ERR_INVALID_ARG;

@@ -216,6 +216,7 @@ struct Options {
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
+    long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
 };
 Options &options();
 

@@ -1440,8 +1440,9 @@ __device__ void map_apply_voxel_serial(const MapView &m, int slot, int head, int
 // `count`) iff the voxel is not full and no stored point -- including the ones appended a moment
 // ago -- is closer than map_resolution (VoxelHashMap.cpp:103-110).  Every load of a voxel is
 // independent of the others: record -> {slot, list} -> {block, points} is three round trips.
-__global__ __launch_bounds__(256) void k_map_apply(MapView m, InsertScratch sc) {
-    constexpr int kGroups = 256 / 32;
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch sc) {
+    constexpr int kGroups = THREADS / 32;
     __shared__ int sh_need[kGroups];
     __shared__ int sh_alloc[4];  // queue position, entries available there, bump base, blocks in the pool
     const int lane = threadIdx.x & 31;
@@ -1718,13 +1719,23 @@ void launch_map_link(const MapView &m, const InsertScratch &sc, const double *in
                        use_pose);
 }
 void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipStream_t s) {
-    // one 32-lane group per voxel record (at most one record per incoming point)
-    hipLaunchKernelGGL(k_map_apply, dim3(grid_for((long)n_max * 32, 256, 2048)), dim3(256), 0, s, m, sc);
+    // one 32-lane group per voxel record (at most one record per incoming point).  A workgroup makes
+    // ONE allocation (three returning atomics on shared words) per trip for all its groups, so larger
+    // workgroups mean fewer serialised atomics.
+    const int threads = (int)options().map_apply_threads;
+    if (threads >= 1024)
+        hipLaunchKernelGGL(k_map_apply<1024>, dim3(grid_for((long)n_max * 32, 1024, 1024)), dim3(1024), 0, s, m, sc);
+    else if (threads >= 512)
+        hipLaunchKernelGGL(k_map_apply<512>, dim3(grid_for((long)n_max * 32, 512, 2048)), dim3(512), 0, s, m, sc);
+    else
+        hipLaunchKernelGGL(k_map_apply<256>, dim3(grid_for((long)n_max * 32, 256, 2048)), dim3(256), 0, s, m, sc);
 }
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
                       const double origin[3], PipeState *reset_state, unsigned *host_rec, int rec_words,
                       hipStream_t s) {
-    hipLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 2048)), dim3(256), 0, s, m, state,
+    // grid-stride over the blocks; at most 256 workgroups: every one of them signs off with a fenced
+    // atomic (frame-record hand-off), which would serialise over thousands of workgroups
+    hipLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 256)), dim3(256), 0, s, m, state,
                        use_state_origin, origin ? origin[0] : 0.0, origin ? origin[1] : 0.0,
                        origin ? origin[2] : 0.0, reset_state, host_rec, rec_words);
 }
