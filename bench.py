@@ -169,6 +169,8 @@ def main():
         "ms_per_frame_host_synced": sync_latency_ms,
         "async_equals_synced_trajectory": same_traj,
     }
+    cyc, tk = pipe.icp_clock()
+    out["icp_shader_mhz"] = 100.0 * cyc / max(1, tk)
     # roofline of the dominant kernel (k_icp): algorithmic bytes of AlignPointsToMap
     # (per iteration N_src*(24+24) + N_src*27*16 + E*24 + 336) / device time
     # measured with hipEvents on the pipeline's own stream around every k_icp launch.

@@ -205,6 +205,9 @@ int kicp_pipeline_icp_timing(kicp_pipeline *p, double *total_ms, uint64_t *launc
  * ([0] association + accumulation, [1] workgroup reduction + publish, [2] cross-workgroup gather,
  * [3] 6x6 solve + pose update) and the number of workgroups that took part */
 int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgroups);
+/* duration of the LAST ICP launch as seen by its workgroup 0: shader-clock cycles (s_memtime) and
+ * 100 MHz wall ticks (s_memrealtime); cycles / ticks * 100 = effective shader clock in MHz */
+int kicp_pipeline_icp_clock(kicp_pipeline *p, uint64_t *cycles, uint64_t *ticks);
 /* per-iteration profile of the LAST ICP launch (at most the first 24 iterations), 6 uint32 per
  * iteration in 10 ns ticks: workgroup 0's {associate, publish, gather, solve}, the slowest
  * 32-lane group's associate time over all workgroups, gather polling passes of workgroup 0 */

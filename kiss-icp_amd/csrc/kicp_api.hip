@@ -188,13 +188,15 @@ static int map_rehash(kicp_map *m, uint32_t new_cap) {
     return KICP_OK;
 }
 
+bool kicp_map::capacity_ok(size_t incoming) const {
+    return 2 * ((size_t)used_ub + incoming) <= slot_cap && (size_t)bump_ub + incoming <= (size_t)blocks_cap;
+}
+
 int kicp_map::ensure_capacity(size_t incoming) {
     // Every incoming point may open a new voxel.  Keep the load factor (live + tombstones) <= 1/2
     // and one block per possible new voxel.  The host only knows upper bounds of the device
     // counters between refreshes; refresh (one small D2H) before deciding to grow.
-    const size_t need_slots = 2 * ((size_t)used_ub + incoming);
-    const size_t need_blocks = (size_t)bump_ub + incoming;
-    if (need_slots <= slot_cap && need_blocks <= (size_t)blocks_cap) return KICP_OK;
+    if (capacity_ok(incoming)) return KICP_OK;
     KICP_TRY(refresh_counters());
     const size_t live = (size_t)h_ctr[C_LIVE], tomb = (size_t)h_ctr[C_TOMB];
     if (2 * ((size_t)used_ub + incoming) > slot_cap) {
@@ -402,7 +404,7 @@ int kicp_map_add_points(kicp_map *m, const double *xyz, size_t n) {
 int kicp_map_remove_far(kicp_map *m, const double origin[3]) {
     if (!m || !origin) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(m->device));
-    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, nullptr, 0, m->stream);
+    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -412,7 +414,7 @@ int kicp_map_update_origin(kicp_map *m, const double *xyz, size_t n, const doubl
     KICP_HIP(hipSetDevice(m->device));
     KICP_TRY(map_upload(m, xyz, n));
     KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, nullptr, 0));
-    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, nullptr, 0, m->stream);
+    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -429,7 +431,7 @@ int kicp_map_update_pose(kicp_map *m, const double *xyz, size_t n, const double 
     KICP_HIP(hipMemcpyAsync(&ms->new_pose, &T, sizeof T, hipMemcpyHostToDevice, m->stream));
     KICP_TRY(map_upload(m, xyz, n));
     KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, ms, 1));
-    launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, nullptr, 0, m->stream);
+    launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -483,6 +485,14 @@ int kicp_map_closest_neighbor(const kicp_map *cm, const double *q, size_t nq, do
 // ==============================================================================================
 // Registration
 // ==============================================================================================
+static PrepState idle_prep_state() {
+    PrepState h;
+    memset(&h, 0, sizeof h);
+    h.tmin_bits = ~0ull;
+    h.tmax_bits = 0ull;
+    return h;
+}
+
 static void init_state(PipeState &s, double initial_threshold) {
     memset(&s, 0, sizeof s);
     s.last_pose = se3_identity();
@@ -492,8 +502,6 @@ static void init_state(PipeState &s, double initial_threshold) {
     s.model_sse = initial_threshold * initial_threshold;  // Threshold.cpp:35
     s.num_samples = 1;
     s.epoch_base = 1;
-    s.tmin_bits = ~0ull;
-    s.tmax_bits = 0ull;
 }
 
 static constexpr unsigned kSpinLimit = 1u << 21;
@@ -728,9 +736,9 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
     if (n == 0) return KICP_OK;
     ScopedStream ss;
     KICP_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
-    DevBuf in, ts, tmp, out, counts, st;
+    DevBuf in, ts, tmp, out, counts, st, prep;
     ScopedBufs sb;
-    sb.v = {&in, &ts, &tmp, &out, &counts, &st};
+    sb.v = {&in, &ts, &tmp, &out, &counts, &st, &prep};
     KICP_TRY(in.reserve(n * 3 * sizeof(double)));
     KICP_TRY(tmp.reserve(n * 3 * sizeof(double)));
     KICP_TRY(out.reserve(n * 3 * sizeof(double)));
@@ -739,11 +747,14 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
     PipeState hs;
     init_state(hs, 0.0);
     KICP_HIP(hipMemcpyAsync(st.p, &hs, sizeof hs, hipMemcpyHostToDevice, ss.s));
+    KICP_TRY(prep.reserve(sizeof(PrepState)));
+    PrepState hp = idle_prep_state();
+    KICP_HIP(hipMemcpyAsync(prep.p, &hp, sizeof hp, hipMemcpyHostToDevice, ss.s));
     KICP_HIP(hipMemcpyAsync(in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ss.s));
     if (do_deskew) {
         KICP_TRY(ts.reserve(n_ts * sizeof(double)));
         KICP_HIP(hipMemcpyAsync(ts.p, timestamps, n_ts * sizeof(double), hipMemcpyHostToDevice, ss.s));
-        launch_ts_minmax(ts.as<double>(), (int)n_ts, st.as<PipeState>(), ss.s);
+        launch_ts_minmax(ts.as<double>(), (int)n_ts, prep.as<PrepState>(), ss.s);
     }
     PreParams P;
     memset(&P, 0, sizeof P);
@@ -754,21 +765,24 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
     P.use_state_motion = 0;
     P.motion = motion;
     P.state = st.as<PipeState>();
+    P.prep = prep.as<PrepState>();
     P.max_range = max_range;
     P.min_range = min_range;
     P.tmp = tmp.as<double>();
     P.blk_counts = counts.as<int>();
     P.out = out.as<double>();
-    P.n_out = &st.as<PipeState>()->n_pre;
+    P.n_out = &prep.as<PrepState>()->n_pre;
     P.ds_tab = nullptr;
     P.err = &st.as<PipeState>()->err;
     launch_pre_flags(P, ss.s);
     launch_pre_scatter(P, ss.s);
     KICP_HIP(hipGetLastError());
     KICP_HIP(hipMemcpyAsync(&hs, st.p, sizeof hs, hipMemcpyDeviceToHost, ss.s));
+    KICP_HIP(hipMemcpyAsync(&hp, prep.p, sizeof hp, hipMemcpyDeviceToHost, ss.s));
     KICP_HIP(hipStreamSynchronize(ss.s));
-    KICP_HIP(hipMemcpy(out_xyz, out.p, (size_t)hs.n_pre * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    *n_out = (size_t)hs.n_pre;
+    if (hs.err) return err_bits_to_status(hs.err);
+    KICP_HIP(hipMemcpy(out_xyz, out.p, (size_t)hp.n_pre * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    *n_out = (size_t)hp.n_pre;
     return KICP_OK;
 }
 
@@ -785,18 +799,28 @@ struct FrameRecord {  // the first kRecWords words mirror the device layout [map
 static_assert(offsetof(FrameRecord, st) == sizeof(int) * C_COUNT, "PipeState sits right behind the map counters");
 constexpr int kRecWords = (int)((sizeof(int) * C_COUNT + sizeof(PipeState)) / sizeof(unsigned));
 
+// Two streams per pipeline.  `stream` carries the frame's serial chain: AlignPointsToMap, then the
+// map update (frame k+1's registration needs frame k's points in the map).  `prep_stream` carries
+// the stages in front of the registration (Preprocess + Voxelize): for frame k+1 they only need
+// frame k's pose (for the deskew motion), so they run while frame k's map update is still in flight.
 struct kicp_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t ev_icp_done = nullptr;      // recorded on `stream` behind every ICP launch
+    hipEvent_t ev_prep_done[2] = {nullptr, nullptr};  // recorded on `prep_stream`, by frame parity
+    uint64_t frames_enqueued = 0;
     kicp_config cfg;
     kicp_map *map = nullptr;
-    DevBuf raw, ts, tmp, pre, fd, src, work, slot1, slot2, tab1, tab2, counts, granules, prof_groups;
+    // fd (the 0.5 v cloud, read by the map update) exists twice, indexed by frame parity
+    DevBuf raw, ts, tmp, pre, fd[2], src, work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
     static constexpr int kRing = 256;
     FrameRecord *ring = nullptr;  // hipHostMalloc
     hipEvent_t ev[kRing][2];
+    hipEvent_t ev_done[kRing];  // behind the last kernel of the frame in that ring slot
     bool ev_ok = false;
     int in_flight = 0;
     uint64_t frames_done = 0;
@@ -816,6 +840,7 @@ static PipeState *pipe_state(kicp_pipeline *p) { return map_mini_state(p->map); 
 static int pipe_reserve(kicp_pipeline *p, size_t n) {
     if (n <= p->cap_points) return KICP_OK;
     if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    KICP_HIP(hipStreamSynchronize(p->prep_stream));
     size_t cap = n + n / 8 + 1024;
     const size_t b3 = cap * 3 * sizeof(double);
     KICP_TRY(p->raw.reserve(b3));
@@ -823,7 +848,8 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->tmp.reserve(b3));
     // pre/fd/src keep their contents (last frame's outputs) across a growth
     KICP_TRY(p->pre.reserve(b3, true, p->stream));
-    KICP_TRY(p->fd.reserve(b3, true, p->stream));
+    KICP_TRY(p->fd[0].reserve(b3, true, p->stream));
+    KICP_TRY(p->fd[1].reserve(b3, true, p->stream));
     KICP_TRY(p->src.reserve(b3, true, p->stream));
     KICP_TRY(p->work.reserve(b3));
     KICP_TRY(p->slot1.reserve(cap * sizeof(int)));
@@ -837,6 +863,26 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     return KICP_OK;
 }
 
+// Tighten the host-side upper bounds of the map counters WITHOUT synchronising: the newest frame
+// whose last kernel has completed left its exact counters in the pinned ring; frames queued behind
+// it can each have added at most one voxel per raw point.
+static void pipe_refresh_bounds(kicp_pipeline *p) {
+    if (!p->ev_ok) return;
+    kicp_map *m = p->map;
+    long pending = 0;
+    for (int i = p->in_flight - 1; i >= 0; --i) {
+        if (hipEventQuery(p->ev_done[i]) == hipSuccess) {
+            const FrameRecord &r = p->ring[i];
+            const long used = (long)r.map_ctr[C_USED] + pending, bump = (long)r.map_ctr[C_BUMP] + pending;
+            if (used < m->used_ub) m->used_ub = used;
+            if (bump < m->bump_ub) m->bump_ub = bump;
+            return;
+        }
+        pending += (long)p->ring[i].n_raw;
+    }
+    (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+}
+
 static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const double *d_ts, size_t n_ts) {
     const kicp_config &c = p->cfg;
     const bool do_deskew = c.deskew && n_ts > 0 && d_ts;  // Preprocessing.cpp:59
@@ -848,15 +894,23 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(kicp_pipeline_sync(p));
     KICP_TRY(pipe_reserve(p, n));
     kicp_map *m = p->map;
+    if (!m->capacity_ok(n)) pipe_refresh_bounds(p);
     KICP_TRY(m->ensure_capacity(n));
-    hipStream_t s = p->stream;
+    hipStream_t s = p->stream, sp = p->prep_stream;
     PipeState *st = pipe_state(p);
+    const int par = (int)(p->frames_enqueued & 1u);
+    PrepState *prep = p->prep.as<PrepState>() + par;
+    double *fd = p->fd[par].as<double>();
     const int nblk = (int)((p->cap_points + 1023) / 1024 + 1);
     int *cnt0 = p->counts.as<int>(), *cnt1 = cnt0 + nblk, *cnt2 = cnt1 + nblk;
     const int n_i = (int)n;
 
+    // ===== prep_stream: everything in front of the registration ===================================
+    // needs the previous frame's pose bookkeeping (last_delta for the deskew, written by its ICP
+    // launch) and the buffers that launch read (src); nothing of the previous frame's map update.
+    if (p->frames_enqueued > 0) KICP_HIP(hipStreamWaitEvent(sp, p->ev_icp_done, 0));
     // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
-    if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, st, s);
+    if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, prep, sp);
     PreParams P;
     memset(&P, 0, sizeof P);
     P.xyz = d_xyz;
@@ -866,44 +920,45 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     P.use_state_motion = 1;
     P.motion = se3_identity();
     P.state = st;
+    P.prep = prep;
     P.max_range = c.max_range;
     P.min_range = c.min_range;
     P.tmp = p->tmp.as<double>();
     P.blk_counts = cnt0;
     P.out = p->pre.as<double>();
-    P.n_out = &st->n_pre;
+    P.n_out = &prep->n_pre;
     P.ds_tab = p->tab1.as<DsSlot>();
     P.ds_mask = p->tab_cap - 1;
     P.ds_voxel = c.voxel_size * 0.5;  // KissICP.cpp:72
     P.ds_slot_of = p->slot1.as<int>();
     P.err = &st->err;
-    launch_pre_flags(P, s);
-    launch_pre_scatter(P, s);
+    launch_pre_flags(P, sp);
+    launch_pre_scatter(P, sp);
 
     // --- Voxelize (KissICP.cpp:70-75) ---------------------------------------------------------
     DsParams D1;
     memset(&D1, 0, sizeof D1);
     D1.in = p->pre.as<double>();
-    D1.n_ptr = &st->n_pre;
+    D1.n_ptr = &prep->n_pre;
     D1.n_max = n_i;
     D1.voxel = c.voxel_size * 0.5;
     D1.tab = p->tab1.as<DsSlot>();
     D1.mask = p->tab_cap - 1;
     D1.slot_of = p->slot1.as<int>();
     D1.blk_counts = cnt1;
-    D1.out = p->fd.as<double>();
-    D1.n_out = &st->n_fd;
+    D1.out = fd;
+    D1.n_out = &prep->n_fd;
     D1.next_tab = p->tab2.as<DsSlot>();
     D1.next_mask = p->tab_cap - 1;
     D1.next_voxel = c.voxel_size * 1.5;  // KissICP.cpp:73
     D1.next_slot_of = p->slot2.as<int>();
     D1.err = &st->err;
-    launch_ds_flags(D1, s);
-    launch_ds_scatter(D1, s);
+    launch_ds_flags(D1, sp);
+    launch_ds_scatter(D1, sp);
     DsParams D2;
     memset(&D2, 0, sizeof D2);
-    D2.in = p->fd.as<double>();
-    D2.n_ptr = &st->n_fd;
+    D2.in = fd;
+    D2.n_ptr = &prep->n_fd;
     D2.n_max = n_i;
     D2.voxel = c.voxel_size * 1.5;
     D2.tab = p->tab2.as<DsSlot>();
@@ -911,11 +966,15 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     D2.slot_of = p->slot2.as<int>();
     D2.blk_counts = cnt2;
     D2.out = p->src.as<double>();
-    D2.n_out = &st->n_src;
+    D2.n_out = &prep->n_src;
     D2.err = &st->err;
-    launch_ds_flags(D2, s);
-    launch_ds_scatter(D2, s);
+    launch_ds_flags(D2, sp);
+    launch_ds_scatter(D2, sp);
+    KICP_HIP(hipGetLastError());
+    KICP_HIP(hipEventRecord(p->ev_prep_done[par], sp));
 
+    // ===== stream: the serial chain =================================================================
+    KICP_HIP(hipStreamWaitEvent(s, p->ev_prep_done[par], 0));
     // --- AlignPointsToMap + threshold / pose bookkeeping (KissICP.cpp:44-63) ---------------------
     const int G = icp_launch_blocks();
     IcpParams I;
@@ -923,7 +982,8 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     icp_fill_policy(I);
     I.frame = p->src.as<double>();
     I.work = p->work.as<double>();
-    I.n_ptr = &st->n_src;
+    I.n_ptr = &prep->n_src;
+    I.prep = prep;
     I.map = m->view();
     I.state = st;
     I.pipeline_mode = 1;
@@ -941,12 +1001,13 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][0], s));
     launch_icp(I, G, options().icp_profile != 0, s);
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][1], s));
+    KICP_HIP(hipEventRecord(p->ev_icp_done, s));
 
     // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
     InsertScratch sc;
     KICP_TRY(m->scratch_reserve(p->cap_points, sc));
     const MapView v = m->view();
-    launch_map_link(v, sc, p->fd.as<double>(), &st->n_fd, 0, n_i, st, 1, s);
+    launch_map_link(v, sc, fd, &prep->n_fd, 0, n_i, st, 1, s);
     launch_map_apply(v, sc, n_i, s);
     m->used_ub += (long)n;
     m->bump_ub += (long)n;
@@ -954,9 +1015,11 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     // --- ... and the frame record, written by the kernel itself into the pinned host ring ---------
     FrameRecord *rec = p->ring + slot;
     rec->n_raw = n;
-    launch_map_prune(v, m->bump_ub, st, 1, nullptr, st, reinterpret_cast<unsigned *>(rec), kRecWords, s);
+    launch_map_prune(v, m->bump_ub, st, 1, nullptr, reinterpret_cast<unsigned *>(rec), kRecWords, s);
     KICP_HIP(hipGetLastError());
+    if (p->ev_ok) KICP_HIP(hipEventRecord(p->ev_done[slot], s));
     p->in_flight++;
+    p->frames_enqueued++;
     return KICP_OK;
 }
 
@@ -990,12 +1053,19 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     p->device = device_id;
     p->cfg = *cfg;
     int s = KICP_OK;
-    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) s = KICP_ERR_HIP;
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_icp_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_prep_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_prep_done[1], hipEventDisableTiming) != hipSuccess)
+        s = KICP_ERR_HIP;
     if (s == KICP_OK) {
         p->ev_ok = true;
-        for (int i = 0; i < kicp_pipeline::kRing && p->ev_ok; ++i)
+        for (int i = 0; i < kicp_pipeline::kRing && p->ev_ok; ++i) {
             for (int j = 0; j < 2; ++j)
                 if (hipEventCreate(&p->ev[i][j]) != hipSuccess) p->ev_ok = false;
+            if (hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming) != hipSuccess) p->ev_ok = false;
+        }
     }
     if (s == KICP_OK && hipHostMalloc((void **)&p->ring, sizeof(FrameRecord) * kicp_pipeline::kRing) != hipSuccess)
         s = KICP_ERR_OOM;
@@ -1008,6 +1078,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
         s = KICP_ERR_HIP;
     }
     if (s == KICP_OK) s = p->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
+    if (s == KICP_OK) s = p->prep.reserve(2 * sizeof(PrepState));
     if (s != KICP_OK) {
         if (s == KICP_ERR_HIP) set_error("pipeline resource creation failed");
         kicp_pipeline_destroy(p);
@@ -1017,6 +1088,8 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     init_state(st, cfg->initial_threshold);
     KICP_HIP(hipMemcpyAsync(pipe_state(p), &st, sizeof st, hipMemcpyHostToDevice, p->stream));
     KICP_HIP(hipMemsetAsync(p->granules.p, 0, p->granules.bytes, p->stream));
+    const PrepState idle[2] = {idle_prep_state(), idle_prep_state()};
+    KICP_HIP(hipMemcpyAsync(p->prep.p, idle, sizeof idle, hipMemcpyHostToDevice, p->stream));
     KICP_HIP(hipStreamSynchronize(p->stream));
     memset(&p->last, 0, sizeof p->last);
     p->last.st = st;
@@ -1027,14 +1100,21 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
 int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (!p) return KICP_OK;
     (void)hipSetDevice(p->device);
+    if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->map) kicp_map_destroy(p->map);
-    for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd, &p->src, &p->work, &p->slot1,
-                      &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups})
+    for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src, &p->work, &p->slot1,
+                      &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep})
         b->release();
+    if (p->ev_icp_done) (void)hipEventDestroy(p->ev_icp_done);
+    for (int i = 0; i < 2; ++i)
+        if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
+    if (p->prep_stream) (void)hipStreamDestroy(p->prep_stream);
     if (p->ev_ok)
-        for (int i = 0; i < kicp_pipeline::kRing; ++i)
+        for (int i = 0; i < kicp_pipeline::kRing; ++i) {
             for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
+            (void)hipEventDestroy(p->ev_done[i]);
+        }
     if (p->ring) (void)hipHostFree(p->ring);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -1098,10 +1178,11 @@ int kicp_pipeline_register_frame(kicp_pipeline *p, const double *xyz, size_t n, 
     KICP_HIP(hipSetDevice(p->device));
     if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
     KICP_TRY(pipe_reserve(p, n > n_ts ? n : n_ts));
-    if (n) KICP_HIP(hipMemcpyAsync(p->raw.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    // the scan goes in on the stream that consumes it (everything queued earlier has completed)
+    if (n) KICP_HIP(hipMemcpyAsync(p->raw.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, p->prep_stream));
     const bool have_ts = timestamps && n_ts > 0;
     if (have_ts)
-        KICP_HIP(hipMemcpyAsync(p->ts.p, timestamps, n_ts * sizeof(double), hipMemcpyHostToDevice, p->stream));
+        KICP_HIP(hipMemcpyAsync(p->ts.p, timestamps, n_ts * sizeof(double), hipMemcpyHostToDevice, p->prep_stream));
     KICP_TRY(pipe_enqueue(p, p->raw.as<double>(), n, have_ts ? p->ts.as<double>() : nullptr, have_ts ? n_ts : 0));
     return kicp_pipeline_sync(p);
 }
@@ -1172,7 +1253,8 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
     *n = cnt;
     const size_t c = cnt < cap ? cnt : cap;
     if (c) {
-        const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src : p->fd;
+        const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src
+                                                                   : p->fd[(p->frames_enqueued - 1) & 1u];
         KICP_HIP(hipMemcpyAsync(out, b.p, c * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
         KICP_HIP(hipStreamSynchronize(p->stream));
     }
@@ -1228,6 +1310,15 @@ int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgro
     KICP_TRY(pipe_state_get(p, h));
     for (int i = 0; i < 4; ++i) cycles[i] = h.prof[i];
     if (workgroups) *workgroups = h.icp_blocks_used;
+    return KICP_OK;
+}
+
+int kicp_pipeline_icp_clock(kicp_pipeline *p, uint64_t *cycles, uint64_t *ticks) {
+    if (!p || !cycles || !ticks) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    *cycles = h.prof_clock[0];
+    *ticks = h.prof_clock[1];
     return KICP_OK;
 }
 

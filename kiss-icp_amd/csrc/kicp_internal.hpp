@@ -107,6 +107,15 @@ struct InsertScratch {
     int parity;     // which C_TOUCHED word this insert counts in
 };
 
+// Per-frame words written by the stages in FRONT of the registration (Preprocess + the two
+// VoxelDownsamples).  The pipeline keeps two copies and alternates between them, so that those
+// stages of frame k+1 can run on a second stream while frame k's map update is still in flight.
+struct PrepState {
+    unsigned long long tmin_bits, tmax_bits;  // timestamp min/max as order-preserving u64 (idle: ~0, 0)
+    int n_pre, n_fd, n_src;                   // points after range crop / 0.5 v / 1.5 v downsample
+    int pad;
+};
+
 constexpr int kIcpProfIters = 24;
 
 // Per-pipeline state that never leaves the device between frames
@@ -120,7 +129,6 @@ struct PipeState {
     double sigma;  // threshold used by the frame being processed
     int num_samples;
     unsigned epoch_base;  // tag base of the in-kernel exchange, advanced by every ICP launch
-    unsigned long long tmin_bits, tmax_bits;  // timestamp min/max as order-preserving u64
     // per-frame result block (copied D2H at sync)
     int n_raw, n_pre, n_fd, n_src;
     int icp_iterations, icp_converged;
@@ -130,6 +138,9 @@ struct PipeState {
     // shader-clock cycles spent by workgroup 0 in the phases of the last ICP launch:
     // [0] association+accumulate, [1] workgroup reduce+publish, [2] gather, [3] solve+update
     unsigned long long prof[4];
+    // whole-launch duration of the last ICP kernel seen by workgroup 0: shader-clock cycles (s_memtime)
+    // and 100 MHz wall ticks (s_memrealtime) -> effective shader clock
+    unsigned long long prof_clock[2];
     // the first kIcpProfIters iterations of the last launch, 10 ns ticks: workgroup 0's
     // {associate, publish, gather, solve}, the slowest group's associate time over ALL workgroups,
     // and the number of polling passes workgroup 0's thread 0 needed in the gather
@@ -187,6 +198,7 @@ struct IcpParams {
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
     int use_lds;           // stage candidate voxels in LDS (0 disables)
+    const PrepState *prep;  // pipeline mode: this frame's counts (copied into the frame record), or nullptr
     unsigned *prof_groups;  // profiling variant only: [kIcpProfIters][256 * 16][4] per-group records, or nullptr
 };
 
@@ -255,6 +267,7 @@ struct kicp_map {
     unsigned insert_seq = 0;
     int scratch_reserve(size_t n_max, kicp::InsertScratch &sc);  // sizes the buffers, picks the parity
     kicp::MapView view() const;
+    bool capacity_ok(size_t incoming_points) const;  // by the host-side upper bounds alone
     int ensure_capacity(size_t incoming_points);
     int refresh_counters();  // D2H of ctr (synchronises the stream)
     int check_errors();

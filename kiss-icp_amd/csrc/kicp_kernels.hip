@@ -155,23 +155,53 @@ __device__ __forceinline__ Probe probe27(const MapView &m, double sx, double sy,
     return pr;
 }
 
+// ------------------------------------------------------------------------------------------
+// lane exchanges inside a 32-lane group without an LDS round trip: DPP row operations for the
+// 2-, 4-, 8- and 16-lane steps (quad_perm / row_half_mirror / row_mirror: ~2 issue cycles instead
+// of a ds_bpermute's ~100-cycle trip), one ds_swizzle SWAP16 for the last step.  The partner
+// pattern is not an xor butterfly for the mirror steps, but every step still merges two disjoint
+// lane sets whose members already agree, which is all an all-reduce needs.
+// ------------------------------------------------------------------------------------------
+template <int STEP>
+__device__ __forceinline__ int group_xchg(int v) {
+    if (STEP == 4) return __builtin_amdgcn_ds_swizzle(v, 0x401F);  // swizzle(SWAP, 16)
+    constexpr int kCtrl = STEP == 0 ? 0xB1 /* quad_perm [1,0,3,2] */
+                          : STEP == 1 ? 0x4E /* quad_perm [2,3,0,1] */
+                          : STEP == 2 ? 0x141 /* row_half_mirror */ : 0x140 /* row_mirror */;
+    return __builtin_amdgcn_update_dpp(v, v, kCtrl, 0xF, 0xF, false);
+}
+template <int STEP>
+__device__ __forceinline__ double group_xchg(double v) {
+    return __hiloint2double(group_xchg<STEP>(__double2hiint(v)), group_xchg<STEP>(__double2loint(v)));
+}
+// lexicographic minimum of (distance, key) over the 32 lanes of a group, carrying a payload;
+// every lane ends with the winner
+template <int STEP>
+__device__ __forceinline__ void group_min_step(double &best, int &key, int &payload) {
+    const double ob = group_xchg<STEP>(best);
+    const int ok = group_xchg<STEP>(key);
+    const int op = group_xchg<STEP>(payload);
+    if (ob < best || (ob == best && ok < key)) {
+        best = ob;
+        key = ok;
+        payload = op;
+    }
+}
+__device__ __forceinline__ void group_min(double &best, int &key, int &payload) {
+    group_min_step<0>(best, key, payload);
+    group_min_step<1>(best, key, payload);
+    group_min_step<2>(best, key, payload);
+    group_min_step<3>(best, key, payload);
+    group_min_step<4>(best, key, payload);
+}
+
 // lexicographic min over (distance, candidate number) inside the 32-lane group; returns the
 // squared distance and the winner's coordinates in nn
 __device__ __forceinline__ double group_argmin(double best, int bkey, double bx, double by, double bz, int lane,
                                                double nn[3]) {
     double gbest = best;
     int gkey = bkey, glane = lane;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(gbest, off, 32);
-        const int ok = __shfl_xor(gkey, off, 32);
-        const int ol = __shfl_xor(glane, off, 32);
-        if (ob < gbest || (ob == gbest && ok < gkey)) {
-            gbest = ob;
-            gkey = ok;
-            glane = ol;
-        }
-    }
+    group_min(gbest, gkey, glane);
     nn[0] = __shfl(bx, glane, 32);
     nn[1] = __shfl(by, glane, 32);
     nn[2] = __shfl(bz, glane, 32);
@@ -557,17 +587,7 @@ __device__ __forceinline__ double scan_window(const double *region, int E, int W
     // lexicographic min over (distance, reference order) across the 32 lanes; the winner's
     // coordinates are then read back from LDS by every lane (same address: broadcast)
     int bkey = bc >= 0 ? tag_order_key(btag, g) : 0x7FFFFFFF;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(best, off, 32);
-        const int ok2 = __shfl_xor(bkey, off, 32);
-        const int oc = __shfl_xor(bc, off, 32);
-        if (ob < best || (ob == best && ok2 < bkey)) {
-            best = ob;
-            bkey = ok2;
-            bc = oc;
-        }
-    }
+    group_min(best, bkey, bc);
     const int rc = bc >= 0 ? bc : 0;
     nn[0] = E > 0 ? X[rc] : 0.0;
     nn[1] = E > 0 ? Y[rc] : 0.0;
@@ -640,6 +660,9 @@ struct IcpShared {  // head of the dynamic LDS (kIcpFixedLds bytes with the regi
 static_assert(sizeof(IcpShared) + kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) <= kIcpFixedLds,
               "kIcpFixedLds too small");
 
+// low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
+__device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
+
 template <bool PROF>
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -656,6 +679,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const MapView &m = P.map;
     PipeState *st = P.state;
 
+    const unsigned long long launch_cyc = clock64(), launch_tick = wall_clock64();
     const int n = count_of(P.n_ptr, P.n_imm);
     // How many of the launched workgroups take part is decided here, from the actual N_src, so the
     // summation order (hence the result, bit for bit) never depends on host-side hints.
@@ -665,7 +689,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if ((int)blockIdx.x >= G) return;
     const int cached_rounds = (P.use_lds && m.max_points <= 32) ? kIcpMaxCachedRounds : 0;
     const unsigned epoch_base = st->epoch_base;
-    unsigned long long t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
+    unsigned t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
     unsigned gather_passes = 0;
 
     SE3 guess;
@@ -682,6 +706,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         ks = P.kernel_scale;
     }
     const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143
+    const double inv_voxel = 1.0 / m.voxel_size;
 
     if (tid == 0) {
         sh.fail = 0;
@@ -704,7 +729,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 
     const int max_iters = map_empty ? 0 : P.max_iters;
     for (int it = 0; it < max_iters; ++it) {
-        const unsigned long long c0 = PROF ? wall_clock64() : 0ull;
+        const unsigned c0 = PROF ? ticks32() : 0u;
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
@@ -714,7 +739,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         for (int p = blockIdx.x + G * grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
             const bool has_meta = round < cached_rounds;
             IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
-            const unsigned long long ta = PROF ? wall_clock64() : 0ull;
+            const unsigned ta = PROF ? ticks32() : 0u;
             double pin[3];
             if (it > 0 && has_meta) {  // running source point lives in LDS
                 pin[0] = meta->s[0];
@@ -728,8 +753,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
             double s[3];
             se3_act(est, pin, s);
-            const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size),
-                      vz = voxel_coord(s[2], m.voxel_size);
+            const int vx = voxel_coord_fast(s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(s[1], m.voxel_size, inv_voxel),
+                      vz = voxel_coord_fast(s[2], m.voxel_size, inv_voxel);
             const int v[3] = {vx, vy, vz};
             bool cached = false;
             if (has_meta && meta->valid)  // is the 27-neighbourhood of (vx, vy, vz) inside the staged window?
@@ -748,12 +773,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
             }
             int path = cached ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
-            const unsigned long long tb = PROF ? wall_clock64() : 0ull;
+            const unsigned tb = PROF ? ticks32() : 0u;
             if (!cached && has_meta && meta->cap >= 0) {
                 cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
                 if (cached) path = 2;
             }
-            const unsigned long long tc = PROF ? wall_clock64() : 0ull;
+            const unsigned tc = PROF ? ticks32() : 0u;
             double nn[3];
             double d2;
             int E;
@@ -778,7 +803,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
                                          : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
             }
-            const unsigned long long td = PROF ? wall_clock64() : 0ull;
+            const unsigned td = PROF ? ticks32() : 0u;
             if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && round == 0) {
                 // per-group record of this iteration (10 ns ticks): where the group's time went
                 unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
@@ -817,7 +842,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
-        const unsigned long long c1 = PROF ? wall_clock64() : 0ull;
+        const unsigned c1 = PROF ? ticks32() : 0u;
         acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
         if (lane == 0) {
 #pragma unroll
@@ -839,7 +864,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
         }
         // ---- gather every workgroup's partial (bounded spin) --------------------------------
-        const unsigned long long c2 = PROF ? wall_clock64() : 0ull;
+        const unsigned c2 = PROF ? ticks32() : 0u;
         if (tid < kIcpParts * kIcpSums) {
             // thread (k, part) sums scalar k over a contiguous range of workgroups, in order;
             // kGatherChunk workgroups (2 granules each) are in flight at a time and only granules
@@ -898,7 +923,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         __syncthreads();
         // ---- waves 0..3 (one per SIMD) solve the same system; the result goes through LDS -----
-        const unsigned long long c3 = PROF ? wall_clock64() : 0ull;
+        const unsigned c3 = PROF ? ticks32() : 0u;
         double nrm2 = 0.0;
         if (tid < kIcpSolveThreads) {
             double S[kIcpSums];
@@ -960,7 +985,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             nrm2 = sh.est[7];
         }
         iterations = it + 1;
-        const unsigned long long c4 = PROF ? wall_clock64() : 0ull;
+        const unsigned c4 = PROF ? ticks32() : 0u;
         t_assoc += c1 - c0;
         t_publish += c2 - c1;
         t_gather += c3 - c2;
@@ -994,11 +1019,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         st->icp_ncorr_last = ncorr_last;
         st->icp_ncorr_total = ncorr_total;
         st->n_src = n;
+        if (P.prep) {
+            st->n_pre = P.prep->n_pre;
+            st->n_fd = P.prep->n_fd;
+        }
         st->icp_blocks_used = G;
         st->prof[0] = t_assoc;
         st->prof[1] = t_publish;
         st->prof[2] = t_gather;
         st->prof[3] = t_solve;
+        st->prof_clock[0] = clock64() - launch_cyc;
+        st->prof_clock[1] = wall_clock64() - launch_tick;
         st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
         if (P.pipeline_mode) {
             st->sigma = ks;
@@ -1079,7 +1110,7 @@ __device__ __forceinline__ double f64_from_order_bits(unsigned long long o) {
 
 // ---- Preprocess ---------------------------------------------------------------------------
 // min / max of the timestamps (Preprocessing.cpp:62)
-__global__ __launch_bounds__(256) void k_ts_minmax(const double *ts, int n_ts, PipeState *st) {
+__global__ __launch_bounds__(256) void k_ts_minmax(const double *ts, int n_ts, PrepState *st) {
     unsigned long long lo = ~0ull, hi = 0ull;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ts; i += gridDim.x * blockDim.x) {
         const unsigned long long o = f64_order_bits(ts[i]);
@@ -1106,8 +1137,8 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_flags(PreParams P) {
     if (i < n) {
         double p[3] = {P.xyz[3 * i], P.xyz[3 * i + 1], P.xyz[3 * i + 2]};
         if (P.deskew) {
-            const double mn = f64_from_order_bits(P.state->tmin_bits);
-            const double mx = f64_from_order_bits(P.state->tmax_bits);
+            const double mn = f64_from_order_bits(P.prep->tmin_bits);
+            const double mx = f64_from_order_bits(P.prep->tmax_bits);
             double omega[6];
             se3_log(P.use_state_motion ? P.state->last_delta : P.motion, omega);
             const double stamp = (P.ts[i] - mn) / (mx - mn);
@@ -1234,7 +1265,13 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_scatter(PreParams P) {
         const int s = ds_claim_aggregated(agg, P.ds_tab, P.ds_mask, valid, key, j, P.err);
         if (keep) P.ds_slot_of[j] = s;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.n_out = grand;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *P.n_out = grand;
+        if (P.prep) {  // k_pre_flags (the only reader) is done: re-arm the timestamp words
+            P.prep->tmin_bits = ~0ull;
+            P.prep->tmax_bits = 0ull;
+        }
+    }
 }
 
 // ---- VoxelDownsample ----------------------------------------------------------------------
@@ -1574,8 +1611,7 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
 // contiguous in HBM -- straight into the frame's slot of the host-pinned ring: no blit kernel.
 __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *state,
                                                    int use_state_origin, double ox, double oy,
-                                                   double oz, PipeState *reset_state, unsigned *host_rec,
-                                                   int rec_words) {
+                                                   double oz, unsigned *host_rec, int rec_words) {
     if (use_state_origin) {
         ox = state->new_pose.t[0];
         oy = state->new_pose.t[1];
@@ -1599,10 +1635,6 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
             atomicSub(&m.ctr[C_LIVE], 1);
             atomicAdd(&m.ctr[C_TOMB], 1);
         }
-    }
-    if (reset_state && blockIdx.x == 0 && threadIdx.x == 0) {  // re-arm the per-frame words
-        reset_state->tmin_bits = ~0ull;
-        reset_state->tmax_bits = 0ull;
     }
     if (host_rec) {
         __shared__ int sh_last;
@@ -1695,7 +1727,7 @@ void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *
     hipLaunchKernelGGL(k_closest_neighbor, dim3(grid_for((long)nq * 32, 256, 2048)), dim3(256), 0, s, m, q,
                        nq, nn, dist);
 }
-void launch_ts_minmax(const double *ts, int n_ts, PipeState *st, hipStream_t s) {
+void launch_ts_minmax(const double *ts, int n_ts, PrepState *st, hipStream_t s) {
     hipLaunchKernelGGL(k_ts_minmax, dim3(grid_for(n_ts, 256, 512)), dim3(256), 0, s, ts, n_ts, st);
 }
 void launch_pre_flags(const PreParams &P, hipStream_t s) {
@@ -1731,13 +1763,12 @@ void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipS
         hipLaunchKernelGGL(k_map_apply<256>, dim3(grid_for((long)n_max * 32, 256, 2048)), dim3(256), 0, s, m, sc);
 }
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
-                      const double origin[3], PipeState *reset_state, unsigned *host_rec, int rec_words,
-                      hipStream_t s) {
+                      const double origin[3], unsigned *host_rec, int rec_words, hipStream_t s) {
     // grid-stride over the blocks; at most 256 workgroups: every one of them signs off with a fenced
     // atomic (frame-record hand-off), which would serialise over thousands of workgroups
     hipLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 256)), dim3(256), 0, s, m, state,
                        use_state_origin, origin ? origin[0] : 0.0, origin ? origin[1] : 0.0,
-                       origin ? origin[2] : 0.0, reset_state, host_rec, rec_words);
+                       origin ? origin[2] : 0.0, host_rec, rec_words);
 }
 void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s) {
     hipLaunchKernelGGL(k_map_rehash, dim3(grid_for(bump_ub, 256, 2048)), dim3(256), 0, s, m);

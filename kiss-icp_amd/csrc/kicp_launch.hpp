@@ -13,7 +13,8 @@ struct PreParams {
     int deskew;         // deskew_ && !timestamps.empty()
     int use_state_motion;
     SE3 motion;         // relative_motion when !use_state_motion
-    PipeState *state;   // last_delta (pipeline) and timestamp min/max words
+    const PipeState *state;  // last_delta (pipeline mode)
+    PrepState *prep;    // timestamp min/max words (re-armed by k_pre_scatter)
     double max_range, min_range;
     double *tmp;        // n x 3 deskewed cloud
     int *blk_counts;    // one per 1024-thread workgroup
@@ -53,7 +54,7 @@ size_t icp_granule_words(int G);
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s);
-void launch_ts_minmax(const double *ts, int n_ts, PipeState *st, hipStream_t s);
+void launch_ts_minmax(const double *ts, int n_ts, PrepState *prep, hipStream_t s);
 void launch_pre_flags(const PreParams &P, hipStream_t s);
 void launch_pre_scatter(const PreParams &P, hipStream_t s);
 void launch_ds_claim(const DsParams &P, hipStream_t s);
@@ -63,8 +64,7 @@ void launch_map_link(const MapView &m, const InsertScratch &sc, const double *in
                      int n_max, const PipeState *state, int use_pose, hipStream_t s);
 void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipStream_t s);
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
-                      const double origin[3], PipeState *reset_state, unsigned *host_rec, int rec_words,
-                      hipStream_t s);
+                      const double origin[3], unsigned *host_rec, int rec_words, hipStream_t s);
 void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s);
 void launch_map_count_points(const MapView &m, long bump_ub, hipStream_t s);
 

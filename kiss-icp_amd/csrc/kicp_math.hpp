@@ -462,6 +462,17 @@ KICP_HD void unpack_voxel(uint64_t key, int &x, int &y, int &z) {
     z = (int)(key & 0x1FFFFF) - kVoxelLimit;
 }
 KICP_HD int voxel_coord(double p, double voxel_size) { return (int)floor(p / voxel_size); }
+// Same value without the IEEE divide on the common path: p * (1 / voxel_size) is within ~2 ulp of
+// the correctly rounded quotient, so the two floors can only differ when the product sits within
+// a few ulp of an integer -- then (and only then) the exact divide decides.
+KICP_HD int voxel_coord_fast(double p, double voxel_size, double inv_voxel_size) {
+    const double q = p * inv_voxel_size;
+    const double f = floor(q);
+    const double r = q - f;                      // exact (Sterbenz) in [0, 1)
+    const double eps = fabs(q) * 0x1p-49 + DBL_MIN;
+    if (r < eps || r > 1.0 - eps) return (int)floor(p / voxel_size);
+    return (int)f;
+}
 
 KICP_HD uint32_t hash_key(uint64_t key, uint32_t mask) {
     uint64_t h = key * 0x9E3779B97F4A7C15ull;

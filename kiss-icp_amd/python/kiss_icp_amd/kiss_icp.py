@@ -148,6 +148,12 @@ class KissICP:
         _cabi.check(_cabi.lib().kicp_pipeline_icp_iteration_profile(self._h, _cabi.ptr(buf), 24, C.byref(n)))
         return buf[: n.value]
 
+    def icp_clock(self):
+        """(shader cycles, 10 ns ticks) of the last ICP launch, workgroup 0"""
+        cyc, tk = C.c_uint64(0), C.c_uint64(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_icp_clock(self._h, C.byref(cyc), C.byref(tk)))
+        return cyc.value, tk.value
+
     def icp_group_profile(self):
         """(n_iters, n_groups, 7) int64 of the last ICP launch ("icp_profile" option on): 10 ns ticks
         {wait-in, transform + window test, window fill, scan}, staged points, examined points, path"""

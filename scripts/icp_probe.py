@@ -17,6 +17,8 @@ for i in range(nf):
     k.register_frame(ds[i][0])
 prof = k.icp_iteration_profile()
 print(opts, k.icp_profile(), 'n_src', k.last_stats()['n_source'])
+cyc, tk = k.icp_clock()
+print('last launch: %d shader cycles in %.2f us -> %.0f MHz' % (cyc, tk / 100, cyc / max(tk, 1) * 100))
 print(' it  assoc publish gather solve | max_assoc passes   (us)')
 for i, r in enumerate(prof):
     print('%3d %6.2f %6.2f %6.2f %6.2f | %6.2f %4d' % (i, r[0] / 100, r[1] / 100, r[2] / 100, r[3] / 100, r[4] / 100, r[5]))
