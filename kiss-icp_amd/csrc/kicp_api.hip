@@ -96,6 +96,7 @@ static void icp_fill_policy(IcpParams &P) {
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 1);
     P.use_lds = options().icp_use_lds != 0;
+    P.groups_used = (int)options().icp_groups;
 }
 
 }  // namespace kicp
@@ -199,8 +200,12 @@ int kicp_map::ensure_capacity(size_t incoming) {
     if (capacity_ok(incoming)) return KICP_OK;
     KICP_TRY(refresh_counters());
     const size_t live = (size_t)h_ctr[C_LIVE], tomb = (size_t)h_ctr[C_TOMB];
+    // Growth targets leave room for kQueueSlack frames of upper-bound accounting: with frames queued
+    // back-to-back the host only learns the true counters a frame or two late, and every refresh
+    // above is a stream synchronisation.
+    constexpr size_t kQueueSlack = 4;
     if (2 * ((size_t)used_ub + incoming) > slot_cap) {
-        const size_t want = 2 * (live + incoming);
+        const size_t want = 2 * (live + kQueueSlack * incoming);
         uint32_t cap = slot_cap;
         if (want > cap) cap = next_pow2(want * 2);
         if (cap != slot_cap || tomb > 0) KICP_TRY(map_rehash(this, cap));
@@ -210,7 +215,7 @@ int kicp_map::ensure_capacity(size_t incoming) {
         }
     }
     if ((size_t)bump_ub + incoming > (size_t)blocks_cap) {
-        size_t want = ((size_t)bump_ub + incoming) * 2;
+        size_t want = ((size_t)bump_ub + kQueueSlack * incoming) * 2;
         if (want > (size_t)0x7FFFFFF0) want = (size_t)0x7FFFFFF0;
         if (want < (size_t)bump_ub + incoming) {
             set_error("voxel pool cannot grow beyond %d blocks", blocks_cap);
@@ -807,7 +812,8 @@ struct kicp_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t prep_stream = nullptr;
-    hipEvent_t ev_icp_done = nullptr;      // recorded on `stream` behind every ICP launch
+    hipEvent_t ev_icp_done = nullptr;      // recorded on `stream` behind an ICP launch when it is not timed
+    hipEvent_t icp_done_event = nullptr;   // the event recorded behind the most recent ICP launch
     hipEvent_t ev_prep_done[2] = {nullptr, nullptr};  // recorded on `prep_stream`, by frame parity
     uint64_t frames_enqueued = 0;
     kicp_config cfg;
@@ -894,7 +900,15 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(kicp_pipeline_sync(p));
     KICP_TRY(pipe_reserve(p, n));
     kicp_map *m = p->map;
-    if (!m->capacity_ok(n)) pipe_refresh_bounds(p);
+    if (!m->capacity_ok(n)) {
+        pipe_refresh_bounds(p);
+        if (!m->capacity_ok(n) && p->ev_ok && p->in_flight > 2) {
+            // throttle instead of draining: wait until only two frames are still queued, then the
+            // bound (exact counters of the newest finished frame + two frames of slack) fits
+            KICP_HIP(hipEventSynchronize(p->ev_done[p->in_flight - 3]));
+            pipe_refresh_bounds(p);
+        }
+    }
     KICP_TRY(m->ensure_capacity(n));
     hipStream_t s = p->stream, sp = p->prep_stream;
     PipeState *st = pipe_state(p);
@@ -908,7 +922,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     // ===== prep_stream: everything in front of the registration ===================================
     // needs the previous frame's pose bookkeeping (last_delta for the deskew, written by its ICP
     // launch) and the buffers that launch read (src); nothing of the previous frame's map update.
-    if (p->frames_enqueued > 0) KICP_HIP(hipStreamWaitEvent(sp, p->ev_icp_done, 0));
+    if (p->icp_done_event) KICP_HIP(hipStreamWaitEvent(sp, p->icp_done_event, 0));
     // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
     if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, prep, sp);
     PreParams P;
@@ -1000,8 +1014,9 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     const bool timing = options().icp_timing != 0 && p->ev_ok;
     if (timing) KICP_HIP(hipEventRecord(p->ev[slot][0], s));
     launch_icp(I, G, options().icp_profile != 0, s);
-    if (timing) KICP_HIP(hipEventRecord(p->ev[slot][1], s));
-    KICP_HIP(hipEventRecord(p->ev_icp_done, s));
+    // one event behind the launch: it closes the timing bracket and tells prep_stream the pose is ready
+    p->icp_done_event = timing ? p->ev[slot][1] : p->ev_icp_done;
+    KICP_HIP(hipEventRecord(p->icp_done_event, s));
 
     // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
     InsertScratch sc;
@@ -1439,6 +1454,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_points_per_group")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;
         options().icp_points_per_group = value;
+    } else if (!strcmp(name, "icp_groups")) {
+        if (value < 1 || value > kIcpGroupsPerBlock) return KICP_ERR_INVALID_ARG;
+        options().icp_groups = value;
     } else if (!strcmp(name, "icp_use_lds")) {
         options().icp_use_lds = value;
     } else if (!strcmp(name, "icp_profile")) {

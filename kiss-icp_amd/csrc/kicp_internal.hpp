@@ -198,6 +198,7 @@ struct IcpParams {
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
     int use_lds;           // stage candidate voxels in LDS (0 disables)
+    int groups_used;       // 1..16 groups of every workgroup take source points (default 16)
     const PrepState *prep;  // pipeline mode: this frame's counts (copied into the frame record), or nullptr
     unsigned *prof_groups;  // profiling variant only: [kIcpProfIters][256 * 16][4] per-group records, or nullptr
 };
@@ -228,6 +229,7 @@ struct Options {
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
+    long icp_groups = 16;        // groups per workgroup that take source points
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
 };
 Options &options();

@@ -683,8 +683,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const int n = count_of(P.n_ptr, P.n_imm);
     // How many of the launched workgroups take part is decided here, from the actual N_src, so the
     // summation order (hence the result, bit for bit) never depends on host-side hints.
+    const int groups_used = P.groups_used;  // groups of a workgroup that take source points (experiments: 8 = one wave per SIMD)
     int G = P.force_blocks > 0 ? P.force_blocks
-                               : (n + kIcpGroupsPerBlock * P.points_per_group - 1) / (kIcpGroupsPerBlock * P.points_per_group);
+                               : (n + groups_used * P.points_per_group - 1) / (groups_used * P.points_per_group);
     G = max(1, min(G, (int)gridDim.x));
     if ((int)blockIdx.x >= G) return;
     const int cached_rounds = (P.use_lds && m.max_points <= 32) ? kIcpMaxCachedRounds : 0;
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // consecutive source points (neighbours in the scan, hence similar neighbourhood sizes) go to
         // different workgroups: point p belongs to workgroup p % G, group (p / G) % 16
         int round = 0;
-        for (int p = blockIdx.x + G * grp; p < n; p += G * kIcpGroupsPerBlock, ++round) {
+        for (int p = (grp < groups_used) ? (int)blockIdx.x + G * grp : n; p < n; p += G * groups_used, ++round) {
             const bool has_meta = round < cached_rounds;
             IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
             const unsigned ta = PROF ? ticks32() : 0u;
