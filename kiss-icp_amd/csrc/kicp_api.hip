@@ -818,8 +818,9 @@ struct kicp_pipeline {
     uint64_t frames_enqueued = 0;
     kicp_config cfg;
     kicp_map *map = nullptr;
-    // fd (the 0.5 v cloud, read by the map update) exists twice, indexed by frame parity
-    DevBuf raw, ts, tmp, pre, fd[2], src, work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
+    // fd (the 0.5 v cloud, read by the map update) and src (the 1.5 v cloud, read by the registration)
+    // exist twice, indexed by frame parity
+    DevBuf raw, ts, tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -856,7 +857,8 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->pre.reserve(b3, true, p->stream));
     KICP_TRY(p->fd[0].reserve(b3, true, p->stream));
     KICP_TRY(p->fd[1].reserve(b3, true, p->stream));
-    KICP_TRY(p->src.reserve(b3, true, p->stream));
+    KICP_TRY(p->src[0].reserve(b3, true, p->stream));
+    KICP_TRY(p->src[1].reserve(b3, true, p->stream));
     KICP_TRY(p->work.reserve(b3));
     KICP_TRY(p->slot1.reserve(cap * sizeof(int)));
     KICP_TRY(p->slot2.reserve(cap * sizeof(int)));
@@ -922,7 +924,11 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     // ===== prep_stream: everything in front of the registration ===================================
     // needs the previous frame's pose bookkeeping (last_delta for the deskew, written by its ICP
     // launch) and the buffers that launch read (src); nothing of the previous frame's map update.
-    if (p->icp_done_event) KICP_HIP(hipStreamWaitEvent(sp, p->icp_done_event, 0));
+    // Frame k's front stages reuse the buffers of frame k-2 (parity), so that frame must be completely
+    // done (frames of earlier batches are: the host synchronised on them).  The pose of frame k-1 is
+    // only needed to deskew; without timestamps the front stages run under frame k-1's registration.
+    if (p->ev_ok && p->in_flight >= 2) KICP_HIP(hipStreamWaitEvent(sp, p->ev_done[p->in_flight - 2], 0));
+    if (do_deskew && p->icp_done_event) KICP_HIP(hipStreamWaitEvent(sp, p->icp_done_event, 0));
     // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
     if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, prep, sp);
     PreParams P;
@@ -979,7 +985,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     D2.mask = p->tab_cap - 1;
     D2.slot_of = p->slot2.as<int>();
     D2.blk_counts = cnt2;
-    D2.out = p->src.as<double>();
+    D2.out = p->src[par].as<double>();
     D2.n_out = &prep->n_src;
     D2.err = &st->err;
     launch_ds_flags(D2, sp);
@@ -994,7 +1000,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     IcpParams I;
     memset(&I, 0, sizeof I);
     icp_fill_policy(I);
-    I.frame = p->src.as<double>();
+    I.frame = p->src[par].as<double>();
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
     I.prep = prep;
@@ -1082,6 +1088,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
             if (hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming) != hipSuccess) p->ev_ok = false;
         }
     }
+    if (s == KICP_OK && !p->ev_ok) s = KICP_ERR_HIP;  // the events order buffer reuse between the two streams
     if (s == KICP_OK && hipHostMalloc((void **)&p->ring, sizeof(FrameRecord) * kicp_pipeline::kRing) != hipSuccess)
         s = KICP_ERR_OOM;
     // KissICP.hpp:62-68: local_map_(voxel_size, max_range, max_points_per_voxel)
@@ -1118,7 +1125,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->map) kicp_map_destroy(p->map);
-    for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src, &p->work, &p->slot1,
+    for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1], &p->work, &p->slot1,
                       &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep})
         b->release();
     if (p->ev_icp_done) (void)hipEventDestroy(p->ev_icp_done);
@@ -1268,8 +1275,8 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
     *n = cnt;
     const size_t c = cnt < cap ? cnt : cap;
     if (c) {
-        const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src
-                                                                   : p->fd[(p->frames_enqueued - 1) & 1u];
+        const unsigned par = (unsigned)((p->frames_enqueued - 1) & 1u);  // the last frame's buffers
+        const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src[par] : p->fd[par];
         KICP_HIP(hipMemcpyAsync(out, b.p, c * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
         KICP_HIP(hipStreamSynchronize(p->stream));
     }

@@ -116,7 +116,7 @@ __device__ __forceinline__ int shift_order(int code) {
 //   3. every lane keeps its best (squared distance, candidate number); a 5-step xor-shuffle takes
 //      the lexicographic minimum = the reference's strict '<' in shift order and, inside a voxel,
 //      std::min_element's first minimum.
-constexpr int kChunk = 9;
+constexpr int kChunk = 6;
 
 struct Probe {
     int blk;   // block id of this lane's voxel or -1
@@ -795,8 +795,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 g.dy = vy - meta->v[1];
                 g.dz = vz - meta->v[2];
                 const int W = n0 * g.n1 * g.n2;
-                d2 = (W == 27) ? scan_window<false>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E)
-                               : scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
+                // one code path for exact and widened windows: the two groups of a wave would otherwise
+                // run their scans one after the other whenever they differ
+                d2 = scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
                 if (path == 0 && W != 27) path = 1;
             } else {
                 const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
