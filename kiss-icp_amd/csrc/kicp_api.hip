@@ -3,6 +3,7 @@
 // every create call fails loudly with KICP_ERR_NO_DEVICE.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -21,7 +22,15 @@ void set_error(const char *fmt, ...) {
 }
 const char *get_error() { return g_err; }
 Options &options() {
-    static Options o;
+    static Options o = [] {
+        Options init;
+        // environment overrides, for running an unmodified test-suite against a variant
+        if (const char *e = getenv("KICP_ICP_GROUP_LANES")) {
+            const long v = atol(e);
+            if (v == 16 || v == 32) init.icp_group_lanes = v;
+        }
+        return init;
+    }();
     return o;
 }
 
@@ -1464,6 +1473,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_groups")) {
         if (value < 1 || value > kIcpGroupsPerBlock) return KICP_ERR_INVALID_ARG;
         options().icp_groups = value;
+    } else if (!strcmp(name, "icp_group_lanes")) {
+        if (value != 16 && value != 32) return KICP_ERR_INVALID_ARG;
+        options().icp_group_lanes = value;
     } else if (!strcmp(name, "icp_use_lds")) {
         options().icp_use_lds = value;
     } else if (!strcmp(name, "icp_profile")) {

@@ -154,6 +154,7 @@ constexpr int kIcpThreads = 512;
 constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 probe lanes)
 constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;  // 16
 constexpr int kIcpSolveThreads = 256;  // waves 0..3 (one per SIMD) solve the 6x6 system, the rest wait
+constexpr int kIcpBookThread = kIcpThreads - 64;  // first lane of the last wave: pose / statistics bookkeeping
 constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gather of one scalar
 constexpr int kIcpMaxBlocks = 256;
 constexpr int kIcpMaxCachedRounds = 4;  // rounds of a group whose neighbourhood may be staged in LDS
@@ -175,7 +176,7 @@ static_assert(sizeof(IcpRegionMeta) == 64, "keep the candidate pool 16-byte alig
 
 // fixed part of k_icp's dynamic LDS, in bytes (the candidate pool takes the rest)
 constexpr size_t kIcpFixedLds =
-    ((size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpParts * kIcpSums + kIcpSums + 8) * sizeof(double) +  // sums + est
+    ((size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpParts * kIcpSums + kIcpSums + 8 + 18) * sizeof(double) +  // sums + est + bookkeeping
      8 * sizeof(int) +                                                                                   // control words
      (size_t)kIcpGroupsPerBlock * 64 * 8 +                                                               // window cells
      (size_t)kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) + 15) & ~(size_t)15;
@@ -230,6 +231,7 @@ struct Options {
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
     long icp_groups = 16;        // groups per workgroup that take source points
+    long icp_group_lanes = 32;   // lanes cooperating on one source point: 32 or 16
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
 };
 Options &options();

@@ -323,7 +323,7 @@ __device__ __forceinline__ double scan_lds(const double *cand, int stride, int E
 // the reference's nested strict '<' loops (VoxelHashMap.cpp:46-70).
 // ------------------------------------------------------------------------------------------
 constexpr double kWindowMargin = 0.125;  // fraction of a voxel
-constexpr int kFillChunk = 9;            // voxels whose points are in flight together during a fill
+constexpr int kFillChunk = 12;            // voxels whose points are in flight together during a fill
 
 // first probe of two independent keys issued together, then each chain resolved
 __device__ __forceinline__ void map_find_pair(const MapView &m, bool ok0, unsigned long long key0, bool ok1,
@@ -603,6 +603,307 @@ __device__ __forceinline__ double closest_neighbor_any(const MapView &m, double 
     return scan_hits_wide(m, pr, sx, sy, sz, lane, nn);
 }
 
+// ==========================================================================================
+// 16-lane groups (one DPP row per group, four groups per wave).  With 32-lane groups the
+// association phase is issue-bound: a wave spends ~600 instructions per source point on work that
+// does not get shorter with more lanes (transform, voxel, window test, arg-min, weight and sums),
+// and two waves share each SIMD.  Half the lanes per point = half the waves per point: the 16
+// points of a workgroup fit in four waves, one per SIMD; the other four waves only take part in
+// the exchange.  Same staged layout, same tie rules, same results as the 32-lane functions.
+// ==========================================================================================
+template <int N>
+__device__ __forceinline__ int row_shr_or_zero(int v) {  // lane l of a 16-lane row reads lane l-N, or 0
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int row_inclusive_scan(int v) {
+    v += row_shr_or_zero<1>(v);
+    v += row_shr_or_zero<2>(v);
+    v += row_shr_or_zero<4>(v);
+    v += row_shr_or_zero<8>(v);
+    return v;
+}
+__device__ __forceinline__ int row_sum(int v) {  // every lane of the row ends with the row's sum
+    v += group_xchg<0>(v);
+    v += group_xchg<1>(v);
+    v += group_xchg<2>(v);
+    v += group_xchg<3>(v);
+    return v;
+}
+__device__ __forceinline__ void group16_min(double &best, int &key, int &payload) {
+    group_min_step<0>(best, key, payload);
+    group_min_step<1>(best, key, payload);
+    group_min_step<2>(best, key, payload);
+    group_min_step<3>(best, key, payload);
+}
+// this group's 16 bits of a wave ballot
+__device__ __forceinline__ unsigned row_ballot(bool pred) {
+    return (unsigned)(__ballot(pred) >> (threadIdx.x & 48)) & 0xFFFFu;
+}
+
+constexpr int kFillChunk16 = 5;  // voxels in flight per trip (a lane holds up to two points of each)
+
+// window_fill for a 16-lane group: lane l answers for the window cells l, l+16, l+32, l+48
+__device__ __forceinline__ bool window_fill16(const MapView &m, const double s[3], const int v[3], int lane,
+                                              int2 *cells, double *pool, int pool_doubles, int *bump,
+                                              IcpRegionMeta *meta, int &range_err) {
+    int lo[3], nn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double f = s[a] / m.voxel_size - (double)v[a];  // position inside the voxel, [0, 1)
+        lo[a] = (f < kWindowMargin) ? -2 : -1;
+        const int hi = (f > 1.0 - kWindowMargin) ? 2 : 1;
+        nn[a] = hi - lo[a] + 1;
+    }
+    const int W = nn[0] * nn[1] * nn[2];  // <= 64
+    bool ok[4];
+    unsigned long long key[4];
+    uint32_t slot[4];
+    Slot pr[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int w = lane + 16 * h;
+        ok[h] = false;
+        key[h] = 0;
+        if (w < W) {
+            const int t = div34(w, nn[2]), iz = w - t * nn[2];
+            const int ix = div34(t, nn[1]), iy = t - ix * nn[1];
+            const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
+            const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
+            if (voxel_in_range(qx, qy, qz)) {
+                ok[h] = true;
+                key[h] = pack_voxel(qx, qy, qz);
+            } else if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) {
+                range_err = 1;
+            }
+        }
+        slot[h] = hash_key(key[h], m.mask);
+        pr[h].key = kKeyEmpty;
+        pr[h].block = -1;
+        pr[h].count = 0;
+    }
+    // the first probe of all four keys is in flight together, then each chain is resolved
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        if (ok[h]) pr[h] = load_slot(m.slots + slot[h]);
+    int blk[4], cnt[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        blk[h] = -1;
+        cnt[h] = 0;
+        for (uint32_t probes = 0; ok[h] && probes <= m.mask; ++probes) {
+            if (pr[h].key == key[h]) {
+                blk[h] = pr[h].block;
+                cnt[h] = pr[h].count;
+                break;
+            }
+            if (pr[h].key == kKeyEmpty) break;
+            slot[h] = (slot[h] + 1) & m.mask;
+            pr[h] = load_slot(m.slots + slot[h]);
+        }
+        if (blk[h] < 0) cnt[h] = 0;
+    }
+    // candidate numbering in window order: row h (cells 16h .. 16h+15) comes after rows 0 .. h-1
+    int E = 0;
+    unsigned long long hits = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int offs = E + row_inclusive_scan(cnt[h]) - cnt[h];
+        cells[lane + 16 * h] = make_int2(blk[h], cnt[h] | (offs << 6) | ((lane + 16 * h) << 18));
+        E += row_sum(cnt[h]);
+        hits |= (unsigned long long)row_ballot(blk[h] >= 0) << (16 * h);
+    }
+    // a region of exactly E candidates: reuse the old allocation when it is large enough,
+    // otherwise take a new one from the workgroup's pool (never freed within a launch)
+    const int need = region_doubles(E);
+    int base = meta->base, cap = meta->cap;
+    if (need > cap) {
+        int nb = -1;
+        if (lane == 0) {
+            nb = atomicAdd(bump, need);
+            if (nb + need > pool_doubles) {
+                atomicAdd(bump, -need);
+                nb = -1;
+            }
+        }
+        nb = row_sum(lane == 0 ? nb + 1 : 0) - 1;  // broadcast lane 0's answer
+        if (nb < 0) {  // pool exhausted: this query searches HBM directly from now on
+            if (lane == 0) {
+                meta->valid = 0;
+                meta->cap = -1;
+            }
+            return false;
+        }
+        base = nb;
+        cap = need;
+    }
+    double *X = pool + base, *Y = X + E, *Z = Y + E;
+    unsigned short *T = reinterpret_cast<unsigned short *>(Z + E);
+    group_lds_sync();  // cells[] visible to the whole group
+    while (hits) {
+        double2 xy[kFillChunk16][2];
+        double zz[kFillChunk16][2];
+        int info[kFillChunk16];
+#pragma unroll
+        for (int u = 0; u < kFillChunk16; ++u) {
+            info[u] = -1;
+            if (hits) {
+                const int j = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const int2 c = cells[j];
+                info[u] = c.y;
+                const int n = c.y & 63;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (lane + 16 * r < n) {
+                        xy[u][r] = block_xy(m, c.x)[lane + 16 * r];
+                        zz[u][r] = block_z(m, c.x)[lane + 16 * r];
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFillChunk16; ++u) {
+            if (info[u] >= 0) {
+                const int n = info[u] & 63;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (lane + 16 * r < n) {
+                        const int i = lane + 16 * r;
+                        const int c = ((info[u] >> 6) & 4095) + i;
+                        X[c] = xy[u][r].x;
+                        Y[c] = xy[u][r].y;
+                        Z[c] = zz[u][r];
+                        T[c] = (unsigned short)(((info[u] >> 18) & 63) | (i << 6));  // {cell, index in voxel}
+                    }
+            }
+        }
+    }
+    if (lane == 0) {
+        meta->v[0] = v[0];
+        meta->v[1] = v[1];
+        meta->v[2] = v[2];
+        meta->lo[0] = (signed char)lo[0];
+        meta->lo[1] = (signed char)lo[1];
+        meta->lo[2] = (signed char)lo[2];
+        meta->hi[0] = (signed char)(lo[0] + nn[0] - 1);
+        meta->hi[1] = (signed char)(lo[1] + nn[1] - 1);
+        meta->hi[2] = (signed char)(lo[2] + nn[2] - 1);
+        meta->E = E;
+        meta->base = base;
+        meta->cap = cap;
+        meta->valid = 1;
+    }
+    group_lds_sync();  // candidates and meta visible to the whole group
+    return true;
+}
+
+// scan_window for a 16-lane group (see scan_window): 4 candidates per lane in flight per trip
+__device__ __forceinline__ double scan_window16(const double *region, int E, int W, const WindowGeom &g, double sx,
+                                                double sy, double sz, int lane, double nn[3], int &examined) {
+    constexpr int U = 4;
+    const double *X = region, *Y = X + E, *Z = Y + E;
+    const unsigned short *T = reinterpret_cast<const unsigned short *>(Z + E);
+    unsigned long long inmask = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {  // lane l answers for the cells l, l+16, l+32, l+48
+        const int w = lane + 16 * h;
+        const int t = div34(w, g.n2), iz = w - t * g.n2;
+        const int ix = div34(t, g.n1), iy = t - ix * g.n1;
+        const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
+        const bool in = w < W && (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
+        inmask |= (unsigned long long)row_ballot(in) << (16 * h);
+    }
+    double best = DBL_MAX;
+    int bc = -1, btag = 0, inside = 0;
+    for (int c0 = lane; __ballot(c0 < E) != 0ull; c0 += 16 * U) {  // wave-uniform trip count (ballots inside)
+        int tag[U];
+        double x[U], y[U], z[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 16 * u;
+            ok[u] = c < E;
+            const int cc = ok[u] ? c : 0;
+            tag[u] = ok[u] ? (int)T[cc] : 0;
+            x[u] = X[cc];
+            y[u] = Y[cc];
+            z[u] = Z[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool v = ok[u] && ((inmask >> (tag[u] & 63)) & 1ull);
+            inside += __popc(row_ballot(v));
+            const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
+            const double d = (ex * ex + ey * ey) + ez * ez;
+            if (v && d <= best) {
+                bool take = d < best;
+                if (!take) take = tag_order_key(tag[u], g) < tag_order_key(btag, g);  // exact tie (rare)
+                if (take) {
+                    best = d;
+                    bc = c0 + 16 * u;
+                    btag = tag[u];
+                }
+            }
+        }
+    }
+    examined = inside;
+    int bkey = bc >= 0 ? tag_order_key(btag, g) : 0x7FFFFFFF;
+    group16_min(best, bkey, bc);
+    const int rc = bc >= 0 ? bc : 0;
+    nn[0] = E > 0 ? X[rc] : 0.0;
+    nn[1] = E > 0 ? Y[rc] : 0.0;
+    nn[2] = E > 0 ? Z[rc] : 0.0;
+    return best;
+}
+
+// GetClosestNeighbor straight from HBM by a 16-lane group (queries without a staged window: pool
+// exhausted, more rounds than cached, max_points_per_voxel > 32, staging disabled): lane l walks
+// the voxels l and l+16 of the shift table point by point.  Simple, not fast.
+__device__ __forceinline__ double hbm_search16(const MapView &m, double sx, double sy, double sz, int lane,
+                                               double nn[3], int &examined, int &range_err) {
+    const int vx = voxel_coord(sx, m.voxel_size), vy = voxel_coord(sy, m.voxel_size),
+              vz = voxel_coord(sz, m.voxel_size);
+    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF, total = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = lane + 16 * h;
+        if (j < 27) {
+            const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1;
+            const int qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1;
+            const int qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+            if (voxel_in_range(qx, qy, qz)) {
+                int cnt = 0;
+                const int blk = map_find(m, pack_voxel(qx, qy, qz), cnt);
+                if (blk >= 0) {
+                    total += cnt;
+                    const double2 *xy = block_xy(m, blk);
+                    const double *z = block_z(m, blk);
+                    for (int k = 0; k < cnt; ++k) {
+                        const double dx = xy[k].x - sx, dy = xy[k].y - sy, dz = z[k] - sz;
+                        const double d = (dx * dx + dy * dy) + dz * dz;
+                        if (d < best) {  // j ascends with h, k ascends: the lane's first minimum in reference order
+                            best = d;
+                            bx = xy[k].x;
+                            by = xy[k].y;
+                            bz = z[k];
+                            bkey = (j << 20) | k;
+                        }
+                    }
+                }
+            } else {
+                range_err = 1;
+            }
+        }
+    }
+    examined = row_sum(total);
+    int src = lane;
+    group16_min(best, bkey, src);
+    nn[0] = __shfl(bx, src, 16);
+    nn[1] = __shfl(by, src, 16);
+    nn[2] = __shfl(bz, src, 16);
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_closest_neighbor: VoxelHashMap::GetClosestNeighbor batched over nq queries
 // ------------------------------------------------------------------------------------------
@@ -652,6 +953,11 @@ struct IcpShared {  // head of the dynamic LDS (kIcpFixedLds bytes with the regi
     double range_sum[kIcpParts][kIcpSums];
     double tot[kIcpSums];
     double est[8];  // q[4], t[3], |dx|
+    // kept by ONE thread (kIcpBookThread of workgroup 0), off the critical path and out of registers:
+    double T_icp[7];  // accumulated update, q[4] t[3]
+    double guess[7];
+    unsigned long long ncorr_last, ncorr_total, examined_total;
+    double pad2;
     int fail;
     int bump;  // doubles handed out from the candidate pool
     int pad[6];
@@ -663,7 +969,9 @@ static_assert(sizeof(IcpShared) + kIcpMaxCachedRounds * kIcpGroupsPerBlock * siz
 // low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
 __device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
 
-template <bool PROF>
+// GL = lanes per source point: 32 (two groups per wave, all eight waves associate) or 16 (four
+// groups per wave: waves 0..3 associate, one per SIMD; waves 4..7 only gather and wait)
+template <bool PROF, int GL>
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
@@ -674,8 +982,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     constexpr int kPoolDoubles = (int)((kIcpLdsBytes - kIcpFixedLds) / sizeof(double));
 
     const int tid = threadIdx.x;
-    const int lane = tid & 31;
-    const int grp = tid >> 5;
+    const int lane = tid & (GL - 1);
+    const int grp = tid / GL;  // GL == 16: threads 256.. get grp >= 16 and never own a source point
     const MapView &m = P.map;
     PipeState *st = P.state;
 
@@ -712,6 +1020,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if (tid == 0) {
         sh.fail = 0;
         sh.bump = 0;
+        const SE3 id = se3_identity();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh.T_icp[i] = id.q[i];
+            sh.guess[i] = guess.q[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sh.T_icp[4 + i] = id.t[i];
+            sh.guess[4 + i] = guess.t[i];
+        }
+        sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
     }
     if (tid < kIcpMaxCachedRounds * kIcpGroupsPerBlock) {
         metas[tid].valid = 0;
@@ -722,9 +1042,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     __syncthreads();
 
     SE3 est = guess;
-    SE3 T_icp = se3_identity();
     int iterations = 0, converged = 0;
-    unsigned long long examined_total = 0, ncorr_total = 0, ncorr_last = 0;
     int range_err = 0;
     bool failed = false;
 
@@ -776,7 +1094,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             int path = cached ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
             const unsigned tb = PROF ? ticks32() : 0u;
             if (!cached && has_meta && meta->cap >= 0) {
-                cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
+                if (GL == 16)
+                    cached = window_fill16(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
+                else
+                    cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
                 if (cached) path = 2;
             }
             const unsigned tc = PROF ? ticks32() : 0u;
@@ -797,8 +1118,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const int W = n0 * g.n1 * g.n2;
                 // one code path for exact and widened windows: the two groups of a wave would otherwise
                 // run their scans one after the other whenever they differ
-                d2 = scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
+                d2 = (GL == 16) ? scan_window16(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E)
+                                : scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
                 if (path == 0 && W != 27) path = 1;
+            } else if (GL == 16) {
+                d2 = hbm_search16(m, s[0], s[1], s[2], lane, nn, E, range_err);
             } else {
                 const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
                 E = pr.E;
@@ -846,7 +1170,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // ---- workgroup reduction (fixed order) ----------------------------------------------
         const unsigned c1 = PROF ? ticks32() : 0u;
         acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
-        if (lane == 0) {
+        if (lane == 0 && grp < kIcpGroupsPerBlock) {
 #pragma unroll
             for (int k = 0; k < kIcpSums; ++k) sh.part[grp][k] = acc[k];
         }
@@ -970,10 +1294,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 sh.est[6] = est.t[2];
                 sh.est[7] = nrm2;
             }
-            T_icp = se3_mul(est, T_icp);
-            ncorr_last = (unsigned long long)S[16];
-            ncorr_total += ncorr_last;
-            examined_total += (unsigned long long)S[17];
         }
         __syncthreads();
         if (tid >= kIcpSolveThreads) {
@@ -985,6 +1305,24 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             est.t[1] = sh.est[5];
             est.t[2] = sh.est[6];
             nrm2 = sh.est[7];
+        }
+        if (blockIdx.x == 0 && tid == kIcpBookThread) {
+            // T_icp = est * T_icp (Registration.cpp:161) and the statistics, by a thread whose wave is
+            // not on the critical path; sh.tot stays valid until the next gather
+            SE3 T;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T.q[i] = sh.T_icp[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T.t[i] = sh.T_icp[4 + i];
+            T = se3_mul(est, T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh.T_icp[i] = T.q[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sh.T_icp[4 + i] = T.t[i];
+            const unsigned long long nc = (unsigned long long)sh.tot[16];
+            sh.ncorr_last = nc;
+            sh.ncorr_total += nc;
+            sh.examined_total += (unsigned long long)sh.tot[17];
         }
         iterations = it + 1;
         const unsigned c4 = PROF ? ticks32() : 0u;
@@ -1011,7 +1349,21 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if (range_err) atomicOr(&st->err, E_RANGE);
     if (failed && tid == 0) atomicOr(&st->err, E_TIMEOUT);
 
+    __syncthreads();  // the bookkeeping thread's last update is in LDS
     if (blockIdx.x == 0 && tid == 0) {
+        SE3 T_icp, guess;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T_icp.q[i] = sh.T_icp[i];
+            guess.q[i] = sh.guess[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T_icp.t[i] = sh.T_icp[4 + i];
+            guess.t[i] = sh.guess[4 + i];
+        }
+        const unsigned long long examined_total = sh.examined_total, ncorr_last = sh.ncorr_last,
+                                 ncorr_total = sh.ncorr_total;
         const SE3 new_pose = se3_mul(T_icp, guess);  // Registration.cpp:166
         st->new_pose = new_pose;
         st->guess = guess;
@@ -1709,20 +2061,25 @@ int icp_prepare() {
     // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute)
     static bool done = false;
     if (done) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
-    if (e != hipSuccess) return (int)e;
+    const void *kernels[4] = {reinterpret_cast<const void *>(k_icp<false, 32>), reinterpret_cast<const void *>(k_icp<true, 32>),
+                              reinterpret_cast<const void *>(k_icp<false, 16>), reinterpret_cast<const void *>(k_icp<true, 16>)};
+    for (const void *k : kernels) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
+        if (e != hipSuccess) return (int)e;
+    }
     done = true;
     return 0;
 }
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s) {
-    if (profile)
-        hipLaunchKernelGGL(k_icp<true>, dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+    const bool lanes16 = options().icp_group_lanes == 16;
+    if (profile && lanes16)
+        hipLaunchKernelGGL((k_icp<true, 16>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+    else if (profile)
+        hipLaunchKernelGGL((k_icp<true, 32>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+    else if (lanes16)
+        hipLaunchKernelGGL((k_icp<false, 16>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
     else
-        hipLaunchKernelGGL(k_icp<false>, dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+        hipLaunchKernelGGL((k_icp<false, 32>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
 }
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s) {
