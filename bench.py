@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--icp-blocks", type=int, default=0)
     ap.add_argument("--icp-ppg", type=int, default=0, help="icp_points_per_group option")
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option (kicp_set_option)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
+    ap.add_argument("--device", type=int, default=-1, help="force this device for every rank (plumbing tests on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -89,9 +91,12 @@ def main():
     rank, local_rank, world = multistream.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.device >= 0:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = multistream.init_process_group("nccl") if world > 1 else None
+    dist = multistream.init_process_group(args.backend) if world > 1 else None
+    comm_device = device if args.backend == "nccl" else None  # gloo exchanges host tensors
     if args.icp_blocks:
         _cabi.set_option("icp_blocks", args.icp_blocks)
     if args.icp_ppg:
@@ -110,18 +115,18 @@ def main():
     torch.cuda.synchronize()
 
     pipe = KissICP(load_config(**cfg_over), device_id=local_rank)
-    multistream.run_batch(pipe, frames[:W], dist, device)  # W untimed warm-up frames
+    multistream.run_batch(pipe, frames[:W], dist, comm_device)  # W untimed warm-up frames
     pipe.icp_timing(reset=True)
 
     # ---- timed region: exactly K frames, barrier + synchronize on both sides -------------------
     multistream.barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    local_poses, all_poses = multistream.run_batch(pipe, frames[W:W + K], dist, device)
+    local_poses, all_poses = multistream.run_batch(pipe, frames[W:W + K], dist, comm_device)
     torch.cuda.synchronize()
     multistream.barrier(dist)
     elapsed = time.perf_counter() - t0
-    elapsed = multistream.max_over_ranks(elapsed, dist, device)
+    elapsed = multistream.max_over_ranks(elapsed, dist, comm_device)
     icp = pipe.icp_timing()
     stats = pipe.last_stats()
 
