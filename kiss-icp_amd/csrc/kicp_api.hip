@@ -821,8 +821,7 @@ struct kicp_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t prep_stream = nullptr;
-    hipEvent_t ev_icp_done = nullptr;      // recorded on `stream` behind an ICP launch when it is not timed
-    hipEvent_t icp_done_event = nullptr;   // the event recorded behind the most recent ICP launch
+    hipEvent_t icp_done_event = nullptr;   // the event recorded behind the most recent ICP launch (or none)
     hipEvent_t ev_prep_done[2] = {nullptr, nullptr};  // recorded on `prep_stream`, by frame parity
     uint64_t frames_enqueued = 0;
     kicp_config cfg;
@@ -836,7 +835,6 @@ struct kicp_pipeline {
     static constexpr int kRing = 256;
     FrameRecord *ring = nullptr;  // hipHostMalloc
     hipEvent_t ev[kRing][2];
-    hipEvent_t ev_done[kRing];  // behind the last kernel of the frame in that ring slot
     bool ev_ok = false;
     int in_flight = 0;
     uint64_t frames_done = 0;
@@ -884,11 +882,11 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
 // whose last kernel has completed left its exact counters in the pinned ring; frames queued behind
 // it can each have added at most one voxel per raw point.
 static void pipe_refresh_bounds(kicp_pipeline *p) {
-    if (!p->ev_ok) return;
     kicp_map *m = p->map;
-    long pending = 0;
-    for (int i = p->in_flight - 1; i >= 0; --i) {
-        if (hipEventQuery(p->ev_done[i]) == hipSuccess) {
+    // ev[i + 1][0] sits in front of frame i+1's registration launch, i.e. behind frame i's last kernel
+    long pending = p->in_flight > 0 ? (long)p->ring[p->in_flight - 1].n_raw : 0;
+    for (int i = p->in_flight - 2; i >= 0; --i) {
+        if (hipEventQuery(p->ev[i + 1][0]) == hipSuccess) {
             const FrameRecord &r = p->ring[i];
             const long used = (long)r.map_ctr[C_USED] + pending, bump = (long)r.map_ctr[C_BUMP] + pending;
             if (used < m->used_ub) m->used_ub = used;
@@ -913,10 +911,11 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     kicp_map *m = p->map;
     if (!m->capacity_ok(n)) {
         pipe_refresh_bounds(p);
-        if (!m->capacity_ok(n) && p->ev_ok && p->in_flight > 2) {
-            // throttle instead of draining: wait until only two frames are still queued, then the
-            // bound (exact counters of the newest finished frame + two frames of slack) fits
-            KICP_HIP(hipEventSynchronize(p->ev_done[p->in_flight - 3]));
+        if (!m->capacity_ok(n) && p->in_flight > 2) {
+            // throttle instead of draining: wait until frame in_flight-3 is done (the launch-start
+            // event of the frame behind it), i.e. at most two frames are still queued; then the bound
+            // (exact counters of the newest finished frame + two frames of slack) fits
+            KICP_HIP(hipEventSynchronize(p->ev[p->in_flight - 2][0]));
             pipe_refresh_bounds(p);
         }
     }
@@ -934,9 +933,10 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     // needs the previous frame's pose bookkeeping (last_delta for the deskew, written by its ICP
     // launch) and the buffers that launch read (src); nothing of the previous frame's map update.
     // Frame k's front stages reuse the buffers of frame k-2 (parity), so that frame must be completely
-    // done (frames of earlier batches are: the host synchronised on them).  The pose of frame k-1 is
-    // only needed to deskew; without timestamps the front stages run under frame k-1's registration.
-    if (p->ev_ok && p->in_flight >= 2) KICP_HIP(hipStreamWaitEvent(sp, p->ev_done[p->in_flight - 2], 0));
+    // done: the event in front of frame k-1's registration launch says so (frames of earlier batches
+    // are done anyway: the host synchronised on them).  The pose of frame k-1 is only needed to
+    // deskew; without timestamps the front stages run under frame k-1's registration.
+    if (p->in_flight >= 2) KICP_HIP(hipStreamWaitEvent(sp, p->ev[p->in_flight - 1][0], 0));
     if (do_deskew && p->icp_done_event) KICP_HIP(hipStreamWaitEvent(sp, p->icp_done_event, 0));
     // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
     if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, prep, sp);
@@ -1026,12 +1026,17 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
         I.prof_groups = p->prof_groups.as<unsigned>();
     }
     const int slot = p->in_flight;
-    const bool timing = options().icp_timing != 0 && p->ev_ok;
-    if (timing) KICP_HIP(hipEventRecord(p->ev[slot][0], s));
+    // Two events per frame, each doing double duty: ev[slot][0] in front of the launch opens the timing
+    // bracket and marks "the previous frame is completely done" (buffer reuse, capacity bounds);
+    // ev[slot][1] behind it closes the bracket and tells prep_stream the pose is ready.
+    KICP_HIP(hipEventRecord(p->ev[slot][0], s));
     launch_icp(I, G, options().icp_profile != 0, s);
-    // one event behind the launch: it closes the timing bracket and tells prep_stream the pose is ready
-    p->icp_done_event = timing ? p->ev[slot][1] : p->ev_icp_done;
-    KICP_HIP(hipEventRecord(p->icp_done_event, s));
+    // (skipped when nobody would look at it: timing off and a configuration that never deskews)
+    p->icp_done_event = nullptr;
+    if (options().icp_timing != 0 || c.deskew) {
+        p->icp_done_event = p->ev[slot][1];
+        KICP_HIP(hipEventRecord(p->icp_done_event, s));
+    }
 
     // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
     InsertScratch sc;
@@ -1047,7 +1052,6 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     rec->n_raw = n;
     launch_map_prune(v, m->bump_ub, st, 1, nullptr, reinterpret_cast<unsigned *>(rec), kRecWords, s);
     KICP_HIP(hipGetLastError());
-    if (p->ev_ok) KICP_HIP(hipEventRecord(p->ev_done[slot], s));
     p->in_flight++;
     p->frames_enqueued++;
     return KICP_OK;
@@ -1085,7 +1089,6 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     int s = KICP_OK;
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_icp_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_prep_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_prep_done[1], hipEventDisableTiming) != hipSuccess)
         s = KICP_ERR_HIP;
@@ -1094,7 +1097,6 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
         for (int i = 0; i < kicp_pipeline::kRing && p->ev_ok; ++i) {
             for (int j = 0; j < 2; ++j)
                 if (hipEventCreate(&p->ev[i][j]) != hipSuccess) p->ev_ok = false;
-            if (hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming) != hipSuccess) p->ev_ok = false;
         }
     }
     if (s == KICP_OK && !p->ev_ok) s = KICP_ERR_HIP;  // the events order buffer reuse between the two streams
@@ -1137,14 +1139,12 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1], &p->work, &p->slot1,
                       &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep})
         b->release();
-    if (p->ev_icp_done) (void)hipEventDestroy(p->ev_icp_done);
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
     if (p->prep_stream) (void)hipStreamDestroy(p->prep_stream);
     if (p->ev_ok)
         for (int i = 0; i < kicp_pipeline::kRing; ++i) {
             for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
-            (void)hipEventDestroy(p->ev_done[i]);
         }
     if (p->ring) (void)hipHostFree(p->ring);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1164,6 +1164,7 @@ int kicp_pipeline_sync(kicp_pipeline *p) {
         if (options().icp_timing && p->ev_ok) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, p->ev[i][0], p->ev[i][1]) == hipSuccess) p->icp_ms += ms;
+            else (void)hipGetLastError();  // e.g. the option was switched on while frames were queued
         }
         p->icp_launches++;
         p->icp_iters += (uint64_t)r.st.icp_iterations;

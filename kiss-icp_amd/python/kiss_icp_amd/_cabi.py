@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
-LIB_PATH = os.path.join(_CSRC, "libkicp.so")
+LIB_PATH = os.environ.get("KICP_LIB") or os.path.join(_CSRC, "libkicp.so")  # KICP_LIB: A/B builds of the same library
 
 KICP_OK = 0
 STATUS_NAMES = {
