@@ -404,6 +404,35 @@ def test_pipeline_async_device_frames_match_sync(gpu, O):
         assert np.array_equal(ks.last_pose, poses_async[i]), i
 
 
+@pytest.mark.parametrize("deskew", [False, True])
+def test_pipeline_async_long_queue_two_streams(gpu, O, deskew):
+    """more frames queued than the pipeline keeps in flight, with and without deskewing: the front
+    stages of frame k+1 run on a second stream (under frame k's registration when no pose is needed,
+    behind it when deskewing), buffers alternate by frame parity, the host throttles instead of
+    synchronising -- and the trajectory is bit for bit the synchronous one"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.datasets import kitti_like, mulran_like
+    from kiss_icp_amd.kiss_icp import KissICP
+
+    n_frames = 14
+    ds = (mulran_like if deskew else kitti_like)(seed=9, n_frames=n_frames, beams=32, azimuth_steps=512)
+    scans = [ds[i] for i in range(n_frames)]
+    ka, ks = KissICP(load_config(deskew=deskew)), KissICP(load_config(deskew=deskew))
+    dev = [(_cabi.DeviceArray(p), _cabi.DeviceArray(t) if len(t) else None) for p, t in scans]
+    for d, t in dev:
+        ka.register_frame_device(d.ptr, d.shape[0], t.ptr if t is not None else None, t.shape[0] if t is not None else 0)
+    ka.sync()
+    poses_async = ka.synced_poses()
+    assert len(poses_async) == n_frames
+    for i, (p, t) in enumerate(scans):
+        ks.register_frame(p, t)
+        assert np.array_equal(ks.last_pose, poses_async[i]), i
+    # and the clouds of the last frame come from the right parity buffers
+    for which in (0, 1, 2):  # preprocessed frame, source, frame downsample
+        assert np.array_equal(ka.output(which), ks.output(which)), which
+
+
 # ---- committed golden fixtures (tests/golden/, made by tests/golden/make_golden.py) ----------------------
 def _golden(name):
     import os
