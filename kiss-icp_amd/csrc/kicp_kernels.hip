@@ -322,7 +322,10 @@ __device__ __forceinline__ double scan_lds(const double *cand, int stride, int E
 // distance ties by (position of the voxel in the reference's shift table, index in the voxel) like
 // the reference's nested strict '<' loops (VoxelHashMap.cpp:46-70).
 // ------------------------------------------------------------------------------------------
-constexpr double kWindowMargin = 0.125;  // fraction of a voxel
+#ifndef KICP_WINDOW_MARGIN
+#define KICP_WINDOW_MARGIN 0.125
+#endif
+constexpr double kWindowMargin = KICP_WINDOW_MARGIN;  // fraction of a voxel
 constexpr int kFillChunk = 12;            // voxels whose points are in flight together during a fill
 
 // first probe of two independent keys issued together, then each chain resolved
@@ -1192,43 +1195,62 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // ---- gather every workgroup's partial (bounded spin) --------------------------------
         const unsigned c2 = PROF ? ticks32() : 0u;
         if (tid < kIcpParts * kIcpSums) {
-            // thread (k, part) sums scalar k over a contiguous range of workgroups, in order;
-            // kGatherChunk workgroups (2 granules each) are in flight at a time and only granules
-            // whose tag has not arrived yet are polled again
-            constexpr int kGatherChunk = 4;
+            // thread (k, part) sums scalar k over a contiguous range of workgroups, in order.  All the
+            // granules of the range (up to kGatherChunk workgroups x 2) are in flight together; every
+            // further pass re-polls, again together, exactly the ones whose tag has not arrived yet:
+            // one memory round trip per pass, however many granules are late.
+            constexpr int kGatherChunk = 10;  // >= ceil(256 / kIcpParts): one chunk per thread for any grid
             const int k = tid % kIcpSums, part = tid / kIcpSums;
             const int b0 = (G * part) / kIcpParts, b1 = (G * (part + 1)) / kIcpParts;
             double v = 0.0;
             bool fail = false;
             for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
                 unsigned long long lo[kGatherChunk], hi[kGatherChunk];
+                const unsigned long long *g0 = gran + ((size_t)b * kIcpSums + k) * 2;
+                unsigned pending = 0;
 #pragma unroll
                 for (int u = 0; u < kGatherChunk; ++u) {
-                    const unsigned long long *g = gran + ((size_t)min(b + u, b1 - 1) * kIcpSums + k) * 2;
-                    lo[u] = granule_load(g);
-                    hi[u] = granule_load(g + 1);
-                }
-#pragma unroll
-                for (int u = 0; u < kGatherChunk; ++u) {
-                    if (b + u >= b1) continue;
-                    const unsigned long long *g = gran + ((size_t)(b + u) * kIcpSums + k) * 2;
-                    unsigned spins = 0;
-                    while ((unsigned)(lo[u] >> 32) != epoch || (unsigned)(hi[u] >> 32) != epoch) {
-                        if (PROF) ++gather_passes;
-                        if (++spins > P.spin_limit ||
-                            ((spins & 255u) == 0 &&
-                             (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
-                            fail = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        lo[u] = granule_load(g);
-                        hi[u] = granule_load(g + 1);
+                    lo[u] = hi[u] = 0ull;
+                    if (b + u < b1) {
+                        lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
+                        hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                        pending |= 1u << u;
                     }
-                    const double pv = __longlong_as_double(
-                        (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
-                    v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
                 }
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u)
+                    if ((unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch) pending &= ~(1u << u);
+                unsigned spins = 0;
+                while (pending) {
+                    if (PROF) ++gather_passes;
+                    if (++spins > P.spin_limit ||
+                        ((spins & 255u) == 0 &&
+                         (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
+                        fail = true;
+                        break;
+                    }
+#ifndef KICP_POLL_NO_SLEEP
+                    __builtin_amdgcn_s_sleep(1);
+#endif
+#pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u)
+                        if ((pending >> u) & 1u) {
+                            lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
+                            hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                        }
+#pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u)
+                        if (((pending >> u) & 1u) && (unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch)
+                            pending &= ~(1u << u);
+                }
+                if (fail) break;
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u)
+                    if (b + u < b1) {
+                        const double pv = __longlong_as_double(
+                            (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
+                        v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+                    }
             }
             sh.range_sum[part][k] = v;
             if (fail) sh.fail = 1;
