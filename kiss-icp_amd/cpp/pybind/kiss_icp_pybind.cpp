@@ -9,7 +9,8 @@
 //   _VoxelHashMap, _Preprocessor, _Registration, _AdaptiveThreshold, _voxel_down_sample,
 //   _correct_kitti_scan  as in the reference (note the kwarg spelling max_correspondance_distance)
 //   _KissICP             extra: the fused device pipeline (pipeline::KissICP)
-// Not bound: _kitti_seq_error / _absolute_trajectory_error (offline metrics, out of scope).
+//   _kitti_seq_error, _absolute_trajectory_error   offline metrics (host arithmetic), kept so the
+//                        reference's python/kiss_icp/metrics.py works on this module
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -18,6 +19,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include "kiss_icp/metrics/Metrics.hpp"
 #include "kiss_icp/pipeline/KissICP.hpp"
 
 namespace py = pybind11;
@@ -44,6 +46,17 @@ Sophus::SE3d se3_from_array(const ArrayD &T) {
 py::array_t<double> se3_to_array(const Sophus::SE3d &T) {
     py::array_t<double> out({4, 4});
     kiss_icp::detail::se3_to_rowmajor(T, out.mutable_data());
+    return out;
+}
+
+// (N, 4, 4) array or a sequence of 4x4 matrices -> std::vector<Eigen::Matrix4d> (no rigidity check:
+// the reference's metrics take plain Matrix4d)
+std::vector<Eigen::Matrix4d> poses_from_array(const ArrayD &a) {
+    if (a.ndim() != 3 || a.shape(1) != 4 || a.shape(2) != 4) throw py::cast_error("expected an (N, 4, 4) float64 array");
+    std::vector<Eigen::Matrix4d> out(static_cast<size_t>(a.shape(0)));
+    for (size_t i = 0; i < out.size(); ++i)
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) out[i](r, c) = a.data()[i * 16 + r * 4 + c];
     return out;
 }
 
@@ -147,6 +160,18 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
             return out;
         },
         "frame"_a);
+
+    // Metrics (kiss_icp_pybind.cpp:141-143)
+    m.def(
+        "_kitti_seq_error",
+        [](const ArrayD &gt, const ArrayD &res) { return metrics::SeqError(poses_from_array(gt), poses_from_array(res)); },
+        "gt_poses"_a, "results_poses"_a);
+    m.def(
+        "_absolute_trajectory_error",
+        [](const ArrayD &gt, const ArrayD &res) {
+            return metrics::AbsoluteTrajectoryError(poses_from_array(gt), poses_from_array(res));
+        },
+        "gt_poses"_a, "results_poses"_a);
 
     // the fused device pipeline (not in the reference's module: its C++ KissICP is used by ROS only)
     py::class_<pipeline::KISSConfig>(m, "_KISSConfig")

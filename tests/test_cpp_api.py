@@ -32,7 +32,7 @@ def built():
 def test_pybind_surface_matches_reference_names(built):
     m = built
     for name in ("_Vector3dVector", "_VoxelHashMap", "_Preprocessor", "_Registration", "_AdaptiveThreshold",
-                 "_voxel_down_sample", "_correct_kitti_scan"):
+                 "_voxel_down_sample", "_correct_kitti_scan", "_kitti_seq_error", "_absolute_trajectory_error"):
         assert hasattr(m, name), name
     for meth in ("_clear", "_empty", "_update", "_add_points", "_remove_far_away_points", "_point_cloud"):
         assert hasattr(m._VoxelHashMap, meth), meth
