@@ -1107,6 +1107,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             double nn[3];
             double d2;
             int E;
+#ifdef KICP_HEAVY_PRIO
+            // a wave that holds a large staged window gets issue priority over its SIMD sibling for
+            // the scan: the heaviest query sets the pace of the whole iteration, light waves have slack
+            if (__ballot(cached && meta->E > KICP_HEAVY_PRIO) != 0ull) __builtin_amdgcn_s_setprio(2);
+#endif
             if (cached) {
                 WindowGeom g;
                 g.lo0 = meta->lo[0];
@@ -1170,6 +1175,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
             }
         }
+#ifdef KICP_HEAVY_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- workgroup reduction (fixed order) ----------------------------------------------
         const unsigned c1 = PROF ? ticks32() : 0u;
         acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)

@@ -4,14 +4,14 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/ab.txt
-( timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "async or kitti_like or align_points" 2>&1 | tail -3 ) > gpurun_out/pytest_ab.log
+( echo skipped ) > gpurun_out/pytest_ab.log
 run() { echo "== $1" >> gpurun_out/ab.txt; shift; ( "$@" >> gpurun_out/ab.txt 2>/dev/null ); }
 run "default" timeout 200 python bench.py --no-cpu-baseline
 run "default again" timeout 200 python bench.py --no-cpu-baseline
 for so in kiss-icp_amd/csrc/variants/*.so; do
   run "$so" env KICP_LIB=$PWD/$so timeout 200 python bench.py --no-cpu-baseline
 done
-run "timing off" timeout 200 python bench.py --no-cpu-baseline --opt icp_timing=0
+
 cat gpurun_out/pytest_ab.log
 python - <<'PY'
 import json
