@@ -188,6 +188,9 @@ def main():
     }
     cyc, tk = pipe.icp_clock()
     out["icp_shader_mhz"] = 100.0 * cyc / max(1, tk)
+    first_us, total_us, n_it = pipe.icp_first_iteration()  # last frame of the timed region
+    out["icp_last_launch"] = {"first_iteration_us": first_us, "total_us": total_us, "iterations": n_it,
+                              "later_iterations_us": (total_us - first_us) / max(1, n_it - 1)}
     # roofline of the dominant kernel (k_icp): algorithmic bytes of AlignPointsToMap
     # (per iteration N_src*(24+24) + N_src*27*16 + E*24 + 336) / device time
     # measured with hipEvents on the pipeline's own stream around every k_icp launch.

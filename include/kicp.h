@@ -208,6 +208,10 @@ int kicp_pipeline_icp_profile(kicp_pipeline *p, uint64_t cycles[4], int *workgro
 /* duration of the LAST ICP launch as seen by its workgroup 0: shader-clock cycles (s_memtime) and
  * 100 MHz wall ticks (s_memrealtime); cycles / ticks * 100 = effective shader clock in MHz */
 int kicp_pipeline_icp_clock(kicp_pipeline *p, uint64_t *cycles, uint64_t *ticks);
+/* the LAST ICP launch as seen by its workgroup 0, in 100 MHz wall ticks: time to the end of its first
+ * iteration (which stages the neighbourhood windows from HBM), total time, iterations executed */
+int kicp_pipeline_icp_first_iteration(kicp_pipeline *p, uint64_t *ticks_first, uint64_t *ticks_total,
+                                      int *iterations);
 /* per-iteration profile of the LAST ICP launch (at most the first 24 iterations), 6 uint32 per
  * iteration in 10 ns ticks: workgroup 0's {associate, publish, gather, solve}, the slowest
  * 32-lane group's associate time over all workgroups, gather polling passes of workgroup 0 */

@@ -1354,6 +1354,16 @@ int kicp_pipeline_icp_clock(kicp_pipeline *p, uint64_t *cycles, uint64_t *ticks)
     return KICP_OK;
 }
 
+int kicp_pipeline_icp_first_iteration(kicp_pipeline *p, uint64_t *ticks_first, uint64_t *ticks_total, int *iterations) {
+    if (!p || !ticks_first || !ticks_total || !iterations) return KICP_ERR_INVALID_ARG;
+    PipeState h;
+    KICP_TRY(pipe_state_get(p, h));
+    *ticks_first = h.icp_iterations > 0 ? h.prof_it0_ticks : 0;
+    *ticks_total = h.prof_clock[1];
+    *iterations = h.icp_iterations;
+    return KICP_OK;
+}
+
 int kicp_pipeline_icp_iteration_profile(kicp_pipeline *p, uint32_t *out, int cap_iters, int *n_iters) {
     if (!p || !n_iters || (!out && cap_iters > 0)) return KICP_ERR_INVALID_ARG;
     PipeState h;

@@ -141,6 +141,7 @@ struct PipeState {
     // whole-launch duration of the last ICP kernel seen by workgroup 0: shader-clock cycles (s_memtime)
     // and 100 MHz wall ticks (s_memrealtime) -> effective shader clock
     unsigned long long prof_clock[2];
+    unsigned long long prof_it0_ticks;  // 100 MHz ticks from the launch's start to the end of its first iteration
     // the first kIcpProfIters iterations of the last launch, 10 ns ticks: workgroup 0's
     // {associate, publish, gather, solve}, the slowest group's associate time over ALL workgroups,
     // and the number of polling passes workgroup 0's thread 0 needed in the gather

@@ -1355,6 +1355,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             sh.examined_total += (unsigned long long)sh.tot[17];
         }
         iterations = it + 1;
+        if (it == 0 && blockIdx.x == 0 && tid == 0) st->prof_it0_ticks = wall_clock64() - launch_tick;
         const unsigned c4 = PROF ? ticks32() : 0u;
         t_assoc += c1 - c0;
         t_publish += c2 - c1;

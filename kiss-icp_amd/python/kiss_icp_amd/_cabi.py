@@ -103,6 +103,7 @@ SIGNATURES = {
     "kicp_pipeline_icp_profile": [_vp, _u64p, C.POINTER(_i)],
     "kicp_pipeline_icp_iteration_profile": [_vp, _vp, _i, C.POINTER(_i)],
     "kicp_pipeline_icp_clock": [_vp, _u64p, _u64p],
+    "kicp_pipeline_icp_first_iteration": [_vp, _u64p, _u64p, C.POINTER(_i)],
     "kicp_pipeline_icp_group_profile": [_vp, _vp, _sz, C.POINTER(_i), C.POINTER(_i)],
     "kicp_pipeline_stream": [_vp, C.POINTER(_vp)],
     "kicp_device_alloc": [_i, _sz, C.POINTER(_vp)],

@@ -154,6 +154,12 @@ class KissICP:
         _cabi.check(_cabi.lib().kicp_pipeline_icp_clock(self._h, C.byref(cyc), C.byref(tk)))
         return cyc.value, tk.value
 
+    def icp_first_iteration(self):
+        """(us to the end of the first iteration, us total, iterations) of the last ICP launch"""
+        a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        _cabi.check(_cabi.lib().kicp_pipeline_icp_first_iteration(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value / 100.0, b.value / 100.0, n.value
+
     def icp_group_profile(self):
         """(n_iters, n_groups, 7) int64 of the last ICP launch ("icp_profile" option on): 10 ns ticks
         {wait-in, transform + window test, window fill, scan}, staged points, examined points, path"""
