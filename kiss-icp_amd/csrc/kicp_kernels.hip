@@ -1058,7 +1058,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // consecutive source points (neighbours in the scan, hence similar neighbourhood sizes) go to
         // different workgroups: point p belongs to workgroup p % G, group (p / G) % 16
         int round = 0;
+#ifdef KICP_CONTIGUOUS_POINTS
+        // experiment: a workgroup takes CONSECUTIVE source points (neighbours in the scan share most of
+        // their voxels, so a workgroup fetches each voxel once instead of eight workgroups fetching it)
+        for (int p = (grp < groups_used) ? (int)blockIdx.x * groups_used + grp : n; p < n; p += G * groups_used, ++round) {
+#else
         for (int p = (grp < groups_used) ? (int)blockIdx.x + G * grp : n; p < n; p += G * groups_used, ++round) {
+#endif
             const bool has_meta = round < cached_rounds;
             IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
             const unsigned ta = PROF ? ticks32() : 0u;
