@@ -2012,9 +2012,19 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
     const int nb = min(m.ctr[C_BUMP], m.blocks_cap);
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
         BlockHdr *hdr = block_hdr(m, b);
+#ifdef KICP_PRUNE_PARALLEL_LOADS
+        // experiment: the three loads of a block are independent of each other (every block below the
+        // high-water mark is valid memory), so issue them together instead of count -> point
+        const int cnt = hdr->count;
+        const double2 p0 = block_xy(m, b)[0];
+        const double z0 = block_z(m, b)[0];
+        if (cnt <= 0) continue;
+        const double dx = p0.x - ox, dy = p0.y - oy, dz = z0 - oz;
+#else
         if (hdr->count <= 0) continue;
         const double2 p0 = block_xy(m, b)[0];
         const double dx = p0.x - ox, dy = p0.y - oy, dz = block_z(m, b)[0] - oz;
+#endif
         if ((dx * dx + dy * dy) + dz * dz >= md2) {
             Slot *sl = m.slots + hdr->slot;
             sl->key = kKeyTomb;

@@ -409,8 +409,15 @@ KICP_HD void ldlt6_solve(const double A[36], const double b[6], double x[6]) {
         }
         const double akk = m[k][k];
         if (fabs(akk) > 0.0) {
+#ifdef KICP_LDLT_RECIP
+            // experiment: one divide per pivot instead of N-k-1 (each quotient moves by <= 1 ulp)
+            const double rk = 1.0 / akk;
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) m[i][k] *= rk;
+#else
 #pragma unroll
             for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
+#endif
         }
     }
     // dst = P b
