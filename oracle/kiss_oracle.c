@@ -41,10 +41,18 @@ int ko_num_procs(void) {
 }
 
 static int resolve_threads(int max_threads) {
-    /* Registration.cpp:130-131: max_num_threads > 0 ? it : tbb max_concurrency() */
+    /* Registration.cpp:130-131: max_num_threads > 0 ? it : tbb max_concurrency().
+     * KISS_ORACLE_THREADS caps the "all cores" default: on a 256-core box forking 256 OpenMP
+     * threads twice per ICP iteration over ~2 k points costs more than the work (the test-suite
+     * sets it; the timed CPU baseline of bench.py passes explicit thread counts and is unaffected). */
     int hw = ko_num_procs();
-    if (max_threads <= 0) return hw;
-    return max_threads;
+    if (max_threads > 0) return max_threads;
+    const char *cap = getenv("KISS_ORACLE_THREADS");
+    if (cap) {
+        const int c = atoi(cap);
+        if (c > 0 && c < hw) return c;
+    }
+    return hw;
 }
 
 /* ======================================================================================

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle's "all cores" default is counter-productive on many-core hosts (see oracle/kiss_oracle.c)
+os.environ.setdefault("KISS_ORACLE_THREADS", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "kiss-icp_amd", "python")):
     if p not in sys.path:
