@@ -30,6 +30,10 @@ def gpu():
     """skip-proof guard: -m gpu tests must run on a box with a GPU and the built library"""
     from kiss_icp_amd import _cabi
 
+    if not os.path.exists(_cabi.LIB_PATH):  # e.g. a fresh checkout on the GPU box: build it (hipcc is in the image)
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "kiss-icp_amd", "csrc")])
     _cabi.lib()  # raises ImportError when libkicp.so is missing -- never fall back
     n = _cabi.device_count()
     if n == 0:
