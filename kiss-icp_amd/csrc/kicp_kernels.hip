@@ -1903,6 +1903,23 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
         int b = cur.block;
         int cnt = (b >= 0) ? cur.count : 0;
         const bool need = slot >= 0 && b < 0;  // new voxel (VoxelHashMap.cpp:112-116)
+#ifdef KICP_APPLY_PREFETCH
+        // experiment: the stored points of an existing voxel and this record's incoming points do not
+        // depend on the allocation below -- have them in flight while its atomics round-trip
+        double pf_ex = 0.0, pf_ey = 0.0, pf_ez = 0.0, pf_nx = 0.0, pf_ny = 0.0, pf_nz = 0.0;
+        const bool pf_ok = slot >= 0 && L <= kRecList && m.max_points <= 32;
+        if (pf_ok && b >= 0 && lane < cnt) {
+            const double2 xy = block_xy(m, b)[lane];
+            pf_ex = xy.x;
+            pf_ey = xy.y;
+            pf_ez = block_z(m, b)[lane];
+        }
+        if (pf_ok && lane < L) {
+            pf_nx = sc.world[3 * my_idx];
+            pf_ny = sc.world[3 * my_idx + 1];
+            pf_nz = sc.world[3 * my_idx + 2];
+        }
+#endif
         // ---- one allocation per workgroup: recycled blocks first, then fresh ones ------------------
         if (lane == 0) sh_need[g] = need ? 1 : 0;
         __syncthreads();
@@ -1950,6 +1967,10 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
         }
         double2 *pxy = block_xy(m, b);
         double *pz = block_z(m, b);
+#ifdef KICP_APPLY_PREFETCH
+        double ex = pf_ex, ey = pf_ey, ez = pf_ez;  // stored point `lane` (a new voxel has none)
+        double nx = pf_nx, ny = pf_ny, nz = pf_nz;  // incoming point held by this lane
+#else
         double ex = 0.0, ey = 0.0, ez = 0.0;  // stored point `lane`
         if (lane < cnt) {
             const double2 xy = pxy[lane];
@@ -1963,6 +1984,7 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
             ny = sc.world[3 * my_idx + 1];
             nz = sc.world[3 * my_idx + 2];
         }
+#endif
         int rank = 0;  // position of this lane's point in ascending point index
         for (int j = 0; j < L; ++j) rank += (__shfl(my_idx, j, 32) < my_idx) ? 1 : 0;
         const int cnt0 = cnt;
