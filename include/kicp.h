@@ -243,8 +243,6 @@ int kicp_device_synchronize(int device_id);
  *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 1)
  *   "icp_groups"      32-lane groups of each ICP workgroup that take source points (1..16, default 16;
  *                     8 leaves one active wave per SIMD)
- *   "icp_group_lanes" lanes cooperating on one source point in the ICP kernel: 32 (two groups per wave) or
- *                     16 (four groups per wave, association on one wave per SIMD)
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)

@@ -1,4 +1,7 @@
 // Registration.hpp -- mirrors cpp/kiss_icp/core/Registration.hpp:33-45 of PRBonn/kiss-icp v1.2.3.
+// API declarations reproduced from PRBonn/kiss-icp (MIT License, Copyright (c) 2022 Ignacio Vizzo, Tiziano Guadagnino,
+// Benedikt Mersch, Cyrill Stachniss) so that existing callers compile unchanged; the implementation behind them is this
+// repository's own.
 #pragma once
 
 #include <vector>

@@ -1,6 +1,9 @@
 // Threshold.hpp -- mirrors cpp/kiss_icp/core/Threshold.hpp:30-50 and Threshold.cpp:30-49 of
 // PRBonn/kiss-icp v1.2.3.  O(1) host arithmetic per frame (the fused device pipeline keeps its own
 // copy of this state in HBM; this class serves code that composes the stages by hand).
+// API declarations reproduced from PRBonn/kiss-icp (MIT License, Copyright (c) 2022 Ignacio Vizzo, Tiziano Guadagnino,
+// Benedikt Mersch, Cyrill Stachniss) so that existing callers compile unchanged; the implementation behind them is this
+// repository's own.
 #pragma once
 
 #include <cmath>

@@ -1,6 +1,9 @@
 // VoxelHashMap.hpp -- mirrors cpp/kiss_icp/core/VoxelHashMap.hpp:38-57 of PRBonn/kiss-icp v1.2.3.
 // Same constructor and methods; the map itself lives in HBM behind a kicp_map handle
 // (include/kicp.h) instead of a tsl::robin_map member.
+// API declarations reproduced from PRBonn/kiss-icp (MIT License, Copyright (c) 2022 Ignacio Vizzo, Tiziano Guadagnino,
+// Benedikt Mersch, Cyrill Stachniss) so that existing callers compile unchanged; the implementation behind them is this
+// repository's own.
 #pragma once
 
 #include <tuple>

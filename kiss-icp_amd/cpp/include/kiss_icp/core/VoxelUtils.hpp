@@ -1,6 +1,9 @@
 // VoxelUtils.hpp -- mirrors cpp/kiss_icp/core/VoxelUtils.hpp:24-51 of PRBonn/kiss-icp v1.2.3.
 // PointToVoxel and the Voxel hash are plain host arithmetic; VoxelDownsample runs on the GPU
 // (kicp_voxel_downsample, include/kicp.h).
+// API declarations reproduced from PRBonn/kiss-icp (MIT License, Copyright (c) 2022 Ignacio Vizzo, Tiziano Guadagnino,
+// Benedikt Mersch, Cyrill Stachniss) so that existing callers compile unchanged; the implementation behind them is this
+// repository's own.
 #pragma once
 
 #include <cmath>

@@ -4,6 +4,9 @@
 // reference's pybind names `_kitti_seq_error` / `_absolute_trajectory_error`
 // (python/kiss_icp/pybind/kiss_icp_pybind.cpp:141-143) and its Python `metrics.py` keep working on
 // this build.  Nothing here is on the registration path.
+// API declarations reproduced from PRBonn/kiss-icp (MIT License, Copyright (c) 2022 Ignacio Vizzo, Tiziano Guadagnino,
+// Benedikt Mersch, Cyrill Stachniss) so that existing callers compile unchanged; the implementation behind them is this
+// repository's own.
 #pragma once
 
 #include <tuple>

@@ -2,6 +2,9 @@
 // KISSConfig fields and defaults, the same KissICP members (RegisterFrame, Voxelize, LocalMap,
 // VoxelMap, pose, delta).  RegisterFrame runs entirely on the GPU through the fused device pipeline
 // (kicp_pipeline_*, include/kicp.h); only the raw scan goes in and the pose comes out.
+// API declarations reproduced from PRBonn/kiss-icp (MIT License, Copyright (c) 2022 Ignacio Vizzo, Tiziano Guadagnino,
+// Benedikt Mersch, Cyrill Stachniss) so that existing callers compile unchanged; the implementation behind them is this
+// repository's own.
 #pragma once
 
 #include <tuple>

@@ -22,15 +22,7 @@ void set_error(const char *fmt, ...) {
 }
 const char *get_error() { return g_err; }
 Options &options() {
-    static Options o = [] {
-        Options init;
-        // environment overrides, for running an unmodified test-suite against a variant
-        if (const char *e = getenv("KICP_ICP_GROUP_LANES")) {
-            const long v = atol(e);
-            if (v == 16 || v == 32) init.icp_group_lanes = v;
-        }
-        return init;
-    }();
+    static Options o;
     return o;
 }
 
@@ -540,7 +532,7 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
         return KICP_ERR_HIP;
     }
     int s = r->state.reserve(sizeof(PipeState));
-    if (s == KICP_OK && icp_prepare() != 0) {
+    if (s == KICP_OK && icp_prepare(device_id) != 0) {
         set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
         s = KICP_ERR_HIP;
     }
@@ -1106,7 +1098,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     if (s == KICP_OK)
         s = map_create_on_stream(cfg->voxel_size, cfg->max_range, (unsigned)cfg->max_points_per_voxel, device_id,
                                  p->stream, &p->map);
-    if (s == KICP_OK && icp_prepare() != 0) {
+    if (s == KICP_OK && icp_prepare(device_id) != 0) {
         set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
         s = KICP_ERR_HIP;
     }
@@ -1484,9 +1476,6 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_groups")) {
         if (value < 1 || value > kIcpGroupsPerBlock) return KICP_ERR_INVALID_ARG;
         options().icp_groups = value;
-    } else if (!strcmp(name, "icp_group_lanes")) {
-        if (value != 16 && value != 32) return KICP_ERR_INVALID_ARG;
-        options().icp_group_lanes = value;
     } else if (!strcmp(name, "icp_use_lds")) {
         options().icp_use_lds = value;
     } else if (!strcmp(name, "icp_profile")) {

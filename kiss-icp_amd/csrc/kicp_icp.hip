@@ -1,0 +1,528 @@
+// kicp_icp.hip -- k_icp: Registration::AlignPointsToMap (core/Registration.cpp:138-167)
+//   = TransformPoints (:55-58) + DataAssociation (:60-78) + VoxelHashMap::GetClosestNeighbor
+//     (core/VoxelHashMap.cpp:46-70) + BuildLinearSystem (:80-121) + LDLT solve / SE3::exp update
+//     (:156-163), the whole <=500-iteration loop in ONE persistent launch.
+//
+// No MFMA anywhere: the normal equations are a 16-scalar f64 reduction per point (~0.4 flop/byte),
+// not a dense contraction.  The work is HBM/L2-latency bound; what matters is one aligned 16-byte
+// load per hash probe, contiguous voxel blocks, 32 lanes cooperating on each query, wave-level
+// (DPP) + LDS reductions, and no host round trip inside the ICP loop.
+#include <mutex>
+
+#include "kicp_search.hpp"
+
+namespace kicp {
+
+// ------------------------------------------------------------------------------------------
+// k_icp: the whole ICP loop of AlignPointsToMap in one persistent launch
+//
+// grid = G workgroups (all co-resident, G <= 256 = one per CU, each owning its CU's 160 KiB of
+// LDS), 512 threads = 16 groups of 32 lanes.  Per iteration every group walks its points (fixed
+// assignment, so the running transformed source of a point is always re-read by the group that
+// wrote it):
+//   s = est * s            TransformPoints of the previous iteration's estimate (Registration.cpp:159;
+//                          est = initial_guess for the first iteration, :147)
+//   (nn, d) = closest neighbour among the 27 voxels, keep iff d < max_dist (strict, :72).  The
+//             first visit of a voxel neighbourhood copies its candidates into an LDS region
+//             (bump-allocated from the workgroup's pool, exactly E points); as long as the query
+//             stays in the same voxel later iterations scan LDS only.
+//   accumulate the 16 unique scalars of J^T w J and J^T w r with J = [I | -hat(s)], r = s - nn,
+//   w = sigma^2 / (sigma + |r|^2)^2 (:81-98).
+// Workgroup partials are reduced in LDS in a fixed order, published as tagged granules, gathered
+// by EVERY workgroup (one hop, no second broadcast; 26 threads per scalar, each summing a
+// contiguous range of workgroups, then the 26 range sums in order: deterministic), and every
+// workgroup solves the same 6x6 system redundantly on its first four waves:
+// dx = LDLT(JTJ).solve(-JTr), est = exp(dx), T_icp = est * T_icp, stop when |dx| <
+// convergence_criterion (:156-163).
+// ------------------------------------------------------------------------------------------
+struct IcpShared {  // head of the dynamic LDS (kIcpFixedLds bytes with the region records)
+    double part[kIcpGroupsPerBlock][kIcpSums];
+    double range_sum[kIcpParts][kIcpSums];
+    double tot[kIcpSums];
+    double est[8];  // q[4], t[3], |dx|
+    // kept by ONE thread (kIcpBookThread of workgroup 0), off the critical path and out of registers:
+    double T_icp[7];  // accumulated update, q[4] t[3]
+    double guess[7];
+    unsigned long long ncorr_last, ncorr_total, examined_total;
+    double pad2;
+    int fail;
+    int bump;  // doubles handed out from the candidate pool
+    int pad[6];
+    int2 cells[kIcpGroupsPerBlock][64];  // per-group scratch of window_fill
+};
+static_assert(sizeof(IcpShared) + kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) <= kIcpFixedLds,
+              "kIcpFixedLds too small");
+
+// low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
+__device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
+
+template <bool PROF>
+__global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
+    // shift its base off 8/16-byte alignment)
+    IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
+    IcpRegionMeta *metas = reinterpret_cast<IcpRegionMeta *>(smem + sizeof(IcpShared));
+    double *pool = reinterpret_cast<double *>(smem + kIcpFixedLds);
+    constexpr int kPoolDoubles = (int)((kIcpLdsBytes - kIcpFixedLds) / sizeof(double));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kIcpGroup - 1);
+    const int grp = tid / kIcpGroup;
+    const MapView &m = P.map;
+    PipeState *st = P.state;
+
+    const unsigned long long launch_cyc = clock64(), launch_tick = wall_clock64();
+    const int n = count_of(P.n_ptr, P.n_imm);
+    // How many of the launched workgroups take part is decided here, from the actual N_src, so the
+    // summation order (hence the result, bit for bit) never depends on host-side hints.
+    const int groups_used = P.groups_used;  // groups of a workgroup that take source points (experiments: 8 = one wave per SIMD)
+    int G = P.force_blocks > 0 ? P.force_blocks
+                               : (n + groups_used * P.points_per_group - 1) / (groups_used * P.points_per_group);
+    G = max(1, min(G, (int)gridDim.x));
+    if ((int)blockIdx.x >= G) return;
+    const int cached_rounds = (P.use_lds && m.max_points <= 32) ? kIcpMaxCachedRounds : 0;
+    const unsigned epoch_base = st->epoch_base;
+    unsigned t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
+    unsigned gather_passes = 0;
+
+    SE3 guess;
+    double max_dist, ks;
+    if (P.pipeline_mode) {
+        // KissICP.cpp:44-47: sigma = ComputeThreshold(); initial_guess = last_pose * last_delta
+        const double sigma = sqrt(st->model_sse / (double)st->num_samples);
+        guess = se3_mul(st->last_pose, st->last_delta);
+        max_dist = 3.0 * sigma;
+        ks = sigma;
+    } else {
+        guess = st->guess;
+        max_dist = P.max_dist;
+        ks = P.kernel_scale;
+    }
+    const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143
+    const double inv_voxel = 1.0 / m.voxel_size;
+
+    if (tid == 0) {
+        sh.fail = 0;
+        sh.bump = 0;
+        const SE3 id = se3_identity();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sh.T_icp[i] = id.q[i];
+            sh.guess[i] = guess.q[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sh.T_icp[4 + i] = id.t[i];
+            sh.guess[4 + i] = guess.t[i];
+        }
+        sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
+    }
+    if (tid < kIcpMaxCachedRounds * kIcpGroupsPerBlock) {
+        metas[tid].valid = 0;
+        metas[tid].cap = 0;
+        metas[tid].base = 0;
+        metas[tid].E = 0;
+    }
+    __syncthreads();
+
+    SE3 est = guess;
+    int iterations = 0, converged = 0;
+    int range_err = 0;
+    bool failed = false;
+
+    const int max_iters = map_empty ? 0 : P.max_iters;
+    for (int it = 0; it < max_iters; ++it) {
+        const unsigned c0 = PROF ? ticks32() : 0u;
+        double acc[kIcpSums];
+#pragma unroll
+        for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
+        // consecutive source points (neighbours in the scan, hence similar neighbourhood sizes) go to
+        // different workgroups: point p belongs to workgroup p % G, group (p / G) % 16
+        int round = 0;
+        for (int p = (grp < groups_used) ? (int)blockIdx.x + G * grp : n; p < n; p += G * groups_used, ++round) {
+            const bool has_meta = round < cached_rounds;
+            IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
+            const unsigned ta = PROF ? ticks32() : 0u;
+            double pin[3];
+            if (it > 0 && has_meta) {  // running source point lives in LDS
+                pin[0] = meta->s[0];
+                pin[1] = meta->s[1];
+                pin[2] = meta->s[2];
+            } else {
+                const double *src = (it == 0) ? P.frame : P.work;
+                pin[0] = src[3 * p];
+                pin[1] = src[3 * p + 1];
+                pin[2] = src[3 * p + 2];
+            }
+            double s[3];
+            se3_act(est, pin, s);
+            const int vx = voxel_coord_fast(s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(s[1], m.voxel_size, inv_voxel),
+                      vz = voxel_coord_fast(s[2], m.voxel_size, inv_voxel);
+            const int v[3] = {vx, vy, vz};
+            bool cached = false;
+            if (has_meta && meta->valid)  // is the 27-neighbourhood of (vx, vy, vz) inside the staged window?
+                cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
+                         meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
+                         meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
+            if (lane == 0) {
+                if (has_meta) {
+                    meta->s[0] = s[0];
+                    meta->s[1] = s[1];
+                    meta->s[2] = s[2];
+                } else {
+                    P.work[3 * p] = s[0];
+                    P.work[3 * p + 1] = s[1];
+                    P.work[3 * p + 2] = s[2];
+                }
+            }
+            int path = cached ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
+            const unsigned tb = PROF ? ticks32() : 0u;
+            if (!cached && has_meta && meta->cap >= 0) {
+                cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
+                if (cached) path = 2;
+            }
+            const unsigned tc = PROF ? ticks32() : 0u;
+            double nn[3];
+            double d2;
+            int E;
+            if (cached) {
+                WindowGeom g;
+                g.lo0 = meta->lo[0];
+                g.lo1 = meta->lo[1];
+                g.lo2 = meta->lo[2];
+                const int n0 = meta->hi[0] - g.lo0 + 1;
+                g.n1 = meta->hi[1] - g.lo1 + 1;
+                g.n2 = meta->hi[2] - g.lo2 + 1;
+                g.dx = vx - meta->v[0];
+                g.dy = vy - meta->v[1];
+                g.dz = vz - meta->v[2];
+                const int W = n0 * g.n1 * g.n2;
+                // one code path for exact and widened windows: the two groups of a wave would otherwise
+                // run their scans one after the other whenever they differ
+                d2 = scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
+                if (path == 0 && W != 27) path = 1;
+            } else {
+                const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
+                E = pr.E;
+                d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
+                                         : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
+            }
+            const unsigned td = PROF ? ticks32() : 0u;
+            if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && round == 0) {
+                // per-group record of this iteration (10 ns ticks): where the group's time went
+                unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
+                                               (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+                r[0] = (unsigned)(ta - c0) | ((unsigned)(tb - ta) << 16);   // wait-in, transform + window test
+                r[1] = (unsigned)(tc - tb) | ((unsigned)(td - tc) << 16);   // window fill, scan
+                r[2] = (unsigned)(has_meta ? meta->E : 0) | ((unsigned)E << 16);  // staged points, examined
+                r[3] = (unsigned)path;
+            }
+            if (lane == 0) {
+                acc[17] += (double)E;
+                if (d2 < DBL_MAX && sqrt(d2) < max_dist) {
+                    const double rx = s[0] - nn[0], ry = s[1] - nn[1], rz = s[2] - nn[2];
+                    const double r2 = (rx * rx + ry * ry) + rz * rz;
+                    const double w = (ks * ks) / ((ks + r2) * (ks + r2));
+                    acc[0] += w;
+                    acc[1] += w * s[0];
+                    acc[2] += w * s[1];
+                    acc[3] += w * s[2];
+                    // w * hat(s)^T hat(s) = w * (|s|^2 I - s s^T), upper triangle
+                    acc[4] += w * (s[1] * s[1] + s[2] * s[2]);
+                    acc[5] += w * (-(s[0] * s[1]));
+                    acc[6] += w * (-(s[0] * s[2]));
+                    acc[7] += w * (s[0] * s[0] + s[2] * s[2]);
+                    acc[8] += w * (-(s[1] * s[2]));
+                    acc[9] += w * (s[0] * s[0] + s[1] * s[1]);
+                    acc[10] += w * rx;
+                    acc[11] += w * ry;
+                    acc[12] += w * rz;
+                    // w * (s x r)
+                    acc[13] += w * (s[1] * rz - s[2] * ry);
+                    acc[14] += w * (s[2] * rx - s[0] * rz);
+                    acc[15] += w * (s[0] * ry - s[1] * rx);
+                    acc[16] += 1.0;
+                }
+            }
+        }
+        // ---- workgroup reduction (fixed order) ----------------------------------------------
+        const unsigned c1 = PROF ? ticks32() : 0u;
+        acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kIcpSums; ++k) sh.part[grp][k] = acc[k];
+        }
+        __syncthreads();
+        const unsigned epoch = epoch_base + (unsigned)it + 1u;
+        unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpSums);
+        if (tid < 2 * kIcpSums) {
+            const int k = tid >> 1;
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < kIcpGroupsPerBlock; ++g) {
+                const double pv = sh.part[g][k];
+                v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+            }
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
+        }
+        // ---- gather every workgroup's partial (bounded spin) --------------------------------
+        const unsigned c2 = PROF ? ticks32() : 0u;
+        if (tid < kIcpParts * kIcpSums) {
+            // thread (k, part) sums scalar k over a contiguous range of workgroups, in order.  All the
+            // granules of the range (up to kGatherChunk workgroups x 2) are in flight together; every
+            // further pass re-polls, again together, exactly the ones whose tag has not arrived yet:
+            // one memory round trip per pass, however many granules are late.
+            constexpr int kGatherChunk = 10;  // >= ceil(256 / kIcpParts): one chunk per thread for any grid
+            const int k = tid % kIcpSums, part = tid / kIcpSums;
+            const int b0 = (G * part) / kIcpParts, b1 = (G * (part + 1)) / kIcpParts;
+            double v = 0.0;
+            bool fail = false;
+            for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
+                unsigned long long lo[kGatherChunk], hi[kGatherChunk];
+                const unsigned long long *g0 = gran + ((size_t)b * kIcpSums + k) * 2;
+                unsigned pending = 0;
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u) {
+                    lo[u] = hi[u] = 0ull;
+                    if (b + u < b1) {
+                        lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
+                        hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                        pending |= 1u << u;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u)
+                    if ((unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch) pending &= ~(1u << u);
+                unsigned spins = 0;
+                while (pending) {
+                    if (PROF) ++gather_passes;
+                    if (++spins > P.spin_limit ||
+                        ((spins & 255u) == 0 &&
+                         (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
+                        fail = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u)
+                        if ((pending >> u) & 1u) {
+                            lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
+                            hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                        }
+#pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u)
+                        if (((pending >> u) & 1u) && (unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch)
+                            pending &= ~(1u << u);
+                }
+                if (fail) break;
+#pragma unroll
+                for (int u = 0; u < kGatherChunk; ++u)
+                    if (b + u < b1) {
+                        const double pv = __longlong_as_double(
+                            (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
+                        v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+                    }
+            }
+            sh.range_sum[part][k] = v;
+            if (fail) sh.fail = 1;
+        }
+        __syncthreads();
+        if (sh.fail) {
+            failed = true;
+            break;
+        }
+        if (tid < kIcpSums) {
+            double v = 0.0;
+#pragma unroll
+            for (int part = 0; part < kIcpParts; ++part) {
+                const double pv = sh.range_sum[part][tid];
+                v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+            }
+            sh.tot[tid] = v;
+        }
+        __syncthreads();
+        // ---- waves 0..3 (one per SIMD) solve the same system; the result goes through LDS -----
+        const unsigned c3 = PROF ? ticks32() : 0u;
+        double nrm2 = 0.0;
+        if (tid < kIcpSolveThreads) {
+            double S[kIcpSums];
+#pragma unroll
+            for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
+            double JTJ[36], nb[6], dx[6];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+            JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+            // top-right block sum w * (-hat(s)) and its transpose
+            JTJ[0 * 6 + 4] = S[3];
+            JTJ[0 * 6 + 5] = -S[2];
+            JTJ[1 * 6 + 3] = -S[3];
+            JTJ[1 * 6 + 5] = S[1];
+            JTJ[2 * 6 + 3] = S[2];
+            JTJ[2 * 6 + 4] = -S[1];
+            JTJ[4 * 6 + 0] = S[3];
+            JTJ[5 * 6 + 0] = -S[2];
+            JTJ[3 * 6 + 1] = -S[3];
+            JTJ[5 * 6 + 1] = S[1];
+            JTJ[3 * 6 + 2] = S[2];
+            JTJ[4 * 6 + 2] = -S[1];
+            JTJ[3 * 6 + 3] = S[4];
+            JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+            JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+            JTJ[4 * 6 + 4] = S[7];
+            JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+            JTJ[5 * 6 + 5] = S[9];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+            ldlt6_solve(JTJ, nb, dx);
+            est = se3_exp(dx);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
+            if (tid == 0) {
+                sh.est[0] = est.q[0];
+                sh.est[1] = est.q[1];
+                sh.est[2] = est.q[2];
+                sh.est[3] = est.q[3];
+                sh.est[4] = est.t[0];
+                sh.est[5] = est.t[1];
+                sh.est[6] = est.t[2];
+                sh.est[7] = nrm2;
+            }
+        }
+        __syncthreads();
+        if (tid >= kIcpSolveThreads) {
+            est.q[0] = sh.est[0];
+            est.q[1] = sh.est[1];
+            est.q[2] = sh.est[2];
+            est.q[3] = sh.est[3];
+            est.t[0] = sh.est[4];
+            est.t[1] = sh.est[5];
+            est.t[2] = sh.est[6];
+            nrm2 = sh.est[7];
+        }
+        if (blockIdx.x == 0 && tid == kIcpBookThread) {
+            // T_icp = est * T_icp (Registration.cpp:161) and the statistics, by a thread whose wave is
+            // not on the critical path; sh.tot stays valid until the next gather
+            SE3 T;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T.q[i] = sh.T_icp[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T.t[i] = sh.T_icp[4 + i];
+            T = se3_mul(est, T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh.T_icp[i] = T.q[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sh.T_icp[4 + i] = T.t[i];
+            const unsigned long long nc = (unsigned long long)sh.tot[16];
+            sh.ncorr_last = nc;
+            sh.ncorr_total += nc;
+            sh.examined_total += (unsigned long long)sh.tot[17];
+        }
+        iterations = it + 1;
+        if (it == 0 && blockIdx.x == 0 && tid == 0) st->prof_it0_ticks = wall_clock64() - launch_tick;
+        const unsigned c4 = PROF ? ticks32() : 0u;
+        t_assoc += c1 - c0;
+        t_publish += c2 - c1;
+        t_gather += c3 - c2;
+        t_solve += c4 - c3;
+        if (PROF && blockIdx.x == 0 && tid == 0 && it < kIcpProfIters) {
+            unsigned *r = st->prof_iter[it];
+            r[0] = (unsigned)(c1 - c0);
+            r[1] = (unsigned)(c2 - c1);
+            r[2] = (unsigned)(c3 - c2);
+            r[3] = (unsigned)(c4 - c3);
+            r[4] = (unsigned)sh.tot[kIcpTickSlot];  // slowest group's association time, any workgroup
+            r[5] = gather_passes;
+        }
+        gather_passes = 0;
+        if (sqrt(nrm2) < P.conv) {
+            converged = 1;
+            break;
+        }
+    }
+
+    if (range_err) atomicOr(&st->err, E_RANGE);
+    if (failed && tid == 0) atomicOr(&st->err, E_TIMEOUT);
+
+    __syncthreads();  // the bookkeeping thread's last update is in LDS
+    if (blockIdx.x == 0 && tid == 0) {
+        SE3 T_icp, guess;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T_icp.q[i] = sh.T_icp[i];
+            guess.q[i] = sh.guess[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T_icp.t[i] = sh.T_icp[4 + i];
+            guess.t[i] = sh.guess[4 + i];
+        }
+        const unsigned long long examined_total = sh.examined_total, ncorr_last = sh.ncorr_last,
+                                 ncorr_total = sh.ncorr_total;
+        const SE3 new_pose = se3_mul(T_icp, guess);  // Registration.cpp:166
+        st->new_pose = new_pose;
+        st->guess = guess;
+        st->icp_iterations = iterations;
+        st->icp_converged = converged;
+        st->icp_examined = examined_total;
+        st->icp_ncorr_last = ncorr_last;
+        st->icp_ncorr_total = ncorr_total;
+        st->n_src = n;
+        if (P.prep) {
+            st->n_pre = P.prep->n_pre;
+            st->n_fd = P.prep->n_fd;
+        }
+        st->icp_blocks_used = G;
+        st->prof[0] = t_assoc;
+        st->prof[1] = t_publish;
+        st->prof[2] = t_gather;
+        st->prof[3] = t_solve;
+        st->prof_clock[0] = clock64() - launch_cyc;
+        st->prof_clock[1] = wall_clock64() - launch_tick;
+        st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
+        if (P.pipeline_mode) {
+            st->sigma = ks;
+            // KissICP.cpp:57-63 + Threshold.cpp:38-49
+            const SE3 dev = se3_mul(se3_inverse(guess), new_pose);
+            const double theta = rotation_angle(dev.q);
+            const double delta_rot = 2.0 * m.max_distance * sin(theta / 2.0);
+            const double delta_trans = sqrt(sqnorm3(dev.t[0], dev.t[1], dev.t[2]));
+            const double model_error = delta_trans + delta_rot;
+            if (model_error > P.min_motion_th) {
+                st->model_sse += model_error * model_error;
+                st->num_samples += 1;
+            }
+            st->last_delta = se3_mul(se3_inverse(st->last_pose), new_pose);
+            st->last_pose = new_pose;
+        }
+    }
+}
+
+size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums; }
+
+int icp_prepare(int device_id) {
+    // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute), once per
+    // device: the attribute belongs to the device's copy of the code object
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device_id < 0 || device_id >= 64) return (int)hipErrorInvalidDevice;
+    if (done[device_id]) return 0;
+    const void *kernels[2] = {reinterpret_cast<const void *>(k_icp<false>), reinterpret_cast<const void *>(k_icp<true>)};
+    for (const void *k : kernels) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    done[device_id] = true;
+    return 0;
+}
+void launch_icp(IcpParams P, int G, bool profile, hipStream_t s) {
+    if (profile)
+        hipLaunchKernelGGL((k_icp<true>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+    else
+        hipLaunchKernelGGL((k_icp<false>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+}
+
+}  // namespace kicp

@@ -232,7 +232,6 @@ struct Options {
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
     long icp_groups = 16;        // groups per workgroup that take source points
-    long icp_group_lanes = 32;   // lanes cooperating on one source point: 32 or 16
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
 };
 Options &options();

@@ -49,7 +49,7 @@ struct DsParams {
     int *err;
 };
 
-int icp_prepare();
+int icp_prepare(int device_id);
 size_t icp_granule_words(int G);
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,

@@ -239,9 +239,6 @@ KICP_HD void mat3_mul(const double A[9], const double B[9], double C[9]) {
 
 // Sophus SE3::exp, a = (upsilon, omega)
 KICP_HD SE3 se3_exp(const double a[6]) {
-#ifdef KICP_CONTRACT_SOLVE
-#pragma clang fp contract(fast)  // see ldlt6_solve
-#endif
     SE3 out;
     const double w[3] = {a[3], a[4], a[5]};
     const double theta_sq = sqnorm3(w[0], w[1], w[2]);
@@ -332,11 +329,6 @@ KICP_HD double rotation_angle(const double q_in[4]) {
 // pivots with |D_i| <= DBL_MIN give a zero component.  Fully unrolled with compile-time
 // indices (swaps are done by predicated selects) so it stays in registers on the device.
 KICP_HD void ldlt6_solve(const double A[36], const double b[6], double x[6]) {
-#ifdef KICP_CONTRACT_SOLVE
-    // experiment: fused multiply-adds in the 6x6 solve only (nothing here decides a voxel or a
-    // neighbour; the result moves by an ulp or so)
-#pragma clang fp contract(fast)
-#endif
     constexpr int N = 6;
     double m[N][N];
     double d[N];
@@ -409,15 +401,8 @@ KICP_HD void ldlt6_solve(const double A[36], const double b[6], double x[6]) {
         }
         const double akk = m[k][k];
         if (fabs(akk) > 0.0) {
-#ifdef KICP_LDLT_RECIP
-            // experiment: one divide per pivot instead of N-k-1 (each quotient moves by <= 1 ulp)
-            const double rk = 1.0 / akk;
-#pragma unroll
-            for (int i = k + 1; i < N; ++i) m[i][k] *= rk;
-#else
 #pragma unroll
             for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
-#endif
         }
     }
     // dst = P b

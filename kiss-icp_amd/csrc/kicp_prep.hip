@@ -1,0 +1,332 @@
+// kicp_prep.hip -- the stages in front of the registration, as order-preserving compactions:
+//   k_ts_minmax, k_pre_*   Preprocessor::Preprocess   core/Preprocessing.cpp:55-95
+//   k_ds_*                 VoxelDownsample            core/VoxelUtils.cpp:7-21
+#include "kicp_launch.hpp"
+
+namespace kicp {
+
+__device__ __forceinline__ int count_of(const int *n_ptr, int n_imm) { return n_ptr ? *n_ptr : n_imm; }
+
+static inline int grid_for(long n, int threads, int cap) {
+    long g = (n + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// order-preserving compaction helpers (1024-thread workgroups, one element per thread)
+// ------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+
+// exclusive position of this thread's flag inside the workgroup + workgroup total
+__device__ __forceinline__ int block_exclusive_scan(bool flag, int &total) {
+    __shared__ int wave_tot[kScanThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long ball = __ballot(flag);
+    const int before = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(ball);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        const int c = wave_tot[w];
+        off += (w < wave) ? c : 0;
+        tot += c;
+    }
+    __syncthreads();
+    total = tot;
+    return off + before;
+}
+
+// sum of counts[0 .. blockIdx.x) -- every workgroup recomputes its own base (counts are few)
+__device__ __forceinline__ int block_base(const int *counts, int *grand_total) {
+    __shared__ int sh_base, sh_all;
+    if (threadIdx.x < 64) {
+        int b = 0, a = 0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) {
+            const int c = counts[i];
+            a += c;
+            if (i < (int)blockIdx.x) b += c;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            b += __shfl_xor(b, off, 64);
+            a += __shfl_xor(a, off, 64);
+        }
+        if (threadIdx.x == 0) {
+            sh_base = b;
+            sh_all = a;
+        }
+    }
+    __syncthreads();
+    if (grand_total) *grand_total = sh_all;
+    return sh_base;
+}
+
+__device__ __forceinline__ unsigned long long f64_order_bits(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_from_order_bits(unsigned long long o) {
+    const unsigned long long b = (o & 0x8000000000000000ull) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o;
+    return __longlong_as_double((long long)b);
+}
+
+// ---- Preprocess ---------------------------------------------------------------------------
+// min / max of the timestamps (Preprocessing.cpp:62)
+__global__ __launch_bounds__(256) void k_ts_minmax(const double *ts, int n_ts, PrepState *st) {
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ts; i += gridDim.x * blockDim.x) {
+        const unsigned long long o = f64_order_bits(ts[i]);
+        lo = o < lo ? o : lo;
+        hi = o > hi ? o : hi;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&st->tmin_bits, lo);
+        atomicMax(&st->tmax_bits, hi);
+    }
+}
+
+// deskew (Preprocessing.cpp:59-84) into tmp[], range test (:86-92), workgroup counts
+__global__ __launch_bounds__(kScanThreads) void k_pre_flags(PreParams P) {
+    const int n = P.n;
+    const int i = blockIdx.x * kScanThreads + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        double p[3] = {P.xyz[3 * i], P.xyz[3 * i + 1], P.xyz[3 * i + 2]};
+        if (P.deskew) {
+            const double mn = f64_from_order_bits(P.prep->tmin_bits);
+            const double mx = f64_from_order_bits(P.prep->tmax_bits);
+            double omega[6];
+            se3_log(P.use_state_motion ? P.state->last_delta : P.motion, omega);
+            const double stamp = (P.ts[i] - mn) / (mx - mn);
+            double a[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a[k] = (stamp - 1.0) * omega[k];
+            const SE3 pose = se3_exp(a);
+            double o[3];
+            se3_act(pose, p, o);
+            p[0] = o[0];
+            p[1] = o[1];
+            p[2] = o[2];
+        }
+        P.tmp[3 * i] = p[0];
+        P.tmp[3 * i + 1] = p[1];
+        P.tmp[3 * i + 2] = p[2];
+        const double r = sqrt(sqnorm3(p[0], p[1], p[2]));
+        keep = (r < P.max_range) && (r > P.min_range);
+    }
+    int total;
+    block_exclusive_scan(keep, total);
+    if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = total;
+}
+
+// find-or-claim the slot of a voxel in the downsample scratch table
+__device__ __forceinline__ int ds_claim(DsSlot *tab, uint32_t mask, unsigned long long key) {
+    // Read before CAS: ~15 scan points share a voxel, so most arrivals find their key already
+    // there and never touch the atomic unit.  Keys are stable for the lifetime of a claim phase,
+    // so a (possibly L1-stale) plain read can only cost an extra CAS, never a wrong answer.
+    uint32_t s = hash_key(key, mask);
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        unsigned long long cur = tab[s].key;
+        if (cur == kKeyEmpty) cur = atomicCAS(&tab[s].key, kKeyEmpty, key);
+        if (cur == kKeyEmpty || cur == key) return (int)s;
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+// atomicMin that skips the atomic when a plain read already shows a smaller index (the stored
+// index only ever decreases, so a stale read can only cause a redundant atomic)
+__device__ __forceinline__ void ds_min_index(DsSlot *tab, int s, int idx) {
+    if (tab[s].minidx > idx) atomicMin(&tab[s].minidx, idx);
+}
+
+// Workgroup-level aggregation of downsample claims: the (up to 1024) points of a workgroup are
+// consecutive in the scan, so most of them share a voxel with a neighbour.  They first meet in a
+// small LDS hash (LDS atomics: no HBM traffic, no cross-XCD contention); only one claim and one
+// atomicMin per DISTINCT voxel of the workgroup then go to the table in HBM.
+constexpr int kAggSlots = 2048;
+struct ClaimAgg {
+    unsigned long long key[kAggSlots];
+    int minidx[kAggSlots];
+    int slot[kAggSlots];
+};
+
+// all kScanThreads threads call this; returns the table slot of this thread's voxel (-1: none)
+__device__ __forceinline__ int ds_claim_aggregated(ClaimAgg &agg, DsSlot *tab, uint32_t mask, bool valid,
+                                                   unsigned long long key, int idx, int *err) {
+    for (int e = threadIdx.x; e < kAggSlots; e += kScanThreads) {
+        agg.key[e] = kKeyEmpty;
+        agg.minidx[e] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    int ls = -1;
+    if (valid) {
+        uint32_t h = hash_key(key, kAggSlots - 1);
+        for (int probes = 0; probes < kAggSlots; ++probes) {
+            unsigned long long cur = agg.key[h];
+            if (cur == kKeyEmpty) cur = atomicCAS(&agg.key[h], kKeyEmpty, key);
+            if (cur == kKeyEmpty || cur == key) {
+                ls = (int)h;
+                break;
+            }
+            h = (h + 1) & (kAggSlots - 1);
+        }
+        atomicMin(&agg.minidx[ls], idx);  // 1024 points never fill 2048 slots: ls >= 0
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAggSlots; e += kScanThreads) {
+        const unsigned long long k = agg.key[e];
+        if (k == kKeyEmpty) continue;
+        const int s = ds_claim(tab, mask, k);
+        if (s >= 0) ds_min_index(tab, s, agg.minidx[e]);
+        else atomicOr(err, E_TABLE_FULL);
+        agg.slot[e] = s;
+    }
+    __syncthreads();
+    return valid ? agg.slot[ls] : -1;
+}
+
+// scatter the range-cropped cloud (order preserving) and, fused, stage A of the first
+// VoxelDownsample: claim the voxel and atomicMin the (new) point index into it
+__global__ __launch_bounds__(kScanThreads) void k_pre_scatter(PreParams P) {
+    __shared__ ClaimAgg agg;
+    const int n = P.n;
+    const int i = blockIdx.x * kScanThreads + threadIdx.x;
+    bool keep = false;
+    double p[3] = {0, 0, 0};
+    if (i < n) {
+        p[0] = P.tmp[3 * i];
+        p[1] = P.tmp[3 * i + 1];
+        p[2] = P.tmp[3 * i + 2];
+        const double r = sqrt(sqnorm3(p[0], p[1], p[2]));
+        keep = (r < P.max_range) && (r > P.min_range);
+    }
+    int total, grand;
+    const int base = block_base(P.blk_counts, &grand);
+    const int j = base + block_exclusive_scan(keep, total);
+    if (keep) {
+        P.out[3 * j] = p[0];
+        P.out[3 * j + 1] = p[1];
+        P.out[3 * j + 2] = p[2];
+    }
+    if (P.ds_tab) {
+        bool valid = false;
+        unsigned long long key = 0;
+        if (keep) {
+            const int vx = voxel_coord(p[0], P.ds_voxel), vy = voxel_coord(p[1], P.ds_voxel),
+                      vz = voxel_coord(p[2], P.ds_voxel);
+            valid = voxel_in_range(vx, vy, vz);
+            if (valid) key = pack_voxel(vx, vy, vz);
+            else atomicOr(P.err, E_RANGE);
+        }
+        const int s = ds_claim_aggregated(agg, P.ds_tab, P.ds_mask, valid, key, j, P.err);
+        if (keep) P.ds_slot_of[j] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *P.n_out = grand;
+        if (P.prep) {  // k_pre_flags (the only reader) is done: re-arm the timestamp words
+            P.prep->tmin_bits = ~0ull;
+            P.prep->tmax_bits = 0ull;
+        }
+    }
+}
+
+// ---- VoxelDownsample ----------------------------------------------------------------------
+// stage A standalone (when the input is not produced by a fused scatter)
+__global__ __launch_bounds__(256) void k_ds_claim(DsParams P) {
+    const int n = count_of(P.n_ptr, P.n_imm);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int vx = voxel_coord(P.in[3 * i], P.voxel), vy = voxel_coord(P.in[3 * i + 1], P.voxel),
+                  vz = voxel_coord(P.in[3 * i + 2], P.voxel);
+        int s = -1;
+        if (voxel_in_range(vx, vy, vz)) {
+            s = ds_claim(P.tab, P.mask, pack_voxel(vx, vy, vz));
+            if (s >= 0) ds_min_index(P.tab, s, i);
+            else atomicOr(P.err, E_TABLE_FULL);
+        } else {
+            atomicOr(P.err, E_RANGE);
+        }
+        P.slot_of[i] = s;
+    }
+}
+
+// stage B: a point survives iff it is the first (lowest index) of its voxel
+__global__ __launch_bounds__(kScanThreads) void k_ds_flags(DsParams P) {
+    const int n = count_of(P.n_ptr, P.n_imm);
+    const int i = blockIdx.x * kScanThreads + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        const int s = P.slot_of[i];
+        keep = (s >= 0) && (P.tab[s].minidx == i);
+    }
+    int total;
+    block_exclusive_scan(keep, total);
+    if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = total;
+}
+
+// stage C: scatter in ascending original index, wipe the scratch slot, and (fused) stage A of the
+// next downsample on the surviving point
+__global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
+    const int n = count_of(P.n_ptr, P.n_imm);
+    const int i = blockIdx.x * kScanThreads + threadIdx.x;
+    bool keep = false;
+    int s = -1;
+    if (i < n) {
+        s = P.slot_of[i];
+        keep = (s >= 0) && (P.tab[s].minidx == i);
+    }
+    int total, grand;
+    const int base = block_base(P.blk_counts, &grand);
+    const int j = base + block_exclusive_scan(keep, total);
+    if (keep) {
+        const double x = P.in[3 * i], y = P.in[3 * i + 1], z = P.in[3 * i + 2];
+        P.out[3 * j] = x;
+        P.out[3 * j + 1] = y;
+        P.out[3 * j + 2] = z;
+        P.tab[s].key = kKeyEmpty;  // each claimed slot has exactly one winner: self-cleaning
+        P.tab[s].minidx = 0x7FFFFFFF;
+        if (P.next_tab) {
+            const int vx = voxel_coord(x, P.next_voxel), vy = voxel_coord(y, P.next_voxel),
+                      vz = voxel_coord(z, P.next_voxel);
+            int s2 = -1;
+            if (voxel_in_range(vx, vy, vz)) {
+                s2 = ds_claim(P.next_tab, P.next_mask, pack_voxel(vx, vy, vz));
+                if (s2 >= 0) ds_min_index(P.next_tab, s2, j);
+                else atomicOr(P.err, E_TABLE_FULL);
+            } else {
+                atomicOr(P.err, E_RANGE);
+            }
+            P.next_slot_of[j] = s2;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.n_out = grand;
+}
+
+void launch_ts_minmax(const double *ts, int n_ts, PrepState *st, hipStream_t s) {
+    hipLaunchKernelGGL(k_ts_minmax, dim3(grid_for(n_ts, 256, 512)), dim3(256), 0, s, ts, n_ts, st);
+}
+void launch_pre_flags(const PreParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_pre_flags, dim3(grid_for(P.n, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
+}
+void launch_pre_scatter(const PreParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_pre_scatter, dim3(grid_for(P.n, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
+}
+void launch_ds_claim(const DsParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_ds_claim, dim3(grid_for(P.n_max, 256, 2048)), dim3(256), 0, s, P);
+}
+void launch_ds_flags(const DsParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_ds_flags, dim3(grid_for(P.n_max, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
+}
+void launch_ds_scatter(const DsParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_ds_scatter, dim3(grid_for(P.n_max, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
+}
+
+}  // namespace kicp

@@ -242,35 +242,6 @@ def test_align_exact_ties_follow_the_reference_order(gpu, O, offset):
             assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
 
 
-def test_icp_16_lane_groups_are_bitwise_identical(gpu, O):
-    """the 16-lane-group variant of the ICP kernel ("icp_group_lanes") assigns points to workgroups
-    and groups exactly like the 32-lane one, picks the same neighbours and sums in the same order"""
-    from kiss_icp_amd import _cabi
-    from kiss_icp_amd.registration import Registration
-
-    rng = np.random.default_rng(41)
-    g, o = _maps(O)
-    world = _scene(rng, 8000)
-    g.add_points(world)
-    o.add_points(world)
-    src = _scene(np.random.default_rng(42), 2500)
-    guess = make_pose((0.3, -0.2, 0.05), (0.002, 0.001, 0.015))
-    out = {}
-    try:
-        for lanes in (32, 16):
-            _cabi.set_option("icp_group_lanes", lanes)
-            r = Registration(500, 1e-4)
-            out[lanes] = (r.align_points_to_map(src, g, guess, 3.0, 1.0), dict(r.last_stats))
-    finally:
-        _cabi.set_option("icp_group_lanes", 32)
-    assert np.array_equal(out[32][0], out[16][0])
-    for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
-        assert out[32][1][k] == out[16][1][k], k
-    To = O.Registration(500, 1e-4).align_points_to_map(src, o, guess, 3.0, 1.0)
-    dt, dr = pose_error(To, out[16][0])
-    assert dt < TIGHT and dr < TIGHT
-
-
 def test_align_degenerate_cases(gpu, O):
     from kiss_icp_amd.registration import Registration
 
