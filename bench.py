@@ -6,13 +6,21 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one RegisterFrame (cpp/kiss_icp/pipeline/KissICP.cpp:35-68) of one scan: deskew/crop,
-two voxel downsamples, the ICP loop against the local map, map update -- all on the GPU, with the
-scans already resident in HBM when the timed region starts.  One process per GPU; rank r runs its own
-synthetic sequence (weak scaling: BASELINE config 4, one stream per GPU) and the ranks all-gather
-their poses over RCCL once per batch.  Rank 0 prints ONE JSON line.
+two voxel downsamples, the ICP loop against the local map, map update -- all on the GPU.
 
-Workload (BASELINE.json configs[1]): KITTI-like HDL-64, 64 x 2048 = 131 072 rays per scan,
-voxel_size 1.0 m, max_range 100 m, no timestamps (python/kiss_icp/datasets/kitti.py:57).
+`value` is measured on the DROP-IN path: every scan starts in pageable HOST memory as a float64 (N,3)
+numpy array (what the reference's dataloaders hand to register_frame, python/kiss_icp/pipeline.py:100-103)
+and goes through kicp_pipeline_register_frame_async (include/kicp.h): staged into pinned memory, uploaded
+under the previous frame's registration, queued.  The device-resident rate (scans already in HBM, which
+the task statement names as the whole-job figure) and the fully synchronous RegisterFrame that also returns
+its two clouds are reported beside it under their own keys (`device_resident`, `sync_with_outputs`).
+
+One process per GPU; rank r runs its own synthetic sequence (weak scaling: BASELINE config 4, one stream
+per GPU) and the ranks all-gather their poses over RCCL once per batch.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): KITTI-like HDL-64, 64 x 2048 = 131 072 rays per scan, voxel_size
+1.0 m, max_range 100 m, no timestamps (python/kiss_icp/datasets/kitti.py:57), on the vegetated street scene
+SURVEY.md section 8(d) specifies (source cloud 4-4.5 k points); 200 timed frames after 10 warm-up frames.
 """
 import argparse
 import json
@@ -31,37 +39,40 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="kitti", choices=["kitti", "mulran", "livox"])
+    ap.add_argument("--workload", default="kitti", choices=["kitti", "kitti-street", "mulran", "livox"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--icp-blocks", type=int, default=0)
-    ap.add_argument("--icp-ppg", type=int, default=0, help="icp_points_per_group option")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (device-resident, f32, synchronous)")
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option (kicp_set_option)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--device", type=int, default=-1, help="force this device for every rank (plumbing tests on a 1-GPU box)")
+    ap.add_argument("--gen-procs", type=int, default=0, help="processes generating the synthetic scans (0 = by core count)")
     return ap.parse_args()
 
 
-def make_dataset(workload, seed, n_frames):
-    from kiss_icp_amd.datasets import kitti_like, livox_like, mulran_like
+def workload(name):
+    """(dataset factory, its keyword arguments, KISSConfig overrides, description)"""
+    from kiss_icp_amd.datasets import kitti_like, kitti_like_vegetated, livox_like, mulran_like
 
-    if workload == "kitti":
-        return kitti_like(seed=seed, n_frames=n_frames), dict(deskew=False), "kitti-like HDL-64 64x2048 rays, voxel 1.0 m"
-    if workload == "mulran":
-        return mulran_like(seed=seed, n_frames=n_frames), dict(deskew=True), "mulran-like OS1-64 64x1024 rays, deskew, voxel 1.0 m"
-    return livox_like(seed=seed, n_frames=n_frames), dict(deskew=False, voxel_size=0.1), "1M-pt 128x8192 rays, voxel 0.1 m"
+    if name == "kitti":
+        return kitti_like_vegetated, {}, dict(deskew=False), "kitti-like HDL-64 64x2048 rays, vegetated street (SURVEY 8d), voxel 1.0 m"
+    if name == "kitti-street":  # round 1's light scene
+        return kitti_like, {}, dict(deskew=False), "kitti-like HDL-64 64x2048 rays, bare street, voxel 1.0 m"
+    if name == "mulran":
+        return mulran_like, {}, dict(deskew=True), "mulran-like OS1-64 64x1024 rays, deskew, voxel 1.0 m"
+    return livox_like, {}, dict(deskew=False, voxel_size=0.1), "1M-pt 128x8192 rays, voxel 0.1 m"
 
 
-def pmc_traffic(workload):
+def pmc_traffic(name):
     """HBM bytes per k_icp launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
     passes over this same command, corrected as calibrated on a known-size copy; scripts/pmc_to_json.py
-    writes the file, scripts/gpu_final.sh collects the counters).  PMC collection cannot run inside
-    the timed bench itself, so this is the committed measurement of the round -- or None."""
+    writes the file, scripts/gpu_final.sh collects the counters).  Counters cannot be collected inside the
+    timed run, so this is the committed measurement of a SEPARATE profiled run -- or None."""
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return float(doc[workload]["kernels"]["k_icp"]["hbm_bytes_per_launch"])
+        return float(doc[name]["kernels"]["k_icp"]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -94,9 +105,22 @@ def cpu_baseline(scans, warmup, steps, cfg):
 
 def main():
     args = parse_args()
+    W, K = args.warmup, args.steps
+    rank = int(os.environ.get("RANK", "0"))
+    factory, ds_kw, cfg_over, workload_name = workload(args.workload)
+    # the synthetic scans first, by a pool of processes, before this process touches the GPU runtime
+    from kiss_icp_amd import multistream
+    from kiss_icp_amd.datasets import generate_scans
+
+    t_gen = time.perf_counter()
+    scans = generate_scans(factory, dict(ds_kw, seed=multistream.stream_seed(args.seed, rank), n_frames=W + K), range(W + K),
+                           processes=args.gen_procs or None)
+    t_gen = time.perf_counter() - t_gen
+
+    import numpy as np
     import torch  # first: libkicp must bind to the HIP runtime torch has already loaded
 
-    from kiss_icp_amd import _cabi, multistream
+    from kiss_icp_amd import _cabi
     from kiss_icp_amd.config import load_config
     from kiss_icp_amd.kiss_icp import KissICP
 
@@ -109,32 +133,22 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = multistream.init_process_group(args.backend) if world > 1 else None
     comm_device = device if args.backend == "nccl" else None  # gloo exchanges host tensors
-    if args.icp_blocks:
-        _cabi.set_option("icp_blocks", args.icp_blocks)
-    if args.icp_ppg:
-        _cabi.set_option("icp_points_per_group", args.icp_ppg)
     for kv in args.opt:
         name, value = kv.split("=")
         _cabi.set_option(name, int(value))
 
-    W, K = args.warmup, args.steps
-    ds, cfg_over, workload_name = make_dataset(args.workload, multistream.stream_seed(args.seed, rank), W + K)
-    scans = [ds[i] for i in range(W + K)]
-    dev_pts = [torch.from_numpy(s[0]).to(device) for s in scans]
-    dev_ts = [torch.from_numpy(s[1]).to(device) if len(s[1]) else None for s in scans]
-    frames = [(d.data_ptr(), d.shape[0], t.data_ptr() if t is not None else None, t.shape[0] if t is not None else 0)
-              for d, t in zip(dev_pts, dev_ts)]
-    torch.cuda.synchronize()
+    # what the reference's dataloaders yield: float64 (N,3) arrays in pageable host memory
+    host = [(np.ascontiguousarray(p, dtype=np.float64), np.ascontiguousarray(t, dtype=np.float64)) for p, t in scans]
 
     pipe = KissICP(load_config(**cfg_over), device_id=local_rank)
-    multistream.run_batch(pipe, frames[:W], dist, comm_device)  # W untimed warm-up frames
+    multistream.run_batch_host(pipe, host[:W], dist, comm_device)  # W untimed warm-up frames
     pipe.icp_timing(reset=True)
 
     # ---- timed region: exactly K frames, barrier + synchronize on both sides -------------------
     multistream.barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    local_poses, all_poses = multistream.run_batch(pipe, frames[W:W + K], dist, comm_device)
+    local_poses, all_poses = multistream.run_batch_host(pipe, host[W:W + K], dist, comm_device)
     torch.cuda.synchronize()
     multistream.barrier(dist)
     elapsed = time.perf_counter() - t0
@@ -142,22 +156,8 @@ def main():
     icp = pipe.icp_timing()
     stats = pipe.last_stats()
 
-    # ---- per-frame latency with a host sync after every frame (outside the timed region) --------
-    pipe2 = KissICP(load_config(**cfg_over), device_id=local_rank)
-    for f in frames[:W]:
-        pipe2.register_frame_device(*f)
-    pipe2.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for f in frames[W:W + K]:
-        pipe2.register_frame_device(*f)
-        pipe2.sync()
-    sync_latency_ms = 1e3 * (time.perf_counter() - t1) / K
-    same_traj = bool((pipe2.last_pose == local_poses[-1]).all())
-
     if rank != 0:
         return
-    import numpy as np
 
     out = {
         "metric": "RegisterFrame scans/s",
@@ -174,8 +174,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": workload_name,
+            "input": "host float64 arrays (pageable) -> kicp_pipeline_register_frame_async",
             "streams": world,
             "parallelism": f"streams{world}" if world > 1 else "single-stream",
+            "frames_driven": W + K,
             "n_raw": int(stats["n_raw"]),
             "n_frame_downsample": int(stats["n_frame_downsample"]),
             "n_source": int(stats["n_source"]),
@@ -183,8 +185,7 @@ def main():
             "icp_iters_per_frame": icp["iterations"] / max(1, icp["launches"]),
         },
         "ms_per_icp_iter": icp["total_ms"] / max(1, icp["iterations"]),
-        "ms_per_frame_host_synced": sync_latency_ms,
-        "async_equals_synced_trajectory": same_traj,
+        "scan_generation_s": t_gen,
     }
     cyc, tk = pipe.icp_clock()
     out["icp_shader_mhz"] = 100.0 * cyc / max(1, tk)
@@ -193,23 +194,84 @@ def main():
                               "later_iterations_us": (total_us - first_us) / max(1, n_it - 1)}
     # roofline of the dominant kernel (k_icp): algorithmic bytes of AlignPointsToMap
     # (per iteration N_src*(24+24) + N_src*27*16 + E*24 + 336) / device time
-    # measured with hipEvents on the pipeline's own stream around every k_icp launch.
+    # measured with hipEvents on the pipeline's own stream around every k_icp launch of the timed region.
     if icp["total_ms"] > 0:
         achieved = icp["algorithmic_bytes"] / (icp["total_ms"] * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_icp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload),
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, a separate run of this command; null = not collected for this workload)",
             "bytes_per_launch": icp["algorithmic_bytes"] / max(1, icp["launches"]),
             "ms_per_launch": icp["total_ms"] / max(1, icp["launches"]),
         }
+
+    # ---- secondary measurements, outside the timed region: the same K frames on fresh pipelines ------------
+    if not args.no_extras and world == 1:
+        def drive(fn_enqueue, prepare=None):
+            k = KissICP(load_config(**cfg_over), device_id=local_rank)
+            for f in host[:W]:
+                k.register_frame_async(*f)
+            k.sync()
+            items = prepare() if prepare else host[W:W + K]
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for it in items:
+                fn_enqueue(k, it)
+            k.sync()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            return k, K / dt
+
+        # (a) scans already resident in HBM (float64), queued back-to-back
+        dev_pts = [torch.from_numpy(p).to(device) for p, _ in host[W:W + K]]
+        dev_ts = [torch.from_numpy(t).to(device) if len(t) else None for _, t in host[W:W + K]]
+        frames = [(d.data_ptr(), d.shape[0], t.data_ptr() if t is not None else None, t.shape[0] if t is not None else 0)
+                  for d, t in zip(dev_pts, dev_ts)]
+        kd, rate_dev = drive(lambda k, f: k.register_frame_device(*f), lambda: frames)
+        out["device_resident"] = {"scans_per_s": rate_dev, "ms_per_frame": 1e3 / rate_dev,
+                                  "same_trajectory_as_host_input": bool((kd.last_pose == local_poses[-1]).all())}
+        del dev_pts, dev_ts
+        # (b) the sensor's native float32 points in host memory (no widening, no narrowing)
+        host32 = [(p.astype(np.float32), t) for p, t in host[W:W + K]]
+        k32, rate32 = drive(lambda k, f: k.register_frame_async(*f), lambda: host32)
+        out["host_float32_input"] = {"scans_per_s": rate32, "ms_per_frame": 1e3 / rate32,
+                                     "same_trajectory_as_host_input": bool((k32.last_pose == local_poses[-1]).all())}
+        # (c) fully synchronous RegisterFrame: wait for the pose after every frame, without and with the two
+        #     clouds the reference's RegisterFrame returns (KissICP.cpp:67) copied back to host arrays
+        ks = KissICP(load_config(**cfg_over), device_id=local_rank)
+        for f in host[:W]:
+            ks.register_frame_async(*f)
+        ks.sync()
+        t = time.perf_counter()
+        for f in host[W:W + K]:
+            ks.register_frame_async(*f)
+            ks.sync()
+        rate_sync = K / (time.perf_counter() - t)
+        ko = KissICP(load_config(**cfg_over), device_id=local_rank)
+        for f in host[:W]:
+            ko.register_frame_async(*f)
+        ko.sync()
+        t = time.perf_counter()
+        for f in host[W:W + K]:
+            ko.register_frame(*f)  # returns (preprocessed frame, source) as numpy arrays
+        rate_out = K / (time.perf_counter() - t)
+        out["sync_per_frame"] = {"scans_per_s": rate_sync, "ms_per_frame": 1e3 / rate_sync,
+                                 "same_trajectory_as_host_input": bool((ks.last_pose == local_poses[-1]).all())}
+        out["sync_with_outputs"] = {"scans_per_s": rate_out, "ms_per_frame": 1e3 / rate_out,
+                                    "same_trajectory_as_host_input": bool((ko.last_pose == local_poses[-1]).all())}
+
     if world == 1 and not args.no_cpu_baseline:
         best, detail = cpu_baseline(scans, W, K, cfg_over)
         D = np.linalg.inv(detail[best]["pose"]) @ local_poses[-1]
         out["cpu_baseline"] = {
             "value": detail[best]["scans_per_s"], "unit": "scans/s", "cores": best, "kind": "port",
-            "sample": f"the same {K} frames after {W} warm-up frames, oracle/kiss_oracle.c (OpenMP in the reference's 3 TBB sites)",
+            "sample": f"the same {K} frames after {W} warm-up frames, host arrays",
+            "what": "oracle/kiss_oracle.c -- a C restatement of the reference path, NOT the upstream binary (Eigen/Sophus/tsl/TBB "
+                    "are not installed); OpenMP in the reference's three TBB sites; gcc -O3 -ffp-contract=off, no -march=native "
+                    "(the reference's Release build is generic x86-64 too)",
             "ms_per_icp_iter": detail[best]["ms_per_icp_iter"],
             "single_thread_scans_per_s": detail[1]["scans_per_s"],
+            "by_threads": {str(t): d["scans_per_s"] for t, d in detail.items()},
             "host_cores": os.cpu_count(),
         }
         out["speedup_vs_cpu"] = out["value"] / detail[best]["scans_per_s"]

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define KICP_VERSION_MAJOR 0
-#define KICP_VERSION_MINOR 1
+#define KICP_VERSION_MINOR 2
 
 typedef enum kicp_status {
     KICP_OK = 0,
@@ -115,6 +115,13 @@ int kicp_align_points_to_map(kicp_registration *reg, const double *frame_xyz, si
                              double max_correspondence_distance, double kernel_scale,
                              double T_out[16], kicp_icp_stats *stats);
 
+/* BuildLinearSystem (Registration.cpp:80-121) as accumulated by the LAST iteration of the most recent
+ * kicp_align_points_to_map on this handle: JTJ row-major 6x6, JTr 6 (the reference solves
+ * JTJ dx = -JTr), and the number of correspondences that went into them.  With
+ * max_num_iterations = 1 this is the system of the initial guess. */
+int kicp_registration_last_system(const kicp_registration *reg, double JTJ[36], double JTr[6],
+                                  uint64_t *n_corr);
+
 /* ------------------------------------------------------------------------------------------
  * Free functions of the stages either side of the path ("next" rows of SURVEY.md section 8f)
  * ---------------------------------------------------------------------------------------- */
@@ -166,10 +173,28 @@ enum { /* kicp_pipeline_output: which cloud of the last frame */
 
 int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **out);
 int kicp_pipeline_destroy(kicp_pipeline *p);
-/* RegisterFrame(frame, timestamps)  KissICP.cpp:35-68, host buffers (copied H2D). Blocks until
- * the frame's pose is available.  timestamps may be NULL / n_timestamps 0. */
+/* RegisterFrame(frame, timestamps)  KissICP.cpp:35-68 on host buffers (pageable memory is fine:
+ * std::vector<Eigen::Vector3d>::data(), a numpy array).  Blocks until the frame's pose is available;
+ * the two clouds RegisterFrame returns stay in HBM until kicp_pipeline_output() asks for them.
+ * timestamps may be NULL / n_timestamps 0.  Equivalent to kicp_pipeline_register_frame_async() +
+ * kicp_pipeline_sync(). */
 int kicp_pipeline_register_frame(kicp_pipeline *p, const double *xyz, size_t n,
                                  const double *timestamps, size_t n_timestamps);
+/* The same without waiting: the scan is copied into pinned staging memory (a few helper threads,
+ * option "staging_threads"), so the caller's buffers are free again when the call returns; its upload and
+ * the stages in front of the registration then run on a second stream UNDER the previous frame's
+ * registration, and the frame is queued behind it (frame k+1 consumes frame k's pose and map on the
+ * device).  float64 scans whose values are all exactly representable in float32 -- anything read from a
+ * float32 sensor file (python/kiss_icp/datasets/kitti.py:66) -- are narrowed for the upload (option
+ * "staging_f32"): half the bytes over PCIe, bit-identical points on the device.  Results:
+ * kicp_pipeline_sync() + kicp_pipeline_synced_poses() / kicp_pipeline_pose().  This is the entry the
+ * throughput figure of bench.py is measured on. */
+int kicp_pipeline_register_frame_async(kicp_pipeline *p, const double *xyz, size_t n,
+                                       const double *timestamps, size_t n_timestamps);
+/* ... for callers that hold the sensor's native float32 points (ROS PointCloud2:
+ * ros/src/Utils.hpp:201-205, KITTI .bin files): no widening on the host at all */
+int kicp_pipeline_register_frame_async_f32(kicp_pipeline *p, const float *xyz, size_t n,
+                                           const double *timestamps, size_t n_timestamps);
 /* Same, with the scan (and timestamps) already resident in this device's HBM.  Enqueues the
  * frame on the pipeline's stream and returns without waiting; frames may be queued
  * back-to-back (frame k+1 consumes frame k's pose on the device).  The buffers must stay
@@ -246,6 +271,14 @@ int kicp_device_synchronize(int device_id);
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
+ *   "icp_lds_kib"     LDS per ICP workgroup in KiB, 64..160 (0 = all 160: one workgroup per CU)
+ *   "icp_reserve_cus" CUs left out of the ICP grid for the front stages of the next frame, which run
+ *                     concurrently on a second stream (default 16; the grid is the device's co-resident
+ *                     maximum minus this)
+ *   "staging_threads" helper threads (besides the caller) that copy a host scan into pinned memory (default 3)
+ *   "staging_f32"     1 = narrow float64 host scans to float32 for the upload when lossless (default 1)
+ *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if
+ *                     their workgroups never became co-resident (exercises the replay path)
  *   "map_apply_threads"  workgroup size of the AddPoints apply kernel: 256, 512 (default) or 1024
  *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
  *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)

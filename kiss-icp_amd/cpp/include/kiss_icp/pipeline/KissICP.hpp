@@ -81,6 +81,7 @@ private:
     double dev_delta_[16];
 
     KISSConfig config_;
+    int device_id_ = 0;
     kicp_pipeline *handle_ = nullptr;
     VoxelHashMap local_map_;  // view of the pipeline's device map
     int last_iterations_ = 0;

@@ -232,6 +232,7 @@ KissICP::KissICP(const KISSConfig &config) : KissICP(config, DefaultDevice()) {}
 
 KissICP::KissICP(const KISSConfig &config, int device_id)
     : config_(config),
+      device_id_(device_id),
       handle_(make_pipeline(config, device_id)),
       local_map_(VoxelHashMap::Borrow(map_of(handle_), config.voxel_size, config.max_range,
                                       static_cast<unsigned>(config.max_points_per_voxel))) {
@@ -277,9 +278,16 @@ KissICP::Vector3dVectorTuple KissICP::RegisterFrame(const std::vector<Eigen::Vec
 }
 
 KissICP::Vector3dVectorTuple KissICP::Voxelize(const std::vector<Eigen::Vector3d> &frame) const {
-    const auto voxel_size = config_.voxel_size;  // KissICP.cpp:70-75
-    auto frame_downsample = kiss_icp::VoxelDownsample(frame, voxel_size * 0.5);
-    auto source = kiss_icp::VoxelDownsample(frame_downsample, voxel_size * 1.5);
+    const auto voxel_size = config_.voxel_size;  // KissICP.cpp:70-75, on THIS pipeline's device
+    auto downsample = [this](const Vector3dVector &in, double v) {
+        Vector3dVector out(in.size());
+        size_t n = 0;
+        check(kicp_voxel_downsample(xyz(in), in.size(), v, device_id_, xyz(out), &n), "KissICP::Voxelize");
+        out.resize(n);
+        return out;
+    };
+    auto frame_downsample = downsample(frame, voxel_size * 0.5);
+    auto source = downsample(frame_downsample, voxel_size * 1.5);
     return {std::move(source), std::move(frame_downsample)};
 }
 

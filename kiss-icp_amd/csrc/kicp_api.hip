@@ -4,8 +4,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "kicp_launch.hpp"
@@ -90,14 +95,171 @@ static int err_bits_to_status(int bits) {
     return KICP_ERR_CAPACITY;
 }
 
-// The ICP grid is always launched at its maximum (one workgroup per CU); the kernel itself picks
-// how many of them take part from the actual N_src (surplus workgroups exit at once).
-static int icp_launch_blocks() { return kIcpMaxBlocks; }
-static void icp_fill_policy(IcpParams &P) {
+// ---- the persistent ICP kernel and the device it shares -------------------------------------------
+// k_icp's workgroups exchange partial sums inside the launch, so all of them must be resident at the
+// same time.  Two things guarantee that: (1) the grid never exceeds what the device can hold
+// (occupancy query x CU count of THIS device or partition, at the launch's LDS size); (2) launches of
+// k_icp on one device are ordered behind each other across handles and streams -- two half-resident
+// grids would wait for each other until their bounded spins give up.
+struct IcpDeviceGate {
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;  // stream of the most recent k_icp launch on this device
+    hipEvent_t ev = nullptr;            // scratch event (a wait captures the record it was issued behind)
+    int max_blocks[2] = {0, 0};         // co-resident workgroups at kIcpLdsBytesShared / kIcpLdsBytesMax
+};
+static IcpDeviceGate &icp_gate(int device_id) {
+    static IcpDeviceGate gates[64];
+    return gates[device_id & 63];
+}
+static int icp_max_blocks(int device_id, int lds_bytes) {
+    IcpDeviceGate &g = icp_gate(device_id);
+    std::lock_guard<std::mutex> lk(g.mu);
+    const int which = lds_bytes >= kIcpLdsBytesMax ? 1 : 0;
+    if (g.max_blocks[which] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 1;
+        int per_cu = icp_blocks_per_cu(lds_bytes);
+        if (per_cu < 1) per_cu = 1;
+        long b = (long)per_cu * cus;
+        g.max_blocks[which] = (int)(b < kIcpMaxBlocks ? b : kIcpMaxBlocks);
+    }
+    return g.max_blocks[which];
+}
+// launch k_icp on `s`, behind any k_icp another stream of this device still has in flight
+static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s) {
+    IcpDeviceGate &g = icp_gate(device_id);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.last_stream && g.last_stream != s) {
+        if (!g.ev) KICP_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+        KICP_HIP(hipEventRecord(g.ev, g.last_stream));
+        KICP_HIP(hipStreamWaitEvent(s, g.ev, 0));
+    }
+    launch_icp(P, grid, profile, s);
+    g.last_stream = s;
+    return KICP_OK;
+}
+// a stream is about to be destroyed: nobody may record on it any more
+static void icp_forget_stream(int device_id, hipStream_t s) {
+    IcpDeviceGate &g = icp_gate(device_id);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.last_stream == s) g.last_stream = nullptr;
+}
+
+// The grid is launched at the device's co-resident maximum; the kernel itself picks how many of the
+// workgroups take part from the actual N_src (surplus workgroups exit at once).  `cap` > 0 lowers the
+// maximum (replay after a timeout).
+static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) {
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 1);
     P.use_lds = options().icp_use_lds != 0;
     P.groups_used = (int)options().icp_groups;
+    // A workgroup owns its CU: 160 KiB of LDS for the candidate pool, and its eight waves fill the CU's
+    // vector register file, so nothing else runs beside it.  The front stages of the NEXT frame run
+    // concurrently on a second stream; a few CUs are left out of the grid for them (they are small
+    // streaming kernels hidden under the registration either way).
+    long lds = options().icp_lds_kib > 0 ? options().icp_lds_kib * 1024 : kIcpLdsBytesMax;
+    if (lds > kIcpLdsBytesMax) lds = kIcpLdsBytesMax;
+    if (lds < 64 * 1024) lds = 64 * 1024;
+    P.lds_bytes = (int)lds;
+    (void)n_hint;
+    int grid = icp_max_blocks(device_id, P.lds_bytes);
+    const int reserve = (int)options().icp_reserve_cus;
+    if (grid > 4 * reserve) grid -= reserve;
+    if (cap > 0 && cap < grid) grid = cap;
+    if (P.force_blocks > grid) P.force_blocks = grid;
+    return grid;
+}
+
+// ---- helper threads for host-side staging copies ------------------------------------------------------
+// RegisterFrame takes pageable host memory (std::vector<Eigen::Vector3d>, numpy arrays).  A 130k-point
+// scan is 3.1 MB; one core copies that in ~0.3 ms -- longer than the GPU needs for the whole frame.  A few
+// helper threads (plus the caller) split the copy into pinned staging memory.
+class StagePool {
+public:
+    explicit StagePool(int helpers) {
+        for (int i = 0; i < helpers; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    // fn(chunk) for every chunk in [0, nchunks), on the helpers and the calling thread; returns when all are done
+    void run(int nchunks, const std::function<void(int)> &fn) {
+        if (nchunks <= 0) return;
+        if (nchunks == 1 || threads_.empty()) {
+            for (int c = 0; c < nchunks; ++c) fn(c);
+            return;
+        }
+        Job job;
+        job.total = nchunks;
+        job.fn = &fn;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            cur_ = &job;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work(job);
+        while (job.done.load(std::memory_order_acquire) < nchunks) std::this_thread::yield();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            cur_ = nullptr;  // no helper can pick the job up any more ...
+        }
+        while (job.active.load(std::memory_order_acquire) > 0) std::this_thread::yield();  // ... and none still holds it
+    }
+
+private:
+    struct Job {
+        std::atomic<int> next{0}, done{0}, active{0};
+        int total = 0;
+        const std::function<void(int)> *fn = nullptr;
+    };
+    static void work(Job &j) {
+        for (;;) {
+            const int c = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= j.total) break;
+            (*j.fn)(c);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;  // generation of the last job this helper worked on
+        for (;;) {
+            Job *j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return quit_ || (cur_ && gen_ != seen); });
+                if (quit_) return;
+                j = cur_;
+                seen = gen_;
+                j->active.fetch_add(1, std::memory_order_acq_rel);  // taken under the lock: the job is still alive
+            }
+            work(*j);
+            j->active.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+    Job *cur_ = nullptr;
+    unsigned long gen_ = 0;
+    bool quit_ = false;
+};
+
+// f64 -> f32 narrowing of a block of coordinates; true iff every value survives the round trip, i.e. the
+// data came from a float32 sensor file (datasets/kitti.py:66, ROS PointCloud2) and nothing is lost
+static bool narrow_exact(const double *src, float *dst, size_t count) {
+    bool ok = true;
+    for (size_t i = 0; i < count; ++i) {
+        const float f = (float)src[i];
+        dst[i] = f;
+        ok &= ((double)f == src[i]);
+    }
+    return ok;
 }
 
 }  // namespace kicp
@@ -560,7 +722,10 @@ int kicp_registration_destroy(kicp_registration *r) {
     r->state.release();
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
-    if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->stream) {
+        icp_forget_stream(r->device, r->stream);
+        (void)hipStreamDestroy(r->stream);
+    }
     delete r;
     return KICP_OK;
 }
@@ -588,36 +753,43 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
     if (n) KICP_HIP(hipMemcpyAsync(r->frame.p, frame_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, r->stream));
     PipeState *st = r->state.as<PipeState>();
     KICP_HIP(hipMemcpyAsync(&st->guess, &guess, sizeof guess, hipMemcpyHostToDevice, r->stream));
-    const int G = icp_launch_blocks();
-    IcpParams P;
-    memset(&P, 0, sizeof P);
-    icp_fill_policy(P);
-    P.frame = r->frame.as<double>();
-    P.work = r->work.as<double>();
-    P.n_ptr = nullptr;
-    P.n_imm = (int)n;
-    P.map = map->view();
-    P.state = st;
-    P.pipeline_mode = 0;
-    P.max_dist = max_correspondence_distance;
-    P.kernel_scale = kernel_scale;
-    P.max_iters = r->max_iters;
-    P.conv = r->conv;
-    P.granules = r->granules.as<unsigned long long>();
-    P.spin_limit = kSpinLimit;
-    KICP_HIP(hipEventRecord(r->ev0, r->stream));
-    launch_icp(P, G, options().icp_profile != 0, r->stream);
-    KICP_HIP(hipGetLastError());
-    KICP_HIP(hipEventRecord(r->ev1, r->stream));
     PipeState h;
-    KICP_HIP(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, r->stream));
-    KICP_HIP(hipStreamSynchronize(r->stream));
-    if (h.err) {
+    for (int attempt = 0, cap = 0;; ++attempt) {
+        IcpParams P;
+        memset(&P, 0, sizeof P);
+        const int G = icp_fill_policy(r->device, P, n, cap);
+        P.frame = r->frame.as<double>();
+        P.work = r->work.as<double>();
+        P.n_ptr = nullptr;
+        P.n_imm = (int)n;
+        P.map = map->view();
+        P.state = st;
+        P.pipeline_mode = 0;
+        P.max_dist = max_correspondence_distance;
+        P.kernel_scale = kernel_scale;
+        P.max_iters = r->max_iters;
+        P.conv = r->conv;
+        P.granules = r->granules.as<unsigned long long>();
+        P.spin_limit = kSpinLimit;
+        KICP_HIP(hipEventRecord(r->ev0, r->stream));
+        KICP_TRY(icp_launch_ordered(r->device, P, G, options().icp_profile != 0, r->stream));
+        KICP_HIP(hipGetLastError());
+        KICP_HIP(hipEventRecord(r->ev1, r->stream));
+        KICP_HIP(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, r->stream));
+        KICP_HIP(hipStreamSynchronize(r->stream));
+        if (!h.err) break;
         int zero = 0;
         KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+        // the workgroups were not all resident (something else holds CUs of this device): the launch
+        // committed nothing, so it is simply repeated with half as many workgroups
+        if ((h.err & E_TIMEOUT) && attempt < 3 && G > 1) {
+            cap = G / 2;
+            continue;
+        }
         return err_bits_to_status(h.err);
     }
     se3_matrix(h.new_pose, T_out);
+    memcpy(r->last_sums, h.icp_last_sums, sizeof r->last_sums);
     if (stats) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r->ev0, r->ev1);
@@ -629,6 +801,29 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         stats->n_corr_total = h.icp_ncorr_total;
         stats->kernel_ms = ms;
     }
+    return KICP_OK;
+}
+
+int kicp_registration_last_system(const kicp_registration *r, double JTJ[36], double JTr[6], uint64_t *n_corr) {
+    if (!r || !JTJ || !JTr) return KICP_ERR_INVALID_ARG;
+    // the 16 unique sums -> the 6x6 / 6x1 of Registration.cpp:80-121 (J = [I | -hat(s)], row-major)
+    const double *S = r->last_sums;
+    for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+    JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+    JTJ[0 * 6 + 4] = JTJ[4 * 6 + 0] = S[3];
+    JTJ[0 * 6 + 5] = JTJ[5 * 6 + 0] = -S[2];
+    JTJ[1 * 6 + 3] = JTJ[3 * 6 + 1] = -S[3];
+    JTJ[1 * 6 + 5] = JTJ[5 * 6 + 1] = S[1];
+    JTJ[2 * 6 + 3] = JTJ[3 * 6 + 2] = S[2];
+    JTJ[2 * 6 + 4] = JTJ[4 * 6 + 2] = -S[1];
+    JTJ[3 * 6 + 3] = S[4];
+    JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+    JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+    JTJ[4 * 6 + 4] = S[7];
+    JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+    JTJ[5 * 6 + 5] = S[9];
+    for (int i = 0; i < 6; ++i) JTr[i] = S[10 + i];
+    if (n_corr) *n_corr = (uint64_t)S[16];
     return KICP_OK;
 }
 
@@ -805,10 +1000,21 @@ struct FrameRecord {  // the first kRecWords words mirror the device layout [map
 static_assert(offsetof(FrameRecord, st) == sizeof(int) * C_COUNT, "PipeState sits right behind the map counters");
 constexpr int kRecWords = (int)((sizeof(int) * C_COUNT + sizeof(PipeState)) / sizeof(unsigned));
 
+// what was enqueued last (enough to run the frame again after a registration that gave up)
+struct FrameInput {
+    bool valid = false;
+    const void *d_xyz = nullptr;
+    int xyz_f32 = 0;
+    size_t n = 0;
+    const double *d_ts = nullptr;
+    size_t n_ts = 0;
+};
+
 // Two streams per pipeline.  `stream` carries the frame's serial chain: AlignPointsToMap, then the
 // map update (frame k+1's registration needs frame k's points in the map).  `prep_stream` carries
-// the stages in front of the registration (Preprocess + Voxelize): for frame k+1 they only need
-// frame k's pose (for the deskew motion), so they run while frame k's map update is still in flight.
+// the upload of the scan and the stages in front of the registration (Preprocess + Voxelize): for
+// frame k+1 they only need frame k's pose (for the deskew motion), so they run while frame k's
+// registration and map update are still in flight.
 struct kicp_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -819,8 +1025,8 @@ struct kicp_pipeline {
     kicp_config cfg;
     kicp_map *map = nullptr;
     // fd (the 0.5 v cloud, read by the map update) and src (the 1.5 v cloud, read by the registration)
-    // exist twice, indexed by frame parity
-    DevBuf raw, ts, tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
+    // exist twice, indexed by frame parity; so do the upload targets raw / ts of the host-input path
+    DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -832,25 +1038,46 @@ struct kicp_pipeline {
     uint64_t frames_done = 0;
     FrameRecord last;  // most recent completed frame
     bool have_last = false;
-    long n_src_hint = 0;
+    // host-input path: pinned staging slots, reused round-robin once their upload has completed
+    static constexpr int kStage = 4;
+    char *stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_points = 0;
+    hipEvent_t ev_h2d[kStage] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_busy[kStage] = {false, false, false, false};
+    uint64_t staged = 0;
+    int f32_skip = 0;  // frames for which the lossless-narrowing attempt is skipped (the last attempt failed)
+    StagePool *pool = nullptr;
+    char *out_stage = nullptr;  // pinned bounce buffer of kicp_pipeline_output
+    size_t out_stage_bytes = 0;
+    // registration replay (timeout): co-residency cap for the ICP grid, the last frame's inputs
+    int icp_cap = 0;
+    int inject_timeouts = 0;  // test hook ("icp_inject_timeout" option, read at create)
+    FrameInput last_in;
     // ICP timing accumulators
     double icp_ms = 0.0;
     uint64_t icp_launches = 0, icp_iters = 0, icp_bytes = 0;
-    std::vector<double> pending_poses;  // row-major 4x4 per frame completed by the last sync
+    std::vector<double> pending_poses;  // row-major 4x4 per frame completed since the caller's last sync
+    bool poses_stale = false;           // the caller has seen them: the next queued frame starts a new list
 };
+
+static int pipe_sync(kicp_pipeline *p, bool user_call);
 
 // The pipeline's PipeState is the one behind its map's counters, so that one contiguous block
 // [map counters | PipeState] is the whole per-frame record.
 static PipeState *pipe_state(kicp_pipeline *p) { return map_mini_state(p->map); }
 
 static int pipe_reserve(kicp_pipeline *p, size_t n) {
-    if (n <= p->cap_points) return KICP_OK;
-    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
+    if (p->cap_points && n <= p->cap_points) return KICP_OK;
+    if (p->in_flight) KICP_TRY(pipe_sync(p, false));
     KICP_HIP(hipStreamSynchronize(p->prep_stream));
+    // never less than a minimum: an EMPTY first scan must still find its buffers (the front-stage
+    // kernels write their counts even for zero points)
     size_t cap = n + n / 8 + 1024;
     const size_t b3 = cap * 3 * sizeof(double);
-    KICP_TRY(p->raw.reserve(b3));
-    KICP_TRY(p->ts.reserve(cap * sizeof(double)));
+    for (int i = 0; i < 2; ++i) {
+        KICP_TRY(p->raw[i].reserve(b3));
+        KICP_TRY(p->ts[i].reserve(cap * sizeof(double)));
+    }
     KICP_TRY(p->tmp.reserve(b3));
     // pre/fd/src keep their contents (last frame's outputs) across a growth
     KICP_TRY(p->pre.reserve(b3, true, p->stream));
@@ -867,6 +1094,35 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
     p->tab_cap = tcap;
     p->cap_points = cap;
+    p->last_in.valid = false;  // the upload targets moved
+    return KICP_OK;
+}
+
+// pinned staging slots of the host-input path: [cap x 3 doubles | cap timestamps] each
+static int pipe_reserve_staging(kicp_pipeline *p) {
+    if (p->stage_points >= p->cap_points && p->stage[0]) return KICP_OK;
+    for (int i = 0; i < kicp_pipeline::kStage; ++i) {
+        if (p->stage_busy[i]) KICP_HIP(hipEventSynchronize(p->ev_h2d[i]));
+        p->stage_busy[i] = false;
+        if (p->stage[i]) KICP_HIP(hipHostFree(p->stage[i]));
+        p->stage[i] = nullptr;
+    }
+    for (int i = 0; i < kicp_pipeline::kStage; ++i) {
+        if (hipHostMalloc((void **)&p->stage[i], p->cap_points * 4 * sizeof(double)) != hipSuccess) {
+            set_error("pinned staging allocation of %zu bytes failed", p->cap_points * 4 * sizeof(double));
+            return KICP_ERR_OOM;
+        }
+        if (!p->ev_h2d[i]) KICP_HIP(hipEventCreateWithFlags(&p->ev_h2d[i], hipEventDisableTiming));
+    }
+    p->stage_points = p->cap_points;
+    if (!p->pool) {
+        long helpers = options().staging_threads;
+        const long hw = (long)std::thread::hardware_concurrency();
+        if (hw > 0 && helpers > hw - 1) helpers = hw - 1;
+        if (helpers < 0) helpers = 0;
+        p->pool = new (std::nothrow) StagePool((int)helpers);
+        if (!p->pool) return KICP_ERR_OOM;
+    }
     return KICP_OK;
 }
 
@@ -890,7 +1146,9 @@ static void pipe_refresh_bounds(kicp_pipeline *p) {
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
 }
 
-static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const double *d_ts, size_t n_ts) {
+// queue one frame whose scan is (or will be, in prep_stream order) in HBM at d_xyz: float64 xyz
+// triples, or float32 ones when xyz_f32 is set
+static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t n, const double *d_ts, size_t n_ts) {
     const kicp_config &c = p->cfg;
     const bool do_deskew = c.deskew && n_ts > 0 && d_ts;  // Preprocessing.cpp:59
     if (do_deskew && n_ts < n) {
@@ -898,7 +1156,11 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
         return KICP_ERR_TIMESTAMPS;
     }
     if (n > (size_t)0x7FFFFFF0 / 3) return KICP_ERR_INVALID_ARG;
-    if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(kicp_pipeline_sync(p));
+    if (p->poses_stale) {
+        p->pending_poses.clear();
+        p->poses_stale = false;
+    }
+    if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(pipe_sync(p, false));
     KICP_TRY(pipe_reserve(p, n));
     kicp_map *m = p->map;
     if (!m->capacity_ok(n)) {
@@ -935,6 +1197,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     PreParams P;
     memset(&P, 0, sizeof P);
     P.xyz = d_xyz;
+    P.xyz_f32 = xyz_f32;
     P.ts = do_deskew ? d_ts : nullptr;
     P.n = n_i;
     P.deskew = do_deskew ? 1 : 0;
@@ -997,10 +1260,12 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     // ===== stream: the serial chain =================================================================
     KICP_HIP(hipStreamWaitEvent(s, p->ev_prep_done[par], 0));
     // --- AlignPointsToMap + threshold / pose bookkeeping (KissICP.cpp:44-63) ---------------------
-    const int G = icp_launch_blocks();
     IcpParams I;
     memset(&I, 0, sizeof I);
-    icp_fill_policy(I);
+    // the source cloud is at most the scan; in practice ~1/60 of it (two voxel downsamples): the LDS policy
+    // goes by the previous frame's count when there is one
+    const size_t n_src_hint = p->have_last ? (size_t)p->last.st.n_src : n / 32;
+    const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap);
     I.frame = p->src[par].as<double>();
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
@@ -1013,6 +1278,10 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     I.conv = c.convergence_criterion;
     I.granules = p->granules.as<unsigned long long>();
     I.spin_limit = kSpinLimit;
+    if (p->inject_timeouts > 0) {
+        I.inject_timeout = 1;
+        p->inject_timeouts--;
+    }
     if (options().icp_profile != 0) {
         KICP_TRY(p->prof_groups.reserve(kIcpGroupProfileWords * sizeof(unsigned)));
         I.prof_groups = p->prof_groups.as<unsigned>();
@@ -1022,7 +1291,7 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     // bracket and marks "the previous frame is completely done" (buffer reuse, capacity bounds);
     // ev[slot][1] behind it closes the bracket and tells prep_stream the pose is ready.
     KICP_HIP(hipEventRecord(p->ev[slot][0], s));
-    launch_icp(I, G, options().icp_profile != 0, s);
+    KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s));
     // (skipped when nobody would look at it: timing off and a configuration that never deskews)
     p->icp_done_event = nullptr;
     if (options().icp_timing != 0 || c.deskew) {
@@ -1046,7 +1315,102 @@ static int pipe_enqueue(kicp_pipeline *p, const double *d_xyz, size_t n, const d
     KICP_HIP(hipGetLastError());
     p->in_flight++;
     p->frames_enqueued++;
+    p->last_in.valid = true;
+    p->last_in.d_xyz = d_xyz;
+    p->last_in.xyz_f32 = xyz_f32;
+    p->last_in.n = n;
+    p->last_in.d_ts = d_ts;
+    p->last_in.n_ts = n_ts;
     return KICP_OK;
+}
+
+// Host-input RegisterFrame, first half: copy the caller's scan into a pinned staging slot (the caller's
+// buffer is free again when this returns), start its upload on prep_stream -- where it runs under the
+// previous frame's registration -- and queue the frame behind it.  Exactly one of xyz64 / xyz32 is set.
+// float64 scans whose values are all exactly representable in float32 (they came from a float32 sensor
+// file) are narrowed on the way: half the bytes over PCIe, bit-identical points on the device.
+static int pipe_stage_and_enqueue(kicp_pipeline *p, const double *xyz64, const float *xyz32, size_t n, const double *ts,
+                                  size_t n_ts) {
+    const bool have_ts = ts && n_ts > 0;
+    if (!have_ts) n_ts = 0;
+    if (p->cfg.deskew && have_ts && n_ts < n) {
+        set_error("timestamps (%zu) shorter than frame (%zu)", n_ts, n);
+        return KICP_ERR_TIMESTAMPS;
+    }
+    if (n > (size_t)0x7FFFFFF0 / 3 || n_ts > (size_t)0x7FFFFFF0) return KICP_ERR_INVALID_ARG;
+    if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(pipe_sync(p, false));
+    KICP_TRY(pipe_reserve(p, n > n_ts ? n : n_ts));
+    KICP_TRY(pipe_reserve_staging(p));
+    const int slot = (int)(p->staged % kicp_pipeline::kStage);
+    if (p->stage_busy[slot]) {  // its previous upload (four frames ago) must have left the slot
+        KICP_HIP(hipEventSynchronize(p->ev_h2d[slot]));
+        p->stage_busy[slot] = false;
+    }
+    char *h = p->stage[slot];
+    double *h_ts = reinterpret_cast<double *>(h + p->stage_points * 3 * sizeof(double));
+    constexpr size_t kChunk = 16384;  // values per task
+    const size_t n_val = n * 3;
+    const int n_chunks = (int)((n_val + kChunk - 1) / kChunk);
+    const int ts_chunks = (int)((n_ts + kChunk - 1) / kChunk);
+    bool as_f32 = xyz32 != nullptr;
+    if (xyz32) {
+        p->pool->run(n_chunks + ts_chunks, [&](int c) {
+            if (c < n_chunks) {
+                const size_t a = (size_t)c * kChunk, b = a + kChunk < n_val ? a + kChunk : n_val;
+                memcpy(reinterpret_cast<float *>(h) + a, xyz32 + a, (b - a) * sizeof(float));
+            } else {
+                const size_t a = (size_t)(c - n_chunks) * kChunk, b = a + kChunk < n_ts ? a + kChunk : n_ts;
+                memcpy(h_ts + a, ts + a, (b - a) * sizeof(double));
+            }
+        });
+    } else {
+        bool try_f32 = options().staging_f32 != 0 && p->f32_skip == 0;
+        if (!try_f32 && p->f32_skip > 0) p->f32_skip--;
+        if (try_f32) {
+            std::atomic<int> inexact{0};
+            p->pool->run(n_chunks + ts_chunks, [&](int c) {
+                if (c < n_chunks) {
+                    if (inexact.load(std::memory_order_relaxed)) return;  // the attempt is void anyway
+                    const size_t a = (size_t)c * kChunk, b = a + kChunk < n_val ? a + kChunk : n_val;
+                    if (!narrow_exact(xyz64 + a, reinterpret_cast<float *>(h) + a, b - a)) inexact.store(1, std::memory_order_relaxed);
+                } else {
+                    const size_t a = (size_t)(c - n_chunks) * kChunk, b = a + kChunk < n_ts ? a + kChunk : n_ts;
+                    memcpy(h_ts + a, ts + a, (b - a) * sizeof(double));
+                }
+            });
+            if (inexact.load()) {
+                try_f32 = false;
+                p->f32_skip = 32;  // genuinely float64 data: do not pay for the attempt on every frame
+            } else {
+                as_f32 = true;
+            }
+            if (!as_f32)
+                p->pool->run(n_chunks, [&](int c) {
+                    const size_t a = (size_t)c * kChunk, b = a + kChunk < n_val ? a + kChunk : n_val;
+                    memcpy(reinterpret_cast<double *>(h) + a, xyz64 + a, (b - a) * sizeof(double));
+                });
+        } else {
+            p->pool->run(n_chunks + ts_chunks, [&](int c) {
+                if (c < n_chunks) {
+                    const size_t a = (size_t)c * kChunk, b = a + kChunk < n_val ? a + kChunk : n_val;
+                    memcpy(reinterpret_cast<double *>(h) + a, xyz64 + a, (b - a) * sizeof(double));
+                } else {
+                    const size_t a = (size_t)(c - n_chunks) * kChunk, b = a + kChunk < n_ts ? a + kChunk : n_ts;
+                    memcpy(h_ts + a, ts + a, (b - a) * sizeof(double));
+                }
+            });
+        }
+    }
+    // upload on the stream that consumes it.  raw[par] / ts[par] were last read by the front stages of
+    // frame k-2, which precede this copy in stream order.
+    const int par = (int)(p->frames_enqueued & 1u);
+    hipStream_t sp = p->prep_stream;
+    if (n) KICP_HIP(hipMemcpyAsync(p->raw[par].p, h, n_val * (as_f32 ? sizeof(float) : sizeof(double)), hipMemcpyHostToDevice, sp));
+    if (n_ts) KICP_HIP(hipMemcpyAsync(p->ts[par].p, h_ts, n_ts * sizeof(double), hipMemcpyHostToDevice, sp));
+    KICP_HIP(hipEventRecord(p->ev_h2d[slot], sp));
+    p->stage_busy[slot] = true;
+    p->staged++;
+    return pipe_enqueue(p, p->raw[par].p, as_f32 ? 1 : 0, n, n_ts ? p->ts[par].as<double>() : nullptr, n_ts);
 }
 
 extern "C" {
@@ -1078,6 +1442,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     if (!p) return KICP_ERR_OOM;
     p->device = device_id;
     p->cfg = *cfg;
+    p->inject_timeouts = (int)options().icp_inject_timeout;
     int s = KICP_OK;
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1104,6 +1469,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     }
     if (s == KICP_OK) s = p->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
     if (s == KICP_OK) s = p->prep.reserve(2 * sizeof(PrepState));
+    if (s == KICP_OK) s = pipe_reserve(p, 0);  // minimum buffers: the first scan may be empty
     if (s != KICP_OK) {
         if (s == KICP_ERR_HIP) set_error("pipeline resource creation failed");
         kicp_pipeline_destroy(p);
@@ -1127,30 +1493,36 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     (void)hipSetDevice(p->device);
     if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    delete p->pool;
+    p->pool = nullptr;
     if (p->map) kicp_map_destroy(p->map);
-    for (DevBuf *b : {&p->raw, &p->ts, &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1], &p->work, &p->slot1,
-                      &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep})
+    for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
+                      &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep})
         b->release();
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
+    for (int i = 0; i < kicp_pipeline::kStage; ++i) {
+        if (p->ev_h2d[i]) (void)hipEventDestroy(p->ev_h2d[i]);
+        if (p->stage[i]) (void)hipHostFree(p->stage[i]);
+    }
+    if (p->out_stage) (void)hipHostFree(p->out_stage);
     if (p->prep_stream) (void)hipStreamDestroy(p->prep_stream);
     if (p->ev_ok)
         for (int i = 0; i < kicp_pipeline::kRing; ++i) {
             for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
         }
     if (p->ring) (void)hipHostFree(p->ring);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->stream) {
+        icp_forget_stream(p->device, p->stream);
+        (void)hipStreamDestroy(p->stream);
+    }
     delete p;
     return KICP_OK;
 }
 
-int kicp_pipeline_sync(kicp_pipeline *p) {
-    if (!p) return KICP_ERR_INVALID_ARG;
-    KICP_HIP(hipSetDevice(p->device));
-    KICP_HIP(hipStreamSynchronize(p->stream));
-    int err_bits = 0;
-    p->pending_poses.clear();
-    for (int i = 0; i < p->in_flight; ++i) {
+// fold the completed frames [0, count) of the ring into the accumulators
+static void pipe_collect(kicp_pipeline *p, int count, int &err_bits) {
+    for (int i = 0; i < count; ++i) {
         const FrameRecord &r = p->ring[i];
         err_bits |= r.st.err | r.map_ctr[C_ERR];
         if (options().icp_timing && p->ev_ok) {
@@ -1168,48 +1540,112 @@ int kicp_pipeline_sync(kicp_pipeline *p) {
         se3_matrix(r.st.last_pose, T);
         p->pending_poses.insert(p->pending_poses.end(), T, T + 16);
     }
-    if (p->in_flight) {
-        p->last = p->ring[p->in_flight - 1];
+    if (count) {
+        p->last = p->ring[count - 1];
         p->have_last = true;
-        p->frames_done += (uint64_t)p->in_flight;
-        p->n_src_hint = p->last.st.n_src;
+        p->frames_done += (uint64_t)count;
         kicp_map *m = p->map;
         memcpy(m->h_ctr, p->last.map_ctr, sizeof m->h_ctr);
         m->used_ub = m->h_ctr[C_USED];
         m->bump_ub = m->h_ctr[C_BUMP] < m->blocks_cap ? m->h_ctr[C_BUMP] : m->blocks_cap;
     }
-    p->in_flight = 0;
-    if (err_bits) {
-        PipeState *st = pipe_state(p);
-        int zero = 0;
-        KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
-        KICP_HIP(hipMemcpy(p->map->ctr.as<int>() + C_ERR, &zero, sizeof zero, hipMemcpyHostToDevice));
-        return err_bits_to_status(err_bits);
-    }
-    return KICP_OK;
 }
+
+int kicp_pipeline_sync(kicp_pipeline *p) {
+    if (!p) return KICP_ERR_INVALID_ARG;
+    return pipe_sync(p, true);
+}
+
+}  // extern "C"
+
+// user_call = false: a wait the library inserted on its own (ring full, buffers growing); the poses it
+// completes stay on the caller's list
+static int pipe_sync(kicp_pipeline *p, bool user_call) {
+    KICP_HIP(hipSetDevice(p->device));
+    if (p->poses_stale) {
+        p->pending_poses.clear();
+        p->poses_stale = false;
+    }
+    if (user_call) p->poses_stale = true;
+    for (int attempt = 0;; ++attempt) {
+        KICP_HIP(hipStreamSynchronize(p->stream));
+        // a registration whose workgroups were not all resident gives up (bounded spin), commits nothing
+        // and poisons the frames queued behind it (they do nothing either): the frames in front are good
+        int good = p->in_flight;
+        for (int i = 0; i < p->in_flight; ++i)
+            if (p->ring[i].st.err & E_TIMEOUT) {
+                good = i;
+                break;
+            }
+        int err_bits = 0;
+        const int queued = p->in_flight;
+        pipe_collect(p, good, err_bits);
+        p->in_flight = 0;
+        if (good < queued) {
+            PipeState *st = pipe_state(p);
+            const int zero = 0;
+            KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+            // the map's host-side bounds counted inserts that never happened: refresh them
+            KICP_TRY(p->map->refresh_counters());
+            // next time with half as many workgroups
+            IcpParams probe;
+            memset(&probe, 0, sizeof probe);
+            const int grid = icp_fill_policy(p->device, probe, p->have_last ? (size_t)p->last.st.n_src : 0, p->icp_cap);
+            p->icp_cap = grid > 1 ? grid / 2 : 1;
+            p->frames_enqueued -= (uint64_t)(queued - good);
+            if (queued - good == 1 && p->last_in.valid && attempt < 3 && !(err_bits & ~E_TIMEOUT)) {
+                // exactly the last frame is missing and its scan is still where it was: run it again
+                const FrameInput in = p->last_in;
+                KICP_TRY(pipe_enqueue(p, in.d_xyz, in.xyz_f32, in.n, in.d_ts, in.n_ts));
+                continue;
+            }
+            set_error("registration gave up waiting for its workgroups (%d frame(s) not processed; re-submit them)", queued - good);
+            return KICP_ERR_TIMEOUT;
+        }
+        if (err_bits) {
+            PipeState *st = pipe_state(p);
+            int zero = 0;
+            KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+            KICP_HIP(hipMemcpy(p->map->ctr.as<int>() + C_ERR, &zero, sizeof zero, hipMemcpyHostToDevice));
+            return err_bits_to_status(err_bits);
+        }
+        return KICP_OK;
+    }
+}
+
+extern "C" {
 
 int kicp_pipeline_register_frame_device(kicp_pipeline *p, const double *d_xyz, size_t n, const double *d_ts,
                                         size_t n_ts) {
     if (!p || (!d_xyz && n)) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(p->device));
-    return pipe_enqueue(p, d_xyz, n, d_ts, n_ts);
+    return pipe_enqueue(p, d_xyz, 0, n, d_ts, n_ts);
+}
+
+int kicp_pipeline_register_frame_async(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps,
+                                       size_t n_ts) {
+    if (!p || (!xyz && n)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    return pipe_stage_and_enqueue(p, xyz, nullptr, n, timestamps, n_ts);
+}
+
+int kicp_pipeline_register_frame_async_f32(kicp_pipeline *p, const float *xyz, size_t n, const double *timestamps,
+                                           size_t n_ts) {
+    if (!p || (!xyz && n)) return KICP_ERR_INVALID_ARG;
+    KICP_HIP(hipSetDevice(p->device));
+    static const float kNone[3] = {0.f, 0.f, 0.f};
+    return pipe_stage_and_enqueue(p, nullptr, xyz ? xyz : kNone, n, timestamps, n_ts);
 }
 
 int kicp_pipeline_register_frame(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps,
                                  size_t n_ts) {
     if (!p || (!xyz && n)) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(p->device));
-    if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
-    KICP_TRY(pipe_reserve(p, n > n_ts ? n : n_ts));
-    // the scan goes in on the stream that consumes it (everything queued earlier has completed)
-    if (n) KICP_HIP(hipMemcpyAsync(p->raw.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, p->prep_stream));
-    const bool have_ts = timestamps && n_ts > 0;
-    if (have_ts)
-        KICP_HIP(hipMemcpyAsync(p->ts.p, timestamps, n_ts * sizeof(double), hipMemcpyHostToDevice, p->prep_stream));
-    KICP_TRY(pipe_enqueue(p, p->raw.as<double>(), n, have_ts ? p->ts.as<double>() : nullptr, have_ts ? n_ts : 0));
+    static const double kNone[3] = {0.0, 0.0, 0.0};
+    KICP_TRY(pipe_stage_and_enqueue(p, xyz ? xyz : kNone, nullptr, n, timestamps, n_ts));
     return kicp_pipeline_sync(p);
 }
+
 
 static int pipe_state_get(kicp_pipeline *p, PipeState &h) {
     if (p->in_flight) KICP_TRY(kicp_pipeline_sync(p));
@@ -1279,8 +1715,36 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
     if (c) {
         const unsigned par = (unsigned)((p->frames_enqueued - 1) & 1u);  // the last frame's buffers
         const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src[par] : p->fd[par];
-        KICP_HIP(hipMemcpyAsync(out, b.p, c * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        const size_t bytes = c * 3 * sizeof(double);
+        if (bytes < (size_t)256 * 1024) {  // small clouds: one direct copy
+            KICP_HIP(hipMemcpyAsync(out, b.p, bytes, hipMemcpyDeviceToHost, p->stream));
+            KICP_HIP(hipStreamSynchronize(p->stream));
+            return KICP_OK;
+        }
+        // large clouds (the preprocessed frame is ~3 MB): DMA into a pinned bounce buffer, then the helper
+        // threads spread it into the caller's pageable memory
+        if (p->out_stage_bytes < bytes) {
+            if (p->out_stage) KICP_HIP(hipHostFree(p->out_stage));
+            p->out_stage = nullptr;
+            p->out_stage_bytes = 0;
+            const size_t want = bytes + bytes / 4;
+            if (hipHostMalloc((void **)&p->out_stage, want) != hipSuccess) {
+                set_error("pinned output buffer of %zu bytes failed", want);
+                return KICP_ERR_OOM;
+            }
+            p->out_stage_bytes = want;
+        }
+        KICP_TRY(pipe_reserve_staging(p));  // (creates the helper threads)
+        constexpr size_t kPiece = 256 * 1024;
+        const int pieces = (int)((bytes + kPiece - 1) / kPiece);
+        KICP_HIP(hipMemcpyAsync(p->out_stage, b.p, bytes, hipMemcpyDeviceToHost, p->stream));
         KICP_HIP(hipStreamSynchronize(p->stream));
+        char *dst = reinterpret_cast<char *>(out);
+        const char *src = p->out_stage;
+        p->pool->run(pieces, [&](int k) {
+            const size_t a = (size_t)k * kPiece, e = a + kPiece < bytes ? a + kPiece : bytes;
+            memcpy(dst + a, src + a, e - a);
+        });
     }
     return KICP_OK;
 }
@@ -1482,6 +1946,20 @@ int kicp_set_option(const char *name, long value) {
         options().icp_profile = value;
     } else if (!strcmp(name, "icp_timing")) {
         options().icp_timing = value;
+    } else if (!strcmp(name, "icp_lds_kib")) {
+        if (value != 0 && (value < 64 || value > 160)) return KICP_ERR_INVALID_ARG;
+        options().icp_lds_kib = value;
+    } else if (!strcmp(name, "icp_reserve_cus")) {
+        if (value < 0 || value > 128) return KICP_ERR_INVALID_ARG;
+        options().icp_reserve_cus = value;
+    } else if (!strcmp(name, "staging_threads")) {
+        if (value < 0 || value > 64) return KICP_ERR_INVALID_ARG;
+        options().staging_threads = value;
+    } else if (!strcmp(name, "staging_f32")) {
+        options().staging_f32 = value;
+    } else if (!strcmp(name, "icp_inject_timeout")) {
+        if (value < 0) return KICP_ERR_INVALID_ARG;
+        options().icp_inject_timeout = value;
     } else if (!strcmp(name, "map_apply_threads")) {
         if (value != 256 && value != 512 && value != 1024) return KICP_ERR_INVALID_ARG;
         options().map_apply_threads = value;

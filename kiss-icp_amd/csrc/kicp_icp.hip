@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
     IcpRegionMeta *metas = reinterpret_cast<IcpRegionMeta *>(smem + sizeof(IcpShared));
     double *pool = reinterpret_cast<double *>(smem + kIcpFixedLds);
-    constexpr int kPoolDoubles = (int)((kIcpLdsBytes - kIcpFixedLds) / sizeof(double));
+    const int kPoolDoubles = (int)(((size_t)P.lds_bytes - kIcpFixedLds) / sizeof(double));
 
     const int tid = threadIdx.x;
     const int lane = tid & (kIcpGroup - 1);
@@ -72,6 +72,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const MapView &m = P.map;
     PipeState *st = P.state;
 
+    // a frame whose registration timed out (workgroups not co-resident) poisons the frames queued behind
+    // it: they leave the state untouched so that the host can replay from the failed frame
+    if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) return;
+    if (P.inject_timeout) {  // test hook: what a launch that never became co-resident leaves behind
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicOr(&st->err, E_TIMEOUT);
+            st->epoch_base = st->epoch_base + (unsigned)P.max_iters + 2u;
+        }
+        return;
+    }
     const unsigned long long launch_cyc = clock64(), launch_tick = wall_clock64();
     const int n = count_of(P.n_ptr, P.n_imm);
     // How many of the launched workgroups take part is decided here, from the actual N_src, so the
@@ -447,6 +457,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if (failed && tid == 0) atomicOr(&st->err, E_TIMEOUT);
 
     __syncthreads();  // the bookkeeping thread's last update is in LDS
+    if (failed) {  // nothing is committed except the tag base of the exchange
+        if (blockIdx.x == 0 && tid == 0) st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
+        return;
+    }
     if (blockIdx.x == 0 && tid == 0) {
         SE3 T_icp, guess;
 #pragma unroll
@@ -475,6 +489,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             st->n_fd = P.prep->n_fd;
         }
         st->icp_blocks_used = G;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) st->icp_last_sums[k] = iterations > 0 ? sh.tot[k] : 0.0;
         st->prof[0] = t_assoc;
         st->prof[1] = t_publish;
         st->prof[2] = t_gather;
@@ -512,17 +528,23 @@ int icp_prepare(int device_id) {
     if (done[device_id]) return 0;
     const void *kernels[2] = {reinterpret_cast<const void *>(k_icp<false>), reinterpret_cast<const void *>(k_icp<true>)};
     for (const void *k : kernels) {
-        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytes);
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytesMax);
         if (e != hipSuccess) return (int)e;
     }
     done[device_id] = true;
     return 0;
 }
+int icp_blocks_per_cu(int lds_bytes) {
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_icp<false>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_icp<true>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) b = 0;
+    return a < b ? a : b;
+}
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s) {
     if (profile)
-        hipLaunchKernelGGL((k_icp<true>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+        hipLaunchKernelGGL((k_icp<true>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
     else
-        hipLaunchKernelGGL((k_icp<false>), dim3(G), dim3(kIcpThreads), kIcpLdsBytes, s, P);
+        hipLaunchKernelGGL((k_icp<false>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
 }
 
 }  // namespace kicp

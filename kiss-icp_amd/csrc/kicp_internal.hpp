@@ -135,6 +135,9 @@ struct PipeState {
     unsigned long long icp_examined, icp_ncorr_last, icp_ncorr_total;
     int err;
     int icp_blocks_used;  // workgroups that took part in the last ICP launch
+    // the 16 unique scalars of J^T W J / J^T W r (BuildLinearSystem, Registration.cpp:80-121), the
+    // correspondence count and the examined count of the LAST iteration of the last launch (k_icp's sum order)
+    double icp_last_sums[18];
     // shader-clock cycles spent by workgroup 0 in the phases of the last ICP launch:
     // [0] association+accumulate, [1] workgroup reduce+publish, [2] gather, [3] solve+update
     unsigned long long prof[4];
@@ -159,7 +162,7 @@ constexpr int kIcpBookThread = kIcpThreads - 64;  // first lane of the last wave
 constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gather of one scalar
 constexpr int kIcpMaxBlocks = 256;
 constexpr int kIcpMaxCachedRounds = 4;  // rounds of a group whose neighbourhood may be staged in LDS
-constexpr int kIcpLdsBytes = 160 * 1024;  // one workgroup per CU owns the whole LDS
+constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the whole LDS
 constexpr size_t kIcpGroupProfileWords = (size_t)kIcpProfIters * kIcpMaxBlocks * kIcpGroupsPerBlock * 4;
 
 // LDS record of one (round, group) query of the persistent ICP kernel
@@ -201,6 +204,8 @@ struct IcpParams {
     int force_blocks;      // > 0: exactly this many workgroups take part
     int use_lds;           // stage candidate voxels in LDS (0 disables)
     int groups_used;       // 1..16 groups of every workgroup take source points (default 16)
+    int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
+    int inject_timeout;    // test hook: behave like a launch whose workgroups never became co-resident
     const PrepState *prep;  // pipeline mode: this frame's counts (copied into the frame record), or nullptr
     unsigned *prof_groups;  // profiling variant only: [kIcpProfIters][256 * 16][4] per-group records, or nullptr
 };
@@ -233,6 +238,11 @@ struct Options {
     long icp_timing = 1;
     long icp_groups = 16;        // groups per workgroup that take source points
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
+    long icp_lds_kib = 0;        // dynamic LDS per ICP workgroup in KiB (0: all 160)
+    long icp_reserve_cus = 16;   // CUs left out of the ICP grid for the concurrent front stages of the next frame
+    long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
+    long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
+    long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once
 };
 Options &options();
 
@@ -284,4 +294,5 @@ struct kicp_registration {
     double conv = 1e-4;
     kicp::DevBuf frame, work, granules, state;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

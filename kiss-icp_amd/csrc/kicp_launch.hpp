@@ -7,7 +7,8 @@ namespace kicp {
 
 // Preprocessor::Preprocess (core/Preprocessing.cpp:55-95) + fused first-downsample claim
 struct PreParams {
-    const double *xyz;  // raw scan
+    const void *xyz;    // raw scan: xyz triples, float64 or (xyz_f32) float32
+    int xyz_f32;
     const double *ts;   // timestamps or nullptr
     int n;              // raw point count (host value: the scan just arrived)
     int deskew;         // deskew_ && !timestamps.empty()
@@ -50,6 +51,7 @@ struct DsParams {
 };
 
 int icp_prepare(int device_id);
+int icp_blocks_per_cu(int lds_bytes);  // co-resident k_icp workgroups per CU (occupancy query, current device)
 size_t icp_granule_words(int G);
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,

@@ -58,7 +58,11 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, InsertScratch sc, c
         m.ctr[C_FTAIL] = m.ctr[C_FPEND];
     }
     SE3 pose;
-    if (use_pose) pose = state->new_pose;
+    if (use_pose) {
+        // a registration that gave up (E_TIMEOUT) left no pose: the frame inserts nothing (the host replays it)
+        if (__hip_atomic_load(&state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) return;
+        pose = state->new_pose;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double p[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
         if (use_pose) {  // VoxelHashMap.cpp:90-92
@@ -309,7 +313,9 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
         oz = state->new_pose.t[2];
     }
     const double md2 = m.max_distance * m.max_distance;
-    const int nb = min(m.ctr[C_BUMP], m.blocks_cap);
+    int nb = min(m.ctr[C_BUMP], m.blocks_cap);
+    if (use_state_origin && (__hip_atomic_load(&state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))
+        nb = 0;  // no pose, nothing to prune around (the frame record is still handed over)
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
         BlockHdr *hdr = block_hdr(m, b);
         if (hdr->count <= 0) continue;

@@ -100,7 +100,18 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_flags(PreParams P) {
     const int i = blockIdx.x * kScanThreads + threadIdx.x;
     bool keep = false;
     if (i < n) {
-        double p[3] = {P.xyz[3 * i], P.xyz[3 * i + 1], P.xyz[3 * i + 2]};
+        double p[3];
+        if (P.xyz_f32) {  // float32 sensor data (or a float64 scan narrowed losslessly by the host): widening is exact
+            const float *f = static_cast<const float *>(P.xyz);
+            p[0] = (double)f[3 * i];
+            p[1] = (double)f[3 * i + 1];
+            p[2] = (double)f[3 * i + 2];
+        } else {
+            const double *d = static_cast<const double *>(P.xyz);
+            p[0] = d[3 * i];
+            p[1] = d[3 * i + 1];
+            p[2] = d[3 * i + 2];
+        }
         if (P.deskew) {
             const double mn = f64_from_order_bits(P.prep->tmin_bits);
             const double mx = f64_from_order_bits(P.prep->tmax_bits);

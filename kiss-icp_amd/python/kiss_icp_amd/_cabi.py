@@ -81,12 +81,15 @@ SIGNATURES = {
     "kicp_registration_create": [_i, _d, _i, _i, C.POINTER(_vp)],
     "kicp_registration_destroy": [_vp],
     "kicp_align_points_to_map": [_vp, _vp, _sz, _vp, _dp, _d, _d, _dp, C.POINTER(IcpStats)],
+    "kicp_registration_last_system": [_vp, _dp, _dp, _u64p],
     "kicp_voxel_downsample": [_vp, _sz, _d, _i, _vp, _szp],
     "kicp_preprocess": [_vp, _sz, _vp, _sz, _dp, _d, _d, _i, _i, _vp, _szp],
     "kicp_config_default": [C.POINTER(Config)],
     "kicp_pipeline_create": [C.POINTER(Config), _i, C.POINTER(_vp)],
     "kicp_pipeline_destroy": [_vp],
     "kicp_pipeline_register_frame": [_vp, _vp, _sz, _vp, _sz],
+    "kicp_pipeline_register_frame_async": [_vp, _vp, _sz, _vp, _sz],
+    "kicp_pipeline_register_frame_async_f32": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_register_frame_device": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_sync": [_vp],
     "kicp_pipeline_synced_poses": [_vp, _vp, _sz, _szp],

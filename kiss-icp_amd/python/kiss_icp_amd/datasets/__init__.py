@@ -1,1 +1,2 @@
-from .synthetic import SyntheticLidar, kitti_like, livox_like, mulran_like, plane_pair  # noqa: F401
+from .synthetic import (SyntheticLidar, generate_scans, kitti_like, kitti_like_vegetated, livox_like,  # noqa: F401
+                        mulran_like, plane_pair)

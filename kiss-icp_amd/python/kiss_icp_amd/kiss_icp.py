@@ -93,7 +93,7 @@ class KissICP:
     def local_map(self):
         h = C.c_void_p()
         _cabi.check(_cabi.lib().kicp_pipeline_map(self._h, C.byref(h)))
-        return VoxelHashMap(0, 0, 0, _borrowed=h)
+        return VoxelHashMap(0, 0, 0, _borrowed=h, _owner=self)  # the handle lives as long as this pipeline
 
     # -- device-side extras ---------------------------------------------------------------------
     def output(self, which):
@@ -102,6 +102,25 @@ class KissICP:
         out = np.empty((n.value, 3))
         _cabi.check(_cabi.lib().kicp_pipeline_output(self._h, which, _cabi.ptr(out), n.value, C.byref(n)))
         return out
+
+    def register_frame_async(self, frame, timestamps=()):
+        """queue a host scan without waiting (kicp_pipeline_register_frame_async): `frame` is (N,3) float64
+        or float32 (the sensor's native precision: no widening on the host); the arrays are free again when
+        the call returns.  sync() waits, synced_poses() / last_pose give the results."""
+        frame = np.asarray(frame)
+        ts = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64).ravel())
+        L = _cabi.lib()
+        if frame.dtype == np.float32:
+            pts = np.ascontiguousarray(frame)
+            if pts.ndim != 2 or pts.shape[1] != 3:
+                raise TypeError("expected an (N, 3) array")
+            st = L.kicp_pipeline_register_frame_async_f32(self._h, _cabi.ptr(pts), len(pts), _cabi.ptr(ts) if len(ts) else None, len(ts))
+        else:
+            pts = _cabi.points(frame)
+            st = L.kicp_pipeline_register_frame_async(self._h, _cabi.ptr(pts), len(pts), _cabi.ptr(ts) if len(ts) else None, len(ts))
+        if st == 8:
+            raise IndexError(L.kicp_last_error().decode())
+        _cabi.check(st)
 
     def register_frame_device(self, d_xyz_ptr, n, d_ts_ptr=None, n_ts=0):
         """enqueue a frame whose points already live in this GPU's HBM (raw device pointers);

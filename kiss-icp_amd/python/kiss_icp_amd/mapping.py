@@ -18,8 +18,9 @@ def get_voxel_hash_map(config, device_id=0):
 
 class VoxelHashMap:
     def __init__(self, voxel_size: float, max_distance: float, max_points_per_voxel: int, device_id: int = 0,
-                 _borrowed=None):
+                 _borrowed=None, _owner=None):
         self._owned = _borrowed is None
+        self._owner = _owner  # a borrowed handle (KissICP.local_map) keeps the object that owns it alive
         if _borrowed is None:
             h = C.c_void_p()
             _cabi.check(_cabi.lib().kicp_map_create(voxel_size, max_distance, max_points_per_voxel, device_id, C.byref(h)))

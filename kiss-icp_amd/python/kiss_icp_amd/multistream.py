@@ -86,3 +86,13 @@ def run_batch(pipeline, device_frames, dist=None, device=None):
     pipeline.sync()
     local = pipeline.synced_poses()
     return local, gather_poses(local, dist, device)
+
+
+def run_batch_host(pipeline, host_frames, dist=None, device=None):
+    """the same for scans in host memory [(points, timestamps), ...]: each is handed to the pipeline's
+    asynchronous host-input entry (staged, uploaded under the previous frame's registration, queued)"""
+    for pts, ts in host_frames:
+        pipeline.register_frame_async(pts, ts)
+    pipeline.sync()
+    local = pipeline.synced_poses()
+    return local, gather_poses(local, dist, device)

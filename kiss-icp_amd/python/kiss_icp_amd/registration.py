@@ -41,3 +41,10 @@ class Registration:
             max_correspondance_distance, kernel, _cabi.dptr(T), C.byref(st)))
         self.last_stats = st.asdict()
         return T
+
+    def last_system(self):
+        """(JTJ (6,6), JTr (6,), n_corr) accumulated by the last iteration of the most recent
+        align_points_to_map (BuildLinearSystem, Registration.cpp:80-121)"""
+        JTJ, JTr, n = np.empty((6, 6)), np.empty(6), C.c_uint64(0)
+        _cabi.check(_cabi.lib().kicp_registration_last_system(self._registration, _cabi.dptr(JTJ), _cabi.dptr(JTr), C.byref(n)))
+        return JTJ, JTr, n.value

@@ -1,0 +1,390 @@
+"""GPU parity tests, second file: the drop-in host-input entries, the configurations of BASELINE.json that
+round 1 left untested on the GPU (1M-point / 0.1 m, full-size deskewed OS1-64, max_points_per_voxel > 32,
+long drives through prune / tombstone / rehash / block recycling), the linear system itself, and the
+robustness paths (two pipelines on one GPU, a registration that gives up and is replayed, an empty first
+scan).  Everything goes through the C-ABI (ctypes) and is checked against the CPU oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import make_pose, pose_error, random_cloud, sort_rows
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-7  # poses (north_star tolerance: 1e-4 m / 1e-4 rad)
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    oracle.lib()
+    return oracle
+
+
+def _pipe(**cfg):
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.kiss_icp import KissICP
+
+    return KissICP(load_config(**cfg))
+
+
+# ---- host-input entries ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("deskew", [False, True])
+def test_async_host_input_is_bitwise_the_sync_path(gpu, O, deskew):
+    """kicp_pipeline_register_frame_async on float64 host arrays (narrowed losslessly to float32 for the
+    upload), on float32 host arrays, and on float64 arrays with the narrowing switched off, queued without
+    waiting: each gives bit for bit the trajectory and clouds of the synchronous per-frame path and of the
+    device-resident path"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like, mulran_like
+
+    n_frames = 12
+    ds = (mulran_like if deskew else kitti_like)(seed=11, n_frames=n_frames, beams=32, azimuth_steps=512)
+    scans = [ds[i] for i in range(n_frames)]
+    ref = _pipe(deskew=deskew)
+    ref_poses = []
+    for p, t in scans:
+        ref.register_frame(p, t)
+        ref_poses.append(ref.last_pose)
+
+    def run(frames, **opts):
+        for k, v in opts.items():
+            _cabi.set_option(k, v)
+        try:
+            k = _pipe(deskew=deskew)
+            for p, t in frames:
+                k.register_frame_async(p, t)
+            k.sync()
+            return k, k.synced_poses()
+        finally:
+            for k_ in opts:
+                _cabi.set_option(k_, 1 if k_ == "staging_f32" else 3)
+
+    variants = {
+        "f64 narrowed": run(scans),
+        "f32 native": run([(p.astype(np.float32), t) for p, t in scans]),
+        "f64 as is": run(scans, staging_f32=0),
+        "no helper threads": run(scans, staging_threads=0),
+    }
+    for name, (k, poses) in variants.items():
+        assert len(poses) == n_frames, name
+        for i in range(n_frames):
+            assert np.array_equal(poses[i], ref_poses[i]), (name, i)
+        for which in (0, 1, 2):
+            assert np.array_equal(k.output(which), ref.output(which)), (name, which)
+    # scans that are NOT float32-representable take the float64 upload and still agree with the oracle
+    rng = np.random.default_rng(5)
+    ko = O.KissICP(deskew=int(deskew))
+    kg = _pipe(deskew=deskew)
+    for p, t in scans[:5]:
+        q = p + rng.normal(0.0, 1e-9, p.shape)  # sub-float32 perturbation
+        kg.register_frame_async(q, t)
+        ko.register_frame(q, t)
+    kg.sync()
+    dt, dr = pose_error(ko.last_pose, kg.last_pose)
+    assert dt < TIGHT and dr < TIGHT
+
+
+def test_async_many_more_frames_than_the_ring(gpu, O):
+    """300 tiny frames queued without a sync: the library waits on its own when its 256-slot ring is full and
+    the caller still gets every pose"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=2, n_frames=8, beams=16, azimuth_steps=128)
+    scans = [ds[i % 8][0] for i in range(300)]
+    ka, ks = _pipe(deskew=False), _pipe(deskew=False)
+    for s in scans:
+        ka.register_frame_async(s)
+    ka.sync()
+    poses = ka.synced_poses()
+    assert len(poses) == 300
+    for i, s in enumerate(scans):
+        ks.register_frame_async(s)
+        if i % 37 == 0:
+            ks.sync()
+    ks.sync()
+    assert np.array_equal(ks.last_pose, poses[-1])
+
+
+def test_empty_first_frame(gpu, O):
+    """the very first scan is empty (no buffers have been sized by a real scan yet): the reference returns the
+    initial guess and carries on"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=4, n_frames=3, beams=16, azimuth_steps=256)
+    scans = [np.zeros((0, 3)), ds[0][0], ds[1][0]]
+    for entry in ("register_frame", "register_frame_async"):
+        kg, ko = _pipe(deskew=False), O.KissICP(deskew=0)
+        for i, pts in enumerate(scans):
+            getattr(kg, entry)(pts)
+            kg.sync()
+            ko.register_frame(pts, np.array([]))
+            dt, dr = pose_error(ko.last_pose, kg.last_pose)
+            assert dt < TIGHT and dr < TIGHT, (entry, i, dt, dr)
+            assert kg.last_stats()["icp"]["iterations"] == ko.last_stats()["iterations"], (entry, i)
+        assert kg.local_map.num_voxels() == ko.local_map.num_voxels()
+
+
+# ---- BASELINE configurations at full size ---------------------------------------------------------------------
+def test_config5_one_million_points_voxel_01(gpu, O):
+    """BASELINE config 5: 128 x 8192 rays (~1.04M points), voxel 0.1 m.  ~72k source points: several rounds
+    of points per group, staged windows beyond the LDS pool fall back to the HBM search, the map grows by
+    hundreds of thousands of voxels per frame (table rehash, pool growth)"""
+    from kiss_icp_amd.datasets import livox_like
+
+    ds = livox_like(seed=2, n_frames=4)
+    kg, ko = _pipe(deskew=False, voxel_size=0.1), O.KissICP(deskew=0, voxel_size=0.1)
+    for i in range(4):
+        pts, ts = ds[i]
+        fg, sg = kg.register_frame(pts, ts)
+        fo, so = ko.register_frame(pts, ts)
+        assert np.array_equal(fg, fo) and np.array_equal(sg, so), i
+        g, o = kg.last_stats(), ko.last_stats()
+        assert g["icp"]["iterations"] == o["iterations"], i
+        assert g["icp"]["points_examined"] == o["points_examined"], i
+        assert g["icp"]["n_corr_last"] == o["n_corr_last"], i
+        dt, dr = pose_error(ko.last_pose, kg.last_pose)
+        assert dt < TIGHT and dr < TIGHT, (i, dt, dr)
+    assert kg.last_stats()["n_source"] > 60000
+    assert kg.local_map.num_voxels() == ko.local_map.num_voxels()
+
+
+def test_config3_full_size_os1_64_with_deskew(gpu, O):
+    """BASELINE config 3 at full size: 64 x 1024 rays with per-point timestamps, motion-distorted scans,
+    deskew on"""
+    from kiss_icp_amd.datasets import mulran_like
+
+    ds = mulran_like(seed=1, n_frames=6)
+    kg, ko = _pipe(deskew=True), O.KissICP(deskew=1)
+    for i in range(6):
+        pts, ts = ds[i]
+        fg, sg = kg.register_frame(pts, ts)
+        fo, so = ko.register_frame(pts, ts)
+        assert fg.shape == fo.shape and sg.shape == so.shape, i
+        np.testing.assert_allclose(fg, fo, rtol=0, atol=1e-9)  # device sincos / atan2 differ in the last ulp
+        assert kg.last_stats()["icp"]["iterations"] == ko.last_stats()["iterations"], i
+        dt, dr = pose_error(ko.last_pose, kg.last_pose)
+        assert dt < TIGHT and dr < TIGHT, (i, dt, dr)
+    assert kg.last_stats()["n_raw"] > 55000
+
+
+def test_vegetated_scene_of_the_bench(gpu, O):
+    """the scene bench.py runs on (foliage: porous, volumetric returns; ~4k source points, two rounds of
+    points per group) for a few frames"""
+    from kiss_icp_amd.datasets import generate_scans, kitti_like_vegetated
+
+    scans = generate_scans(kitti_like_vegetated, dict(seed=0, n_frames=8), range(8), processes=4)
+    kg, ko = _pipe(deskew=False), O.KissICP(deskew=0)
+    for i, (pts, ts) in enumerate(scans):
+        kg.register_frame_async(pts, ts)
+        ko.register_frame_noout(pts, ts)
+        kg.sync()
+        g, o = kg.last_stats(), ko.last_stats()
+        assert g["icp"]["iterations"] == o["iterations"], i
+        assert g["icp"]["points_examined"] == o["points_examined"], i
+        dt, dr = pose_error(ko.last_pose, kg.last_pose)
+        assert dt < TIGHT and dr < TIGHT, (i, dt, dr)
+    assert kg.last_stats()["n_source"] > 3500
+
+
+# ---- max_points_per_voxel > 32 (serial voxel paths) ----------------------------------------------------------
+def test_max_points_per_voxel_40(gpu, O):
+    from kiss_icp_amd.datasets import kitti_like
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(40)
+    g, o = VoxelHashMap(1.0, 100.0, 40), O.VoxelHashMap(1.0, 100.0, 40)
+    for k in range(3):  # dense: many voxels reach the 40-point cap, the spacing rule sqrt(1/40) decides the rest
+        pts = rng.uniform(-6.0, 6.0, size=(60000, 3)) * np.array([1.0, 1.0, 0.3])
+        g.add_points(pts)
+        o.add_points(pts)
+        assert g.num_voxels() == o.num_voxels()
+        assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud())), k
+    keys = np.floor(g.point_cloud()).astype(np.int64)
+    assert np.unique(keys, axis=0, return_counts=True)[1].max() > 32  # the wide-voxel paths really ran
+    q = rng.uniform(-7.0, 7.0, size=(2000, 3)) * np.array([1.0, 1.0, 0.4])
+    nn, dist = g.closest_neighbor(q)
+    for i in range(len(q)):
+        onn, od = o.closest_neighbor(q[i])
+        assert np.array_equal(nn[i], onn) and dist[i] == od, i
+    src = rng.uniform(-5.0, 5.0, size=(1500, 3)) * np.array([1.0, 1.0, 0.3])
+    guess = make_pose((0.05, -0.03, 0.01), (0.001, 0.002, 0.004))
+    rg, ro = Registration(500, 1e-4), O.Registration(500, 1e-4)
+    Tg = rg.align_points_to_map(src, g, guess, 1.0, 0.3)
+    To = ro.align_points_to_map(src, o, guess, 1.0, 0.3)
+    assert rg.last_stats["iterations"] == ro.last_stats["iterations"]
+    assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
+    dt, dr = pose_error(To, Tg)
+    assert dt < TIGHT and dr < TIGHT
+    # and a short drive with the wide voxels
+    ds = kitti_like(seed=6, n_frames=6, beams=32, azimuth_steps=512)
+    kg, ko = _pipe(deskew=False, max_points_per_voxel=40), O.KissICP(deskew=0, max_points_per_voxel=40)
+    for i in range(6):
+        kg.register_frame(ds[i][0])
+        ko.register_frame(ds[i][0], np.array([]))
+        dt, dr = pose_error(ko.last_pose, kg.last_pose)
+        assert dt < TIGHT and dr < TIGHT, i
+    np.testing.assert_allclose(sort_rows(kg.local_map.point_cloud()), sort_rows(ko.local_map.point_cloud()), rtol=0, atol=1e-9)
+
+
+# ---- long drive: prune -> tombstones -> rehash -> block recycling inside the asynchronous pipeline -----------------
+def test_long_drive_map_content_every_50_frames(gpu, O):
+    """240 frames at reduced resolution through the asynchronous host-input pipeline with a 40 m map radius:
+    the vehicle leaves its own map several times over, so voxels are pruned, their slots tombstoned and
+    rehashed, their blocks recycled -- and every 60 frames the map holds exactly the oracle's points"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    n_frames = 240
+    ds = kitti_like(seed=8, n_frames=n_frames, beams=32, azimuth_steps=512, yaw_deg=0.8)
+    kg, ko = _pipe(deskew=False, max_range=40.0, voxel_size=0.5), O.KissICP(deskew=0, max_range=40.0, voxel_size=0.5)
+    checked = 0
+    for i in range(n_frames):
+        pts, ts = ds[i]
+        kg.register_frame_async(pts, ts)
+        ko.register_frame_noout(pts, ts)
+        if (i + 1) % 60 == 0:
+            kg.sync()
+            dt, dr = pose_error(ko.last_pose, kg.last_pose)
+            assert dt < 1e-6 and dr < 1e-6, (i, dt, dr)
+            assert kg.last_stats()["icp"]["iterations"] == ko.last_stats()["iterations"], i
+            gm, om = kg.local_map, ko.local_map
+            assert gm.num_voxels() == om.num_voxels(), i
+            np.testing.assert_allclose(sort_rows(gm.point_cloud()), sort_rows(om.point_cloud()), rtol=0, atol=1e-8)
+            checked += 1
+    assert checked == 4
+
+
+# ---- BuildLinearSystem itself -----------------------------------------------------------------------------------
+def test_linear_system_matches_the_oracle(gpu, O):
+    """the 6x6 / 6x1 normal equations of one iteration (Registration.cpp:80-121), element by element: the
+    sums the kernel accumulated against the oracle's BuildLinearSystem on the same correspondences"""
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(61)
+    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
+    world = random_cloud(rng, 40000, extent=30.0, z_extent=4.0)
+    g.add_points(world)
+    o.add_points(world)
+    for n_src, max_dist, kernel in ((3000, 3.0, 1.0), (700, 0.6, 0.2), (9000, 6.0, 2.0)):
+        src = world[rng.choice(len(world), n_src, replace=False)] + rng.normal(0, 0.05, (n_src, 3))
+        reg = Registration(1, 1e-12)  # one iteration: the system of the initial guess (identity)
+        reg.align_points_to_map(src, g, np.eye(4), max_dist, kernel)
+        JTJ, JTr, n_corr = reg.last_system()
+        oJTJ, oJTr, on = O.build_linear_system(src, o, max_dist, kernel)
+        assert n_corr == on
+        scale = np.abs(oJTJ).max()
+        np.testing.assert_allclose(JTJ, oJTJ, rtol=0, atol=1e-12 * scale)  # summation order differs, nothing else
+        np.testing.assert_allclose(JTr, oJTr, rtol=0, atol=1e-12 * max(1.0, np.abs(oJTr).max()) * n_src)
+        assert np.array_equal(JTJ, JTJ.T)
+
+
+def test_icp_without_lds_staging(gpu, O):
+    """icp_use_lds = 0: every iteration searches the map in HBM (the path a query takes when the LDS pool is
+    exhausted); same neighbours, same sums"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(71)
+    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
+    world = random_cloud(rng, 30000, extent=25.0, z_extent=3.0)
+    g.add_points(world)
+    o.add_points(world)
+    src = world[rng.choice(len(world), 2500, replace=False)] + rng.normal(0, 0.03, (2500, 3))
+    guess = make_pose((0.2, -0.1, 0.02), (0.002, -0.001, 0.01))
+    out = {}
+    try:
+        for lds in (1, 0):
+            _cabi.set_option("icp_use_lds", lds)
+            r = Registration(500, 1e-4)
+            out[lds] = (r.align_points_to_map(src, g, guess, 3.0, 1.0), dict(r.last_stats))
+    finally:
+        _cabi.set_option("icp_use_lds", 1)
+    assert np.array_equal(out[0][0], out[1][0])  # same assignment of points to groups, same order of sums
+    for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
+        assert out[0][1][k] == out[1][1][k], k
+    To = O.Registration(500, 1e-4).align_points_to_map(src, o, guess, 3.0, 1.0)
+    dt, dr = pose_error(To, out[0][0])
+    assert dt < TIGHT and dr < TIGHT
+
+
+# ---- robustness ---------------------------------------------------------------------------------------------
+def test_two_pipelines_on_one_gpu_from_two_threads(gpu, O):
+    """two LiDAR streams, two pipelines, two host threads, ONE GPU: the persistent registration kernels of the
+    two handles must not interleave (each needs all its workgroups resident); the per-device launch gate orders
+    them and both trajectories are those of a pipeline running alone"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    n_frames = 10
+    data = [[kitti_like(seed=s, n_frames=n_frames)[i][0] for i in range(n_frames)] for s in (20, 21)]
+    alone = []
+    for scans in data:
+        k = _pipe(deskew=False)
+        for s in scans:
+            k.register_frame_async(s)
+        k.sync()
+        alone.append(k.synced_poses())
+    results, errors = [None, None], []
+
+    def drive(j):
+        try:
+            k = _pipe(deskew=False)
+            for s in data[j]:
+                k.register_frame_async(s)
+            k.sync()
+            results[j] = k.synced_poses()
+        except Exception as e:  # noqa: BLE001
+            errors.append((j, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(j,)) for j in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for j in range(2):
+        assert np.array_equal(results[j], alone[j]), j
+
+
+def test_a_registration_that_gives_up_is_replayed(gpu, O):
+    """a launch whose workgroups never become co-resident gives up after a bounded spin and commits nothing;
+    the synchronous entry then runs the frame again on half as many workgroups.  (Injected through the
+    icp_inject_timeout test hook: the real thing takes seconds per occurrence.)"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=9, n_frames=5, beams=32, azimuth_steps=512)
+    ko = O.KissICP(deskew=0)
+    _cabi.set_option("icp_inject_timeout", 2)  # the first two registrations of the next pipeline give up
+    try:
+        kg = _pipe(deskew=False)
+    finally:
+        _cabi.set_option("icp_inject_timeout", 0)
+    for i in range(5):
+        pts = ds[i][0]
+        kg.register_frame(pts)  # frame 0: the map is empty, but the launch still happens and gives up twice
+        ko.register_frame(pts, np.array([]))
+        dt, dr = pose_error(ko.last_pose, kg.last_pose)
+        assert dt < TIGHT and dr < TIGHT, (i, dt, dr)
+        assert kg.local_map.num_voxels() == ko.local_map.num_voxels(), i
+    # with frames queued BEHIND the one that gave up, the caller is told (the scans are gone) and can go on
+    _cabi.set_option("icp_inject_timeout", 1)
+    try:
+        kq = _pipe(deskew=False)
+    finally:
+        _cabi.set_option("icp_inject_timeout", 0)
+    kq.register_frame_async(ds[0][0])
+    kq.register_frame_async(ds[1][0])
+    with pytest.raises(_cabi.KicpError) as e:
+        kq.sync()
+    assert e.value.status == 6
+    ko2 = O.KissICP(deskew=0)
+    for i in range(3):  # re-submitted from the start: the pipeline state was left untouched
+        kq.register_frame(ds[i][0])
+        ko2.register_frame(ds[i][0], np.array([]))
+    dt, dr = pose_error(ko2.last_pose, kq.last_pose)
+    assert dt < TIGHT and dr < TIGHT
