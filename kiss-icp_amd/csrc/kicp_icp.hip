@@ -197,21 +197,24 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             double d2;
             int E;
             if (cached) {
-                WindowGeom g;
-                g.lo0 = meta->lo[0];
-                g.lo1 = meta->lo[1];
-                g.lo2 = meta->lo[2];
-                const int n0 = meta->hi[0] - g.lo0 + 1;
-                g.n1 = meta->hi[1] - g.lo1 + 1;
-                g.n2 = meta->hi[2] - g.lo2 + 1;
-                g.dx = vx - meta->v[0];
-                g.dy = vy - meta->v[1];
-                g.dz = vz - meta->v[2];
-                const int W = n0 * g.n1 * g.n2;
-                // one code path for exact and widened windows: the two groups of a wave would otherwise
-                // run their scans one after the other whenever they differ
-                d2 = scan_window<true>(pool + meta->base, meta->E, W, g, s[0], s[1], s[2], lane, nn, E);
-                if (path == 0 && W != 27) path = 1;
+                // the staged keys belong to one voxel offset of the query inside its window; a query that has
+                // crossed into another voxel (a few times per launch at most) gets them recomputed
+                const int dx = vx - meta->v[0], dy = vy - meta->v[1], dz = vz - meta->v[2];
+                if (dx != meta->d[0] || dy != meta->d[1] || dz != meta->d[2]) {
+                    WindowGeom g;
+                    g.lo0 = meta->lo[0];
+                    g.lo1 = meta->lo[1];
+                    g.lo2 = meta->lo[2];
+                    g.n1 = meta->hi[1] - g.lo1 + 1;
+                    g.n2 = meta->hi[2] - g.lo2 + 1;
+                    g.dx = dx;
+                    g.dy = dy;
+                    g.dz = dz;
+                    window_rekey(pool + meta->base, meta->E, g, lane, meta);
+                }
+                E = meta->examined;
+                d2 = scan_keys(pool + meta->base, meta->E, s[0], s[1], s[2], lane, nn);
+                if (path == 0 && (meta->hi[0] - meta->lo[0]) * (meta->hi[1] - meta->lo[1]) * (meta->hi[2] - meta->lo[2]) != 8) path = 1;
             } else {
                 const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
                 E = pr.E;

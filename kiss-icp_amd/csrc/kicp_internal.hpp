@@ -174,7 +174,9 @@ struct IcpRegionMeta {
     int cap;      // doubles the region owns
     int valid;    // window complete
     signed char lo[3], hi[3];  // window extent per axis, in voxels relative to v (-2..-1, 1..2)
-    char pad[6];
+    signed char d[3];          // voxel of the query relative to v for which the staged keys were computed
+    char pad;
+    unsigned short examined;   // staged points inside the query's 27 voxels for that offset
 };
 static_assert(sizeof(IcpRegionMeta) == 64, "keep the candidate pool 16-byte aligned");
 

@@ -35,10 +35,26 @@ __device__ __forceinline__ Slot load_slot(const Slot *p) {
     return s;
 }
 
-// block id (and stored point count) of a voxel, or -1
+// block id (and stored point count) of a voxel, or -1.  Linear probing; the first kProbeAhead slots of the
+// chain are loaded TOGETHER (they share one or two cache lines), so that a lookup is one memory round
+// trip however the chain happens to fall: with 27..64 independent lookups per query and a wave waiting for
+// its slowest lane, dependent probe steps were the longest part of a window fill.
+constexpr int kProbeAhead = 4;
 __device__ __forceinline__ int map_find(const MapView &m, unsigned long long key, int &count) {
     uint32_t s = hash_key(key, m.mask);
-    for (uint32_t probes = 0; probes <= m.mask; ++probes) {
+    Slot a[kProbeAhead];
+#pragma unroll
+    for (int i = 0; i < kProbeAhead; ++i) a[i] = load_slot(m.slots + ((s + i) & m.mask));
+#pragma unroll
+    for (int i = 0; i < kProbeAhead; ++i) {
+        if (a[i].key == key) {
+            count = a[i].count;
+            return a[i].block;
+        }
+        if (a[i].key == kKeyEmpty) return -1;
+    }
+    s = (s + kProbeAhead) & m.mask;
+    for (uint32_t probes = kProbeAhead; probes <= m.mask; ++probes) {
         const Slot sl = load_slot(m.slots + s);
         if (sl.key == key) {
             count = sl.count;
@@ -312,38 +328,66 @@ __device__ __forceinline__ double scan_lds(const double *cand, int stride, int E
 constexpr double kWindowMargin = 0.125;  // fraction of a voxel
 constexpr int kFillChunk = 12;            // voxels whose points are in flight together during a fill
 
-// first probe of two independent keys issued together, then each chain resolved
+// two independent lookups, the first kProbeAhead slots of both chains in flight together
 __device__ __forceinline__ void map_find_pair(const MapView &m, bool ok0, unsigned long long key0, bool ok1,
                                               unsigned long long key1, int &blk0, int &cnt0, int &blk1,
                                               int &cnt1) {
-    uint32_t s0 = hash_key(key0, m.mask), s1 = hash_key(key1, m.mask);
-    Slot a, b;
-    a.key = b.key = kKeyEmpty;
-    a.block = b.block = -1;
-    a.count = b.count = 0;
-    if (ok0) a = load_slot(m.slots + s0);
-    if (ok1) b = load_slot(m.slots + s1);
+    const uint32_t s0 = hash_key(key0, m.mask), s1 = hash_key(key1, m.mask);
+    Slot a[kProbeAhead], b[kProbeAhead];
+#pragma unroll
+    for (int i = 0; i < kProbeAhead; ++i) {
+        a[i].key = b[i].key = kKeyEmpty;
+        a[i].block = b[i].block = -1;
+        a[i].count = b[i].count = 0;
+        if (ok0) a[i] = load_slot(m.slots + ((s0 + i) & m.mask));
+        if (ok1) b[i] = load_slot(m.slots + ((s1 + i) & m.mask));
+    }
     blk0 = blk1 = -1;
     cnt0 = cnt1 = 0;
-    for (uint32_t probes = 0; ok0 && probes <= m.mask; ++probes) {
-        if (a.key == key0) {
-            blk0 = a.block;
-            cnt0 = a.count;
-            break;
+    bool done0 = !ok0, done1 = !ok1;
+#pragma unroll
+    for (int i = 0; i < kProbeAhead; ++i) {
+        if (!done0) {
+            if (a[i].key == key0) {
+                blk0 = a[i].block;
+                cnt0 = a[i].count;
+                done0 = true;
+            } else if (a[i].key == kKeyEmpty) {
+                done0 = true;
+            }
         }
-        if (a.key == kKeyEmpty) break;
-        s0 = (s0 + 1) & m.mask;
-        a = load_slot(m.slots + s0);
+        if (!done1) {
+            if (b[i].key == key1) {
+                blk1 = b[i].block;
+                cnt1 = b[i].count;
+                done1 = true;
+            } else if (b[i].key == kKeyEmpty) {
+                done1 = true;
+            }
+        }
     }
-    for (uint32_t probes = 0; ok1 && probes <= m.mask; ++probes) {
-        if (b.key == key1) {
-            blk1 = b.block;
-            cnt1 = b.count;
+    // a chain longer than kProbeAhead (rare at load factor <= 1/2): one slot at a time
+    uint32_t s = (s0 + kProbeAhead) & m.mask;
+    for (uint32_t probes = kProbeAhead; !done0 && probes <= m.mask; ++probes) {
+        const Slot sl = load_slot(m.slots + s);
+        if (sl.key == key0) {
+            blk0 = sl.block;
+            cnt0 = sl.count;
             break;
         }
-        if (b.key == kKeyEmpty) break;
-        s1 = (s1 + 1) & m.mask;
-        b = load_slot(m.slots + s1);
+        if (sl.key == kKeyEmpty) break;
+        s = (s + 1) & m.mask;
+    }
+    s = (s1 + kProbeAhead) & m.mask;
+    for (uint32_t probes = kProbeAhead; !done1 && probes <= m.mask; ++probes) {
+        const Slot sl = load_slot(m.slots + s);
+        if (sl.key == key1) {
+            blk1 = sl.block;
+            cnt1 = sl.count;
+            break;
+        }
+        if (sl.key == kKeyEmpty) break;
+        s = (s + 1) & m.mask;
     }
     if (blk0 < 0) cnt0 = 0;
     if (blk1 < 0) cnt1 = 0;
@@ -356,7 +400,15 @@ __device__ __forceinline__ void group_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ int region_doubles(int E) { return 3 * E + (E + 3) / 4; }
+// doubles of a region of E candidates: X[E] Y[E] Z[E], then 16-bit tags T[E] and 16-bit keys K[E]
+__device__ __forceinline__ int region_doubles(int E) { return 3 * E + 2 * ((E + 3) / 4); }
+__device__ __forceinline__ unsigned short *region_tags(double *region, int E) {
+    return reinterpret_cast<unsigned short *>(region + 3 * E);
+}
+__device__ __forceinline__ unsigned short *region_keys(double *region, int E) {
+    return reinterpret_cast<unsigned short *>(region + 3 * E + (E + 3) / 4);
+}
+constexpr int kKeyOutside = 0xFFFF;  // key of a staged point that is not in the query's 27 voxels
 
 // Stage the (widened) neighbourhood of the query s (voxel v) into an LDS region described by *meta;
 // `cells` is this group's scratch of 64 int2.  Returns false when the workgroup's pool is exhausted
@@ -375,22 +427,25 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
     const int W = nn[0] * nn[1] * nn[2];  // <= 64
     bool ok[2];
     unsigned long long key[2];
-    int code[2];
+    int code[2], so[2];  // cell number in window order; position in the reference's shift table (31: not one of the 27)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int w = lane + 32 * h;
         ok[h] = false;
         key[h] = 0;
         code[h] = 0;
+        so[h] = 31;
         if (w < W) {
             const int iz = w % nn[2], t = w / nn[2], iy = t % nn[1], ix = t / nn[1];
             const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
             const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
             code[h] = w;  // cell number in window order (x-major, z fastest)
+            const bool core = ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1;
+            if (core) so[h] = shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1));
             if (voxel_in_range(qx, qy, qz)) {
                 ok[h] = true;
                 key[h] = pack_voxel(qx, qy, qz);
-            } else if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) {
+            } else if (core) {
                 range_err = 1;
             }
         }
@@ -409,8 +464,12 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
     }
     const int tot0 = __shfl(incl0, 31, 32);
     const int E = tot0 + __shfl(incl1, 31, 32);
-    cells[lane] = make_int2(blk[0], cnt[0] | ((incl0 - cnt[0]) << 6) | (code[0] << 18));
-    cells[lane + 32] = make_int2(blk[1], cnt[1] | ((tot0 + incl1 - cnt[1]) << 6) | (code[1] << 18));
+    // points the reference examines from here: those of the 27 voxels around v
+    int core_pts = (so[0] != 31 ? cnt[0] : 0) + (so[1] != 31 ? cnt[1] : 0);
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) core_pts += __shfl_xor(core_pts, off, 32);
+    cells[lane] = make_int2(blk[0], cnt[0] | ((incl0 - cnt[0]) << 6) | (code[0] << 18) | (so[0] << 24));
+    cells[lane + 32] = make_int2(blk[1], cnt[1] | ((tot0 + incl1 - cnt[1]) << 6) | (code[1] << 18) | (so[1] << 24));
     // a region of exactly E candidates: reuse the old allocation when it is large enough,
     // otherwise take a new one from the workgroup's pool (never freed within a launch)
     const int need = region_doubles(E);
@@ -436,7 +495,7 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
         cap = need;
     }
     double *X = pool + base, *Y = X + E, *Z = Y + E;
-    unsigned short *T = reinterpret_cast<unsigned short *>(Z + E);
+    unsigned short *T = region_tags(X, E), *K = region_keys(X, E);
     group_lds_sync();  // cells[] visible to the whole group
     const int half_shift = threadIdx.x & 32;
     unsigned long long hits = (unsigned long long)(unsigned)(__ballot(blk[0] >= 0) >> half_shift) |
@@ -467,6 +526,8 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
                 Y[c] = xy[u].y;
                 Z[c] = zz[u];
                 T[c] = (unsigned short)(((info[u] >> 18) & 63) | (lane << 6));  // {cell, index in voxel}
+                const int so_c = (info[u] >> 24) & 31;  // the query sits in the window's centre voxel right now
+                K[c] = (unsigned short)(so_c == 31 ? kKeyOutside : ((so_c << 5) | lane));
             }
         }
     }
@@ -484,6 +545,8 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
         meta->base = base;
         meta->cap = cap;
         meta->valid = 1;
+        meta->d[0] = meta->d[1] = meta->d[2] = 0;
+        meta->examined = (unsigned short)core_pts;
     }
     group_lds_sync();  // candidates and meta visible to the whole group
     return true;
@@ -510,71 +573,73 @@ __device__ __forceinline__ int tag_order_key(int tag, const WindowGeom &g) {
     return (cell_shift_order(tag & 63, g) << 5) | ((tag >> 6) & 31);
 }
 
-// Returns the squared distance (DBL_MAX: no candidate), the neighbour, and the number of map points
-// in the query's 27-voxel neighbourhood (= points the reference examines).  Four candidates per
-// lane are in flight per trip (all LDS reads issued before the first use), no divergent control
-// flow on the common path: the reference's tie rules (strict '<' in shift order, then
-// std::min_element's first minimum) only cost anything when two distances are EQUAL.
-//   FILTER = false: the window is exactly the query's 27 voxels (no widened side, d = 0).
-template <bool FILTER>
-__device__ __forceinline__ double scan_window(const double *region, int E, int W, const WindowGeom &g, double sx,
-                                              double sy, double sz, int lane, double nn[3], int &examined) {
+// The query has moved to another voxel of its (widened) window: recompute every staged point's key for
+// the new offset g.d* -- {position of its voxel in the reference's shift table seen from the query, index
+// inside the voxel}, or kKeyOutside when the voxel is not one of the query's 27 -- and the number of points
+// the reference would examine.  Happens a few times per query and launch; the per-iteration scan then
+// needs neither the window geometry nor the tags.
+__device__ __forceinline__ void window_rekey(double *region, int E, const WindowGeom &g, int lane, IcpRegionMeta *meta) {
+    const unsigned short *T = region_tags(region, E);
+    unsigned short *K = region_keys(region, E);
+    int inside = 0;
+    for (int c = lane; c < E; c += 32) {
+        const int tag = T[c];
+        const int w = tag & 63;
+        const int t = div34(w, g.n2), iz = w - t * g.n2;
+        const int ix = div34(t, g.n1), iy = t - ix * g.n1;
+        const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
+        const bool in = (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
+        K[c] = (unsigned short)(in ? ((shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)) << 5) | ((tag >> 6) & 31)) : kKeyOutside);
+        inside += in ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) inside += __shfl_xor(inside, off, 32);
+    if (lane == 0) {
+        meta->d[0] = (signed char)g.dx;
+        meta->d[1] = (signed char)g.dy;
+        meta->d[2] = (signed char)g.dz;
+        meta->examined = (unsigned short)inside;
+    }
+    group_lds_sync();
+}
+
+// GetClosestNeighbor over a staged window whose keys are current: 32 lanes stride over the packed list, four
+// candidates per lane in flight per trip, no divergent control flow.  Strict '<' in shift order, then
+// std::min_element's first minimum inside a voxel (VoxelHashMap.cpp:55-63) = the lexicographic minimum of
+// (squared distance, key); keys only matter when two distances are EQUAL.
+__device__ __forceinline__ double scan_keys(const double *region, int E, double sx, double sy, double sz, int lane,
+                                            double nn[3]) {
     constexpr int U = 4;
     const double *X = region, *Y = X + E, *Z = Y + E;
-    const unsigned short *T = reinterpret_cast<const unsigned short *>(Z + E);
-    const int half_shift = threadIdx.x & 32;
-    unsigned long long inmask = ~0ull;
-    if (FILTER) {  // which cells of the window belong to the query's 27 voxels: lane j answers for cells j, j + 32
-        bool in[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int w = lane + 32 * h;
-            const int t = div34(w, g.n2), iz = w - t * g.n2;
-            const int ix = div34(t, g.n1), iy = t - ix * g.n1;
-            const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
-            in[h] = w < W && (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
-        }
-        inmask = (unsigned long long)(unsigned)(__ballot(in[0]) >> half_shift) |
-                 ((unsigned long long)(unsigned)(__ballot(in[1]) >> half_shift) << 32);
-    }
+    const unsigned short *K = region_keys(const_cast<double *>(region), E);
     double best = DBL_MAX;
-    int bc = -1, btag = 0, inside = 0;
-    for (int c0 = lane; __ballot(c0 < E) != 0ull; c0 += 32 * U) {  // wave-uniform trip count (ballots inside)
-        int tag[U];
+    int bkey = kKeyOutside, bc = -1;
+    for (int c0 = lane; __ballot(c0 < E) != 0ull; c0 += 32 * U) {  // wave-uniform trip count
+        int key[U];
         double x[U], y[U], z[U];
-        bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = c0 + 32 * u;
-            ok[u] = c < E;
-            const int cc = ok[u] ? c : 0;
-            tag[u] = ok[u] ? (int)T[cc] : 0;
+            const bool ok = c < E;
+            const int cc = ok ? c : 0;
+            const int k = (int)K[cc];
+            key[u] = ok ? k : kKeyOutside;
             x[u] = X[cc];
             y[u] = Y[cc];
             z[u] = Z[cc];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool v = ok[u] && (!FILTER || ((inmask >> (tag[u] & 63)) & 1ull));
-            if (FILTER) inside += __popc((unsigned)(__ballot(v) >> half_shift));
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
             const double d = (ex * ex + ey * ey) + ez * ez;
-            if (v && d <= best) {
-                bool take = d < best;
-                if (!take) take = tag_order_key(tag[u], g) < tag_order_key(btag, g);  // exact tie (rare)
-                if (take) {
-                    best = d;
-                    bc = c0 + 32 * u;
-                    btag = tag[u];
-                }
-            }
+            const bool take = key[u] != kKeyOutside && (d < best || (d == best && key[u] < bkey));
+            best = take ? d : best;
+            bkey = take ? key[u] : bkey;
+            bc = take ? c0 + 32 * u : bc;
         }
     }
-    examined = FILTER ? inside : E;
-    // lexicographic min over (distance, reference order) across the 32 lanes; the winner's
-    // coordinates are then read back from LDS by every lane (same address: broadcast)
-    int bkey = bc >= 0 ? tag_order_key(btag, g) : 0x7FFFFFFF;
-    group_min(best, bkey, bc);
+    int gkey = bc >= 0 ? bkey : 0x7FFFFFFF;
+    group_min(best, gkey, bc);
     const int rc = bc >= 0 ? bc : 0;
     nn[0] = E > 0 ? X[rc] : 0.0;
     nn[1] = E > 0 ? Y[rc] : 0.0;
