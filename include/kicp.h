@@ -273,8 +273,10 @@ int kicp_device_synchronize(int device_id);
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
  *   "icp_lds_kib"     LDS per ICP workgroup in KiB, 64..160 (0 = all 160: one workgroup per CU)
  *   "icp_reserve_cus" CUs left out of the ICP grid for the front stages of the next frame, which run
- *                     concurrently on a second stream (default 16; the grid is the device's co-resident
- *                     maximum minus this)
+ *                     concurrently on a second stream (default 32 = one per shader engine: workgroups are
+ *                     handed to the shader engines in turn, so a kernel whose next workgroup falls on a
+ *                     full engine waits even when other engines have room; the grid is the device's
+ *                     co-resident maximum minus this)
  *   "staging_threads" helper threads (besides the caller) that copy a host scan into pinned memory (default 3)
  *   "staging_f32"     1 = narrow float64 host scans to float32 for the upload when lossless (default 1)
  *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if

@@ -197,23 +197,24 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             double d2;
             int E;
             if (cached) {
-                // the staged keys belong to one voxel offset of the query inside its window; a query that has
-                // crossed into another voxel (a few times per launch at most) gets them recomputed
+                // the scan list belongs to one voxel offset of the query inside its window; a query that has
+                // crossed into another voxel (a few times per launch at most) gets it rebuilt
                 const int dx = vx - meta->v[0], dy = vy - meta->v[1], dz = vz - meta->v[2];
                 if (dx != meta->d[0] || dy != meta->d[1] || dz != meta->d[2]) {
                     WindowGeom g;
                     g.lo0 = meta->lo[0];
                     g.lo1 = meta->lo[1];
                     g.lo2 = meta->lo[2];
+                    g.n0 = meta->hi[0] - g.lo0 + 1;
                     g.n1 = meta->hi[1] - g.lo1 + 1;
                     g.n2 = meta->hi[2] - g.lo2 + 1;
                     g.dx = dx;
                     g.dy = dy;
                     g.dz = dz;
-                    window_rekey(pool + meta->base, meta->E, g, lane, meta);
+                    window_index(pool + meta->base, meta->E, g, lane, reinterpret_cast<int *>(sh.cells[grp]), meta);
                 }
                 E = meta->examined;
-                d2 = scan_keys(pool + meta->base, meta->E, s[0], s[1], s[2], lane, nn);
+                d2 = scan_list(pool + meta->base, meta->E, E, s[0], s[1], s[2], lane, nn);
                 if (path == 0 && (meta->hi[0] - meta->lo[0]) * (meta->hi[1] - meta->lo[1]) * (meta->hi[2] - meta->lo[2]) != 8) path = 1;
             } else {
                 const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
@@ -281,37 +282,148 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
             granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
         }
-        // ---- gather every workgroup's partial (bounded spin) --------------------------------
+        // ---- exchange: workgroup 0 gathers every partial, solves, and broadcasts the update --------------
+        // (Every workgroup gathering every partial -- G x G x 304 bytes of agent-scope loads per iteration --
+        // costs more than a second hop once G reaches a few dozen: at 240 workgroups the all-gather moved
+        // 17.5 MB per iteration and took ~5 us; this way 73 KB go to one workgroup and 128 bytes come back.)
         const unsigned c2 = PROF ? ticks32() : 0u;
-        if (tid < kIcpParts * kIcpSums) {
-            // thread (k, part) sums scalar k over a contiguous range of workgroups, in order.  All the
-            // granules of the range (up to kGatherChunk workgroups x 2) are in flight together; every
-            // further pass re-polls, again together, exactly the ones whose tag has not arrived yet:
-            // one memory round trip per pass, however many granules are late.
-            constexpr int kGatherChunk = 10;  // >= ceil(256 / kIcpParts): one chunk per thread for any grid
-            const int k = tid % kIcpSums, part = tid / kIcpSums;
-            const int b0 = (G * part) / kIcpParts, b1 = (G * (part + 1)) / kIcpParts;
-            double v = 0.0;
-            bool fail = false;
-            for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
-                unsigned long long lo[kGatherChunk], hi[kGatherChunk];
-                const unsigned long long *g0 = gran + ((size_t)b * kIcpSums + k) * 2;
-                unsigned pending = 0;
-#pragma unroll
-                for (int u = 0; u < kGatherChunk; ++u) {
-                    lo[u] = hi[u] = 0ull;
-                    if (b + u < b1) {
-                        lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
-                        hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
-                        pending |= 1u << u;
+        unsigned long long *est_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpSums) + (size_t)(it & 1) * 16;
+        unsigned c3 = c2;
+        double nrm2 = 0.0;
+        if (blockIdx.x == 0) {
+            if (tid < kIcpParts * kIcpSums) {
+                // thread (k, part) sums scalar k over a contiguous range of workgroups, in order.  All the
+                // granules of the range (up to kGatherChunk workgroups x 2) are in flight together; every
+                // further pass re-polls, again together, exactly the ones whose tag has not arrived yet:
+                // one memory round trip per pass, however many granules are late.
+                constexpr int kGatherChunk = 10;  // >= ceil(256 / kIcpParts): one chunk per thread for any grid
+                const int k = tid % kIcpSums, part = tid / kIcpSums;
+                const int b0 = (G * part) / kIcpParts, b1 = (G * (part + 1)) / kIcpParts;
+                double v = 0.0;
+                bool fail = false;
+                for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
+                    unsigned long long lo[kGatherChunk], hi[kGatherChunk];
+                    const unsigned long long *g0 = gran + ((size_t)b * kIcpSums + k) * 2;
+                    unsigned pending = 0;
+    #pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u) {
+                        lo[u] = hi[u] = 0ull;
+                        if (b + u < b1) {
+                            lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
+                            hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                            pending |= 1u << u;
+                        }
                     }
+    #pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u)
+                        if ((unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch) pending &= ~(1u << u);
+                    unsigned spins = 0;
+                    while (pending) {
+                        if (PROF) ++gather_passes;
+                        if (++spins > P.spin_limit ||
+                            ((spins & 255u) == 0 &&
+                             (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
+                            fail = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+    #pragma unroll
+                        for (int u = 0; u < kGatherChunk; ++u)
+                            if ((pending >> u) & 1u) {
+                                lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
+                                hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                            }
+    #pragma unroll
+                        for (int u = 0; u < kGatherChunk; ++u)
+                            if (((pending >> u) & 1u) && (unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch)
+                                pending &= ~(1u << u);
+                    }
+                    if (fail) break;
+    #pragma unroll
+                    for (int u = 0; u < kGatherChunk; ++u)
+                        if (b + u < b1) {
+                            const double pv = __longlong_as_double(
+                                (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
+                            v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+                        }
                 }
-#pragma unroll
-                for (int u = 0; u < kGatherChunk; ++u)
-                    if ((unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch) pending &= ~(1u << u);
+                sh.range_sum[part][k] = v;
+                if (fail) sh.fail = 1;
+            }
+            __syncthreads();
+            if (sh.fail) {
+                // tell the waiting workgroups at once (they check the error word while they spin)
+                if (tid == 0) atomicOr(&st->err, E_TIMEOUT);
+                failed = true;
+                break;
+            }
+            if (tid < kIcpSums) {
+                double v = 0.0;
+    #pragma unroll
+                for (int part = 0; part < kIcpParts; ++part) {
+                    const double pv = sh.range_sum[part][tid];
+                    v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+                }
+                sh.tot[tid] = v;
+            }
+            __syncthreads();
+            __syncthreads();
+            // ---- waves 0..3 (one per SIMD) solve the same system; the result goes through LDS -----
+            c3 = PROF ? ticks32() : 0u;
+            if (tid < kIcpSolveThreads) {
+                double S[kIcpSums];
+    #pragma unroll
+                for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
+                double JTJ[36], nb[6], dx[6];
+    #pragma unroll
+                for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+                JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+                // top-right block sum w * (-hat(s)) and its transpose
+                JTJ[0 * 6 + 4] = S[3];
+                JTJ[0 * 6 + 5] = -S[2];
+                JTJ[1 * 6 + 3] = -S[3];
+                JTJ[1 * 6 + 5] = S[1];
+                JTJ[2 * 6 + 3] = S[2];
+                JTJ[2 * 6 + 4] = -S[1];
+                JTJ[4 * 6 + 0] = S[3];
+                JTJ[5 * 6 + 0] = -S[2];
+                JTJ[3 * 6 + 1] = -S[3];
+                JTJ[5 * 6 + 1] = S[1];
+                JTJ[3 * 6 + 2] = S[2];
+                JTJ[4 * 6 + 2] = -S[1];
+                JTJ[3 * 6 + 3] = S[4];
+                JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+                JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+                JTJ[4 * 6 + 4] = S[7];
+                JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+                JTJ[5 * 6 + 5] = S[9];
+    #pragma unroll
+                for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+                ldlt6_solve(JTJ, nb, dx);
+                est = se3_exp(dx);
+    #pragma unroll
+                for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
+                if (tid == 0) {
+                    sh.est[0] = est.q[0];
+                    sh.est[1] = est.q[1];
+                    sh.est[2] = est.q[2];
+                    sh.est[3] = est.q[3];
+                    sh.est[4] = est.t[0];
+                    sh.est[5] = est.t[1];
+                    sh.est[6] = est.t[2];
+                    sh.est[7] = nrm2;
+                }
+            }
+            if (tid < 64) {  // the update, as 16 tagged granules: thread 0 has just put it in LDS (same wave)
+                group_lds_sync();
+                if (tid < 16) granule_store(est_gran + tid, epoch, reinterpret_cast<const unsigned *>(sh.est)[tid]);
+            }
+        } else {
+            if (tid < 16) {
+                unsigned long long g = granule_load(est_gran + tid);
                 unsigned spins = 0;
-                while (pending) {
-                    if (PROF) ++gather_passes;
+                bool fail = false;
+                while ((unsigned)(g >> 32) != epoch) {
                     if (++spins > P.spin_limit ||
                         ((spins & 255u) == 0 &&
                          (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
@@ -319,93 +431,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                    for (int u = 0; u < kGatherChunk; ++u)
-                        if ((pending >> u) & 1u) {
-                            lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
-                            hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
-                        }
-#pragma unroll
-                    for (int u = 0; u < kGatherChunk; ++u)
-                        if (((pending >> u) & 1u) && (unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch)
-                            pending &= ~(1u << u);
+                    g = granule_load(est_gran + tid);
                 }
-                if (fail) break;
-#pragma unroll
-                for (int u = 0; u < kGatherChunk; ++u)
-                    if (b + u < b1) {
-                        const double pv = __longlong_as_double(
-                            (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
-                        v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-                    }
+                reinterpret_cast<unsigned *>(sh.est)[tid] = (unsigned)g;  // little-endian halves of est[0..7]
+                if (fail) sh.fail = 1;
             }
-            sh.range_sum[part][k] = v;
-            if (fail) sh.fail = 1;
         }
         __syncthreads();
         if (sh.fail) {
             failed = true;
             break;
         }
-        if (tid < kIcpSums) {
-            double v = 0.0;
-#pragma unroll
-            for (int part = 0; part < kIcpParts; ++part) {
-                const double pv = sh.range_sum[part][tid];
-                v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-            }
-            sh.tot[tid] = v;
-        }
-        __syncthreads();
-        // ---- waves 0..3 (one per SIMD) solve the same system; the result goes through LDS -----
-        const unsigned c3 = PROF ? ticks32() : 0u;
-        double nrm2 = 0.0;
-        if (tid < kIcpSolveThreads) {
-            double S[kIcpSums];
-#pragma unroll
-            for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
-            double JTJ[36], nb[6], dx[6];
-#pragma unroll
-            for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
-            JTJ[0] = JTJ[7] = JTJ[14] = S[0];
-            // top-right block sum w * (-hat(s)) and its transpose
-            JTJ[0 * 6 + 4] = S[3];
-            JTJ[0 * 6 + 5] = -S[2];
-            JTJ[1 * 6 + 3] = -S[3];
-            JTJ[1 * 6 + 5] = S[1];
-            JTJ[2 * 6 + 3] = S[2];
-            JTJ[2 * 6 + 4] = -S[1];
-            JTJ[4 * 6 + 0] = S[3];
-            JTJ[5 * 6 + 0] = -S[2];
-            JTJ[3 * 6 + 1] = -S[3];
-            JTJ[5 * 6 + 1] = S[1];
-            JTJ[3 * 6 + 2] = S[2];
-            JTJ[4 * 6 + 2] = -S[1];
-            JTJ[3 * 6 + 3] = S[4];
-            JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
-            JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
-            JTJ[4 * 6 + 4] = S[7];
-            JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
-            JTJ[5 * 6 + 5] = S[9];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
-            ldlt6_solve(JTJ, nb, dx);
-            est = se3_exp(dx);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
-            if (tid == 0) {
-                sh.est[0] = est.q[0];
-                sh.est[1] = est.q[1];
-                sh.est[2] = est.q[2];
-                sh.est[3] = est.q[3];
-                sh.est[4] = est.t[0];
-                sh.est[5] = est.t[1];
-                sh.est[6] = est.t[2];
-                sh.est[7] = nrm2;
-            }
-        }
-        __syncthreads();
-        if (tid >= kIcpSolveThreads) {
+        if (blockIdx.x != 0 || tid >= kIcpSolveThreads) {
             est.q[0] = sh.est[0];
             est.q[1] = sh.est[1];
             est.q[2] = sh.est[2];
@@ -519,7 +556,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     }
 }
 
-size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums; }
+size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums + 32; }  // partials, then the update (2 x 16)
 
 int icp_prepare(int device_id) {
     // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute), once per

@@ -241,7 +241,7 @@ struct Options {
     long icp_groups = 16;        // groups per workgroup that take source points
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
     long icp_lds_kib = 0;        // dynamic LDS per ICP workgroup in KiB (0: all 160)
-    long icp_reserve_cus = 16;   // CUs left out of the ICP grid for the concurrent front stages of the next frame
+    long icp_reserve_cus = 32;   // CUs left out of the ICP grid (one per shader engine) for the front stages of the next frame
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once

@@ -40,30 +40,43 @@ __device__ __forceinline__ Slot load_slot(const Slot *p) {
 // trip however the chain happens to fall: with 27..64 independent lookups per query and a wave waiting for
 // its slowest lane, dependent probe steps were the longest part of a window fill.
 constexpr int kProbeAhead = 4;
-__device__ __forceinline__ int map_find(const MapView &m, unsigned long long key, int &count) {
-    uint32_t s = hash_key(key, m.mask);
-    Slot a[kProbeAhead];
-#pragma unroll
-    for (int i = 0; i < kProbeAhead; ++i) a[i] = load_slot(m.slots + ((s + i) & m.mask));
+// resolve a lookup over the slots already loaded: selects only (no early exit, so the loads stay together)
+__device__ __forceinline__ bool probe_resolve(const Slot (&a)[kProbeAhead], unsigned long long key, int &blk, int &cnt) {
+    bool done = false;
+    blk = -1;
+    cnt = 0;
 #pragma unroll
     for (int i = 0; i < kProbeAhead; ++i) {
-        if (a[i].key == key) {
-            count = a[i].count;
-            return a[i].block;
-        }
-        if (a[i].key == kKeyEmpty) return -1;
+        const bool hit = !done && a[i].key == key;
+        const bool end = !done && a[i].key == kKeyEmpty;
+        blk = hit ? a[i].block : blk;
+        cnt = hit ? a[i].count : cnt;
+        done = done || hit || end;
     }
-    s = (s + kProbeAhead) & m.mask;
+    return done;
+}
+// the rest of a chain longer than kProbeAhead (rare at load factor <= 1/2): one slot at a time
+__device__ __forceinline__ void probe_tail(const MapView &m, uint32_t s, unsigned long long key, int &blk, int &cnt) {
     for (uint32_t probes = kProbeAhead; probes <= m.mask; ++probes) {
         const Slot sl = load_slot(m.slots + s);
         if (sl.key == key) {
-            count = sl.count;
-            return sl.block;
+            blk = sl.block;
+            cnt = sl.count;
+            return;
         }
-        if (sl.key == kKeyEmpty) return -1;
+        if (sl.key == kKeyEmpty) return;
         s = (s + 1) & m.mask;
     }
-    return -1;
+}
+__device__ __forceinline__ int map_find(const MapView &m, unsigned long long key, int &count) {
+    const uint32_t s = hash_key(key, m.mask);
+    Slot a[kProbeAhead];
+#pragma unroll
+    for (int i = 0; i < kProbeAhead; ++i) a[i] = load_slot(m.slots + ((s + i) & m.mask));
+    int blk, cnt;
+    if (!probe_resolve(a, key, blk, cnt)) probe_tail(m, (s + kProbeAhead) & m.mask, key, blk, cnt);
+    count = cnt;
+    return blk;
 }
 
 // The 27 neighbour shifts in the reference's order (core/VoxelHashMap.cpp:35-41), two bits per
@@ -342,53 +355,10 @@ __device__ __forceinline__ void map_find_pair(const MapView &m, bool ok0, unsign
         if (ok0) a[i] = load_slot(m.slots + ((s0 + i) & m.mask));
         if (ok1) b[i] = load_slot(m.slots + ((s1 + i) & m.mask));
     }
-    blk0 = blk1 = -1;
-    cnt0 = cnt1 = 0;
-    bool done0 = !ok0, done1 = !ok1;
-#pragma unroll
-    for (int i = 0; i < kProbeAhead; ++i) {
-        if (!done0) {
-            if (a[i].key == key0) {
-                blk0 = a[i].block;
-                cnt0 = a[i].count;
-                done0 = true;
-            } else if (a[i].key == kKeyEmpty) {
-                done0 = true;
-            }
-        }
-        if (!done1) {
-            if (b[i].key == key1) {
-                blk1 = b[i].block;
-                cnt1 = b[i].count;
-                done1 = true;
-            } else if (b[i].key == kKeyEmpty) {
-                done1 = true;
-            }
-        }
-    }
-    // a chain longer than kProbeAhead (rare at load factor <= 1/2): one slot at a time
-    uint32_t s = (s0 + kProbeAhead) & m.mask;
-    for (uint32_t probes = kProbeAhead; !done0 && probes <= m.mask; ++probes) {
-        const Slot sl = load_slot(m.slots + s);
-        if (sl.key == key0) {
-            blk0 = sl.block;
-            cnt0 = sl.count;
-            break;
-        }
-        if (sl.key == kKeyEmpty) break;
-        s = (s + 1) & m.mask;
-    }
-    s = (s1 + kProbeAhead) & m.mask;
-    for (uint32_t probes = kProbeAhead; !done1 && probes <= m.mask; ++probes) {
-        const Slot sl = load_slot(m.slots + s);
-        if (sl.key == key1) {
-            blk1 = sl.block;
-            cnt1 = sl.count;
-            break;
-        }
-        if (sl.key == kKeyEmpty) break;
-        s = (s + 1) & m.mask;
-    }
+    const bool done0 = probe_resolve(a, key0, blk0, cnt0);
+    const bool done1 = probe_resolve(b, key1, blk1, cnt1);
+    if (!done0) probe_tail(m, (s0 + kProbeAhead) & m.mask, key0, blk0, cnt0);
+    if (!done1) probe_tail(m, (s1 + kProbeAhead) & m.mask, key1, blk1, cnt1);
     if (blk0 < 0) cnt0 = 0;
     if (blk1 < 0) cnt1 = 0;
 }
@@ -400,15 +370,85 @@ __device__ __forceinline__ void group_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// doubles of a region of E candidates: X[E] Y[E] Z[E], then 16-bit tags T[E] and 16-bit keys K[E]
-__device__ __forceinline__ int region_doubles(int E) { return 3 * E + 2 * ((E + 3) / 4); }
-__device__ __forceinline__ unsigned short *region_tags(double *region, int E) {
-    return reinterpret_cast<unsigned short *>(region + 3 * E);
+// ------------------------------------------------------------------------------------------
+// Staged windows.  A query's region (doubles out of its workgroup's pool) holds
+//   P[E]   the E map points of the window's voxels as xyz triples (24 bytes each), voxel after voxel in
+//          window order (x-major, z fastest);
+//   C[64]  per window cell {first point (bits 6..), points (bits 0..5)};
+//   I[..]  the SCAN LIST: positions (into P) of the points of the query's 27 voxels, in exactly the order the
+//          reference visits them (shift table VoxelHashMap.cpp:35-41, then index inside the voxel), 16 bits
+//          each.  The per-iteration search strides over this list and nothing else: no geometry, no tags, no
+//          filtering, and strict '<' alone reproduces the reference's tie rules because the list is in its
+//          order.  The list is rebuilt (from C, no HBM access) only when the query moves to another voxel of
+//          its window -- a few times per launch.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int region_doubles(int E) { return 3 * E + 32 + (E + 3) / 4; }
+__device__ __forceinline__ unsigned *region_cells(double *region, int E) {
+    return reinterpret_cast<unsigned *>(region + 3 * E);
 }
-__device__ __forceinline__ unsigned short *region_keys(double *region, int E) {
-    return reinterpret_cast<unsigned short *>(region + 3 * E + (E + 3) / 4);
+__device__ __forceinline__ unsigned short *region_list(double *region, int E) {
+    return reinterpret_cast<unsigned short *>(region + 3 * E + 32);
 }
-constexpr int kKeyOutside = 0xFFFF;  // key of a staged point that is not in the query's 27 voxels
+
+struct WindowGeom {
+    int lo0, lo1, lo2;  // window extent (voxels relative to the centre voxel), low corner
+    int n0, n1, n2;     // cells along x, y, z (3 or 4)
+    int dx, dy, dz;     // query voxel relative to the centre voxel
+};
+__device__ __forceinline__ int div34(int w, int n) { return n == 4 ? (w >> 2) : ((w * 43) >> 7); }  // w < 128
+
+// (Re)build the scan list of a region for the query offset g.d*; `scratch` = 32 ints of this group.
+// Lane l answers for the window cells l and l + 32.
+__device__ __forceinline__ void window_index(double *region, int E, const WindowGeom &g, int lane, int *scratch,
+                                             IcpRegionMeta *meta) {
+    const unsigned *C = region_cells(region, E);
+    unsigned short *I = region_list(region, E);
+    const int W = g.n0 * g.n1 * g.n2;
+    int so[2], cnt[2], off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int w = lane + 32 * h;
+        const unsigned c = C[w];
+        cnt[h] = (int)(c & 63u);
+        off[h] = (int)(c >> 6);
+        const int t = div34(w, g.n2), iz = w - t * g.n2;
+        const int ix = div34(t, g.n1), iy = t - ix * g.n1;
+        const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
+        const bool in = w < W && (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
+        so[h] = in ? shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)) : 31;
+    }
+    // point counts by position in the shift table -> where each voxel's run starts in the list
+    scratch[lane] = 0;
+    group_lds_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (so[h] != 31) scratch[so[h]] = cnt[h];  // the 27 positions are distinct cells
+    group_lds_sync();
+    const int mine = scratch[lane];  // entries 27..31 stay 0
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int up = __shfl_up(incl, o, 32);
+        if (lane >= o) incl += up;
+    }
+    const int examined = __shfl(incl, 31, 32);
+    group_lds_sync();  // everybody has read its count
+    scratch[lane] = incl - mine;
+    group_lds_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (so[h] != 31) {
+            const int k0 = scratch[so[h]];
+            for (int j = 0; j < cnt[h]; ++j) I[k0 + j] = (unsigned short)(off[h] + j);
+        }
+    if (lane == 0) {
+        meta->d[0] = (signed char)g.dx;
+        meta->d[1] = (signed char)g.dy;
+        meta->d[2] = (signed char)g.dz;
+        meta->examined = (unsigned short)examined;
+    }
+    group_lds_sync();
+}
 
 // Stage the (widened) neighbourhood of the query s (voxel v) into an LDS region described by *meta;
 // `cells` is this group's scratch of 64 int2.  Returns false when the workgroup's pool is exhausted
@@ -427,32 +467,26 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
     const int W = nn[0] * nn[1] * nn[2];  // <= 64
     bool ok[2];
     unsigned long long key[2];
-    int code[2], so[2];  // cell number in window order; position in the reference's shift table (31: not one of the 27)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int w = lane + 32 * h;
         ok[h] = false;
         key[h] = 0;
-        code[h] = 0;
-        so[h] = 31;
         if (w < W) {
             const int iz = w % nn[2], t = w / nn[2], iy = t % nn[1], ix = t / nn[1];
             const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
             const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
-            code[h] = w;  // cell number in window order (x-major, z fastest)
-            const bool core = ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1;
-            if (core) so[h] = shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1));
             if (voxel_in_range(qx, qy, qz)) {
                 ok[h] = true;
                 key[h] = pack_voxel(qx, qy, qz);
-            } else if (core) {
+            } else if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) {
                 range_err = 1;
             }
         }
     }
     int blk[2], cnt[2];
     map_find_pair(m, ok[0], key[0], ok[1], key[1], blk[0], cnt[0], blk[1], cnt[1]);
-    // candidate numbering: window order, cells 0..31 first
+    // staging order: window order, cells 0..31 first
     int incl0 = cnt[0], incl1 = cnt[1];
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1) {
@@ -464,13 +498,10 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
     }
     const int tot0 = __shfl(incl0, 31, 32);
     const int E = tot0 + __shfl(incl1, 31, 32);
-    // points the reference examines from here: those of the 27 voxels around v
-    int core_pts = (so[0] != 31 ? cnt[0] : 0) + (so[1] != 31 ? cnt[1] : 0);
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) core_pts += __shfl_xor(core_pts, off, 32);
-    cells[lane] = make_int2(blk[0], cnt[0] | ((incl0 - cnt[0]) << 6) | (code[0] << 18) | (so[0] << 24));
-    cells[lane + 32] = make_int2(blk[1], cnt[1] | ((tot0 + incl1 - cnt[1]) << 6) | (code[1] << 18) | (so[1] << 24));
-    // a region of exactly E candidates: reuse the old allocation when it is large enough,
+    const int offs0 = incl0 - cnt[0], offs1 = tot0 + incl1 - cnt[1];
+    cells[lane] = make_int2(blk[0], cnt[0] | (offs0 << 6));
+    cells[lane + 32] = make_int2(blk[1], cnt[1] | (offs1 << 6));
+    // a region of exactly E points: reuse the old allocation when it is large enough,
     // otherwise take a new one from the workgroup's pool (never freed within a launch)
     const int need = region_doubles(E);
     int base = meta->base, cap = meta->cap;
@@ -494,8 +525,10 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
         base = nb;
         cap = need;
     }
-    double *X = pool + base, *Y = X + E, *Z = Y + E;
-    unsigned short *T = region_tags(X, E), *K = region_keys(X, E);
+    double *P = pool + base;
+    unsigned *C = region_cells(P, E);
+    C[lane] = (unsigned)(cnt[0] | (offs0 << 6));
+    C[lane + 32] = (unsigned)(cnt[1] | (offs1 << 6));
     group_lds_sync();  // cells[] visible to the whole group
     const int half_shift = threadIdx.x & 32;
     unsigned long long hits = (unsigned long long)(unsigned)(__ballot(blk[0] >= 0) >> half_shift) |
@@ -521,13 +554,10 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
 #pragma unroll
         for (int u = 0; u < kFillChunk; ++u) {
             if (info[u] >= 0) {
-                const int c = ((info[u] >> 6) & 4095) + lane;
-                X[c] = xy[u].x;
-                Y[c] = xy[u].y;
-                Z[c] = zz[u];
-                T[c] = (unsigned short)(((info[u] >> 18) & 63) | (lane << 6));  // {cell, index in voxel}
-                const int so_c = (info[u] >> 24) & 31;  // the query sits in the window's centre voxel right now
-                K[c] = (unsigned short)(so_c == 31 ? kKeyOutside : ((so_c << 5) | lane));
+                double *q = P + 3 * ((info[u] >> 6) + lane);
+                q[0] = xy[u].x;
+                q[1] = xy[u].y;
+                q[2] = zz[u];
             }
         }
     }
@@ -545,105 +575,91 @@ __device__ __forceinline__ bool window_fill(const MapView &m, const double s[3],
         meta->base = base;
         meta->cap = cap;
         meta->valid = 1;
-        meta->d[0] = meta->d[1] = meta->d[2] = 0;
-        meta->examined = (unsigned short)core_pts;
     }
-    group_lds_sync();  // candidates and meta visible to the whole group
+    WindowGeom g;
+    g.lo0 = lo[0];
+    g.lo1 = lo[1];
+    g.lo2 = lo[2];
+    g.n0 = nn[0];
+    g.n1 = nn[1];
+    g.n2 = nn[2];
+    g.dx = g.dy = g.dz = 0;  // the query sits in the window's centre voxel right now
+    window_index(P, E, g, lane, reinterpret_cast<int *>(cells), meta);  // (ends with a group sync: points, cells, list, meta visible)
     return true;
 }
 
-// ---- scan of a staged window ---------------------------------------------------------------------
-// A staged point carries the tag {cell of its voxel in the window (6 bits), index inside the voxel
-// (5 bits)}.  The query sits in the voxel at offset d = (dx, dy, dz) from the window's centre voxel;
-// its candidates are the points whose cell lies in [d-1, d+1]^3 -- the reference's 27 voxels.
-struct WindowGeom {
-    int lo0, lo1, lo2;  // window extent (voxels relative to the centre voxel), low corner
-    int n1, n2;         // cells along y and z (3 or 4)
-    int dx, dy, dz;     // query voxel relative to the centre voxel
-};
-__device__ __forceinline__ int div34(int w, int n) { return n == 4 ? (w >> 2) : ((w * 43) >> 7); }  // w < 128
-// position of cell w's voxel in the reference's shift table (VoxelHashMap.cpp:35-41), seen from the query
-__device__ __forceinline__ int cell_shift_order(int w, const WindowGeom &g) {
-    const int t = div34(w, g.n2), iz = w - t * g.n2;
-    const int ix = div34(t, g.n1), iy = t - ix * g.n1;
-    const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
-    return shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1));
+// minimum of (distance, key) over the 32 lanes of a group, lexicographic; every lane ends with the winner.
+// Two all-reduces (DPP row operations + one swizzle each): the distance first, then the key among the lanes
+// that hold that distance.
+template <int STEP>
+__device__ __forceinline__ void group_fmin_step(double &v) {
+    const double o = group_xchg<STEP>(v);
+    v = o < v ? o : v;
 }
-__device__ __forceinline__ int tag_order_key(int tag, const WindowGeom &g) {
-    return (cell_shift_order(tag & 63, g) << 5) | ((tag >> 6) & 31);
+template <int STEP>
+__device__ __forceinline__ void group_imin_step(int &v) {
+    const int o = group_xchg<STEP>(v);
+    v = o < v ? o : v;
 }
-
-// The query has moved to another voxel of its (widened) window: recompute every staged point's key for
-// the new offset g.d* -- {position of its voxel in the reference's shift table seen from the query, index
-// inside the voxel}, or kKeyOutside when the voxel is not one of the query's 27 -- and the number of points
-// the reference would examine.  Happens a few times per query and launch; the per-iteration scan then
-// needs neither the window geometry nor the tags.
-__device__ __forceinline__ void window_rekey(double *region, int E, const WindowGeom &g, int lane, IcpRegionMeta *meta) {
-    const unsigned short *T = region_tags(region, E);
-    unsigned short *K = region_keys(region, E);
-    int inside = 0;
-    for (int c = lane; c < E; c += 32) {
-        const int tag = T[c];
-        const int w = tag & 63;
-        const int t = div34(w, g.n2), iz = w - t * g.n2;
-        const int ix = div34(t, g.n1), iy = t - ix * g.n1;
-        const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
-        const bool in = (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
-        K[c] = (unsigned short)(in ? ((shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)) << 5) | ((tag >> 6) & 31)) : kKeyOutside);
-        inside += in ? 1 : 0;
-    }
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) inside += __shfl_xor(inside, off, 32);
-    if (lane == 0) {
-        meta->d[0] = (signed char)g.dx;
-        meta->d[1] = (signed char)g.dy;
-        meta->d[2] = (signed char)g.dz;
-        meta->examined = (unsigned short)inside;
-    }
-    group_lds_sync();
+__device__ __forceinline__ void group_min_dist_key(double &best, int &key) {
+    double g = best;
+    group_fmin_step<0>(g);
+    group_fmin_step<1>(g);
+    group_fmin_step<2>(g);
+    group_fmin_step<3>(g);
+    group_fmin_step<4>(g);
+    int k = (best == g) ? key : 0x7FFFFFFF;
+    group_imin_step<0>(k);
+    group_imin_step<1>(k);
+    group_imin_step<2>(k);
+    group_imin_step<3>(k);
+    group_imin_step<4>(k);
+    best = g;
+    key = k;
 }
 
-// GetClosestNeighbor over a staged window whose keys are current: 32 lanes stride over the packed list, four
-// candidates per lane in flight per trip, no divergent control flow.  Strict '<' in shift order, then
-// std::min_element's first minimum inside a voxel (VoxelHashMap.cpp:55-63) = the lexicographic minimum of
-// (squared distance, key); keys only matter when two distances are EQUAL.
-__device__ __forceinline__ double scan_keys(const double *region, int E, double sx, double sy, double sz, int lane,
-                                            double nn[3]) {
+// GetClosestNeighbor over a staged window: 32 lanes stride over the scan list, four candidates per lane in
+// flight per trip, no divergent control flow.  A lane meets its candidates in the reference's order, so
+// strict '<' keeps the reference's choice among equal distances; across lanes the smaller list position wins.
+// Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
+__device__ __forceinline__ double scan_list(const double *region, int E, int examined, double sx, double sy, double sz,
+                                            int lane, double nn[3]) {
     constexpr int U = 4;
-    const double *X = region, *Y = X + E, *Z = Y + E;
-    const unsigned short *K = region_keys(const_cast<double *>(region), E);
+    const double *P = region;
+    const unsigned short *I = region_list(const_cast<double *>(region), E);
     double best = DBL_MAX;
-    int bkey = kKeyOutside, bc = -1;
-    for (int c0 = lane; __ballot(c0 < E) != 0ull; c0 += 32 * U) {  // wave-uniform trip count
-        int key[U];
+    int bi = 0x7FFFFFFF;
+    for (int i0 = lane; __ballot(i0 < examined) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
+        int pos[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 32 * u;
+            pos[u] = (int)I[i < examined ? i : 0];
+        }
         double x[U], y[U], z[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int c = c0 + 32 * u;
-            const bool ok = c < E;
-            const int cc = ok ? c : 0;
-            const int k = (int)K[cc];
-            key[u] = ok ? k : kKeyOutside;
-            x[u] = X[cc];
-            y[u] = Y[cc];
-            z[u] = Z[cc];
+            const double *q = P + 3 * pos[u];
+            x[u] = q[0];
+            y[u] = q[1];
+            z[u] = q[2];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const int i = i0 + 32 * u;
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
             const double d = (ex * ex + ey * ey) + ez * ez;
-            const bool take = key[u] != kKeyOutside && (d < best || (d == best && key[u] < bkey));
+            const bool take = (i < examined) & (d < best);
             best = take ? d : best;
-            bkey = take ? key[u] : bkey;
-            bc = take ? c0 + 32 * u : bc;
+            bi = take ? i : bi;
         }
     }
-    int gkey = bc >= 0 ? bkey : 0x7FFFFFFF;
-    group_min(best, gkey, bc);
-    const int rc = bc >= 0 ? bc : 0;
-    nn[0] = E > 0 ? X[rc] : 0.0;
-    nn[1] = E > 0 ? Y[rc] : 0.0;
-    nn[2] = E > 0 ? Z[rc] : 0.0;
+    group_min_dist_key(best, bi);
+    const int p = (int)I[bi != 0x7FFFFFFF ? bi : 0];
+    const bool found = bi != 0x7FFFFFFF;
+    nn[0] = found ? P[3 * p] : 0.0;
+    nn[1] = found ? P[3 * p + 1] : 0.0;
+    nn[2] = found ? P[3 * p + 2] : 0.0;
     return best;
 }
 
