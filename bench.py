@@ -183,6 +183,7 @@ def main():
             "n_source": int(stats["n_source"]),
             "map_voxels": int(stats["map_voxels"]),
             "icp_iters_per_frame": icp["iterations"] / max(1, icp["launches"]),
+            "icp_workgroups": pipe.icp_profile()["workgroups"],
         },
         "ms_per_icp_iter": icp["total_ms"] / max(1, icp["iterations"]),
         "scan_generation_s": t_gen,
@@ -228,7 +229,7 @@ def main():
         frames = [(d.data_ptr(), d.shape[0], t.data_ptr() if t is not None else None, t.shape[0] if t is not None else 0)
                   for d, t in zip(dev_pts, dev_ts)]
         kd, rate_dev = drive(lambda k, f: k.register_frame_device(*f), lambda: frames)
-        out["device_resident"] = {"scans_per_s": rate_dev, "ms_per_frame": 1e3 / rate_dev,
+        out["device_resident"] = {"scans_per_s": rate_dev, "ms_per_frame": 1e3 / rate_dev, "icp_workgroups": kd.icp_profile()["workgroups"],
                                   "same_trajectory_as_host_input": bool((kd.last_pose == local_poses[-1]).all())}
         del dev_pts, dev_ts
         # (b) the sensor's native float32 points in host memory (no widening, no narrowing)

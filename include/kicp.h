@@ -266,8 +266,6 @@ int kicp_device_synchronize(int device_id);
  *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src
  *                     on the device: ceil(N_src / (16 * icp_points_per_group)), at most 256)
  *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 1)
- *   "icp_groups"      32-lane groups of each ICP workgroup that take source points (1..16, default 16;
- *                     8 leaves one active wave per SIMD)
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)

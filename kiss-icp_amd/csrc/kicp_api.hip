@@ -152,7 +152,6 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 1);
     P.use_lds = options().icp_use_lds != 0;
-    P.groups_used = (int)options().icp_groups;
     // A workgroup owns its CU: 160 KiB of LDS for the candidate pool, and its eight waves fill the CU's
     // vector register file, so nothing else runs beside it.  The front stages of the NEXT frame run
     // concurrently on a second stream; a few CUs are left out of the grid for them (they are small
@@ -1937,9 +1936,6 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_points_per_group")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;
         options().icp_points_per_group = value;
-    } else if (!strcmp(name, "icp_groups")) {
-        if (value < 1 || value > kIcpGroupsPerBlock) return KICP_ERR_INVALID_ARG;
-        options().icp_groups = value;
     } else if (!strcmp(name, "icp_use_lds")) {
         options().icp_use_lds = value;
     } else if (!strcmp(name, "icp_profile")) {

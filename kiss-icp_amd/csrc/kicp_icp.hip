@@ -35,7 +35,19 @@ namespace kicp {
 // dx = LDLT(JTJ).solve(-JTr), est = exp(dx), T_icp = est * T_icp, stop when |dx| <
 // convergence_criterion (:156-163).
 // ------------------------------------------------------------------------------------------
-struct IcpShared {  // head of the dynamic LDS (kIcpFixedLds bytes with the region records)
+// one source point of the chunk a workgroup is working on (phases A -> B -> C of an iteration)
+struct IcpPoint {
+    double s[3];   // transformed source point                               (A)
+    double nn[3];  // its closest map point                                   (B)
+    double d2;     // squared distance, DBL_MAX when the neighbourhood is empty (B)
+    int E;         // map points the reference examines for it                (B)
+    int flag;      // 0 staged window valid, 1 window must be (re)staged, 2 search HBM directly (A)
+    int v[3];      // voxel of s                                              (A)
+    int pad;
+};
+static_assert(sizeof(IcpPoint) == 80, "IcpPoint layout");
+
+struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records and the candidate pool follow
     double part[kIcpGroupsPerBlock][kIcpSums];
     double range_sum[kIcpParts][kIcpSums];
     double tot[kIcpSums];
@@ -47,11 +59,13 @@ struct IcpShared {  // head of the dynamic LDS (kIcpFixedLds bytes with the regi
     double pad2;
     int fail;
     int bump;  // doubles handed out from the candidate pool
-    int pad[6];
-    int2 cells[kIcpGroupsPerBlock][64];  // per-group scratch of window_fill
+    int next_point;  // phase B: next unserved point of the chunk
+    int pad[5];
+    int2 cells[kIcpGroupsPerBlock][64];  // per-group scratch of window_fill; phase C reuses it for the terms
+    IcpPoint pts[kIcpChunk];
 };
-static_assert(sizeof(IcpShared) + kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) <= kIcpFixedLds,
-              "kIcpFixedLds too small");
+static_assert(sizeof(IcpShared) % 16 == 0, "the region records behind it must stay 16-byte aligned");
+static_assert(kIcpTermChunk * kIcpTerms * sizeof(double) <= sizeof(int2) * kIcpGroupsPerBlock * 64, "terms alias the cell scratch");
 
 // low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
 __device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
@@ -63,8 +77,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // shift its base off 8/16-byte alignment)
     IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
     IcpRegionMeta *metas = reinterpret_cast<IcpRegionMeta *>(smem + sizeof(IcpShared));
-    double *pool = reinterpret_cast<double *>(smem + kIcpFixedLds);
-    const int kPoolDoubles = (int)(((size_t)P.lds_bytes - kIcpFixedLds) / sizeof(double));
 
     const int tid = threadIdx.x;
     const int lane = tid & (kIcpGroup - 1);
@@ -86,12 +98,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const int n = count_of(P.n_ptr, P.n_imm);
     // How many of the launched workgroups take part is decided here, from the actual N_src, so the
     // summation order (hence the result, bit for bit) never depends on host-side hints.
-    const int groups_used = P.groups_used;  // groups of a workgroup that take source points (experiments: 8 = one wave per SIMD)
     int G = P.force_blocks > 0 ? P.force_blocks
-                               : (n + groups_used * P.points_per_group - 1) / (groups_used * P.points_per_group);
+                               : (n + kIcpGroupsPerBlock * P.points_per_group - 1) / (kIcpGroupsPerBlock * P.points_per_group);
     G = max(1, min(G, (int)gridDim.x));
     if ((int)blockIdx.x >= G) return;
-    const int cached_rounds = (P.use_lds && m.max_points <= 32) ? kIcpMaxCachedRounds : 0;
+    // Point p belongs to workgroup p % G (consecutive source points -- neighbours in the scan, hence similar
+    // neighbourhood sizes -- go to different workgroups); its LOCAL index there is j = p / G.  A workgroup
+    // owns n_local points; the first n_meta of them may keep a staged window in LDS, the rest search HBM.
+    const int n_local = ((int)blockIdx.x < n) ? (n - (int)blockIdx.x + G - 1) / G : 0;
+    const int n_meta = (P.use_lds && m.max_points <= 32) ? min((n + G - 1) / G, kIcpMaxMeta) : 0;
+    double *pool = reinterpret_cast<double *>(smem + sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpRegionMeta));
+    const int kPoolDoubles = (int)(((size_t)P.lds_bytes - sizeof(IcpShared) - (size_t)n_meta * sizeof(IcpRegionMeta)) / sizeof(double));
+    double(*terms)[kIcpTerms] = reinterpret_cast<double(*)[kIcpTerms]>(&sh.cells[0][0]);
     const unsigned epoch_base = st->epoch_base;
     unsigned t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
     unsigned gather_passes = 0;
@@ -128,11 +146,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
     }
-    if (tid < kIcpMaxCachedRounds * kIcpGroupsPerBlock) {
-        metas[tid].valid = 0;
-        metas[tid].cap = 0;
-        metas[tid].base = 0;
-        metas[tid].E = 0;
+    for (int i = tid; i < n_meta; i += kIcpThreads) {
+        metas[i].valid = 0;
+        metas[i].cap = 0;
+        metas[i].base = 0;
+        metas[i].E = 0;
     }
     __syncthreads();
 
@@ -144,38 +162,44 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const int max_iters = map_empty ? 0 : P.max_iters;
     for (int it = 0; it < max_iters; ++it) {
         const unsigned c0 = PROF ? ticks32() : 0u;
-        double acc[kIcpSums];
-#pragma unroll
-        for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
-        // consecutive source points (neighbours in the scan, hence similar neighbourhood sizes) go to
-        // different workgroups: point p belongs to workgroup p % G, group (p / G) % 16
-        int round = 0;
-        for (int p = (grp < groups_used) ? (int)blockIdx.x + G * grp : n; p < n; p += G * groups_used, ++round) {
-            const bool has_meta = round < cached_rounds;
-            IcpRegionMeta *meta = metas + (has_meta ? round : 0) * kIcpGroupsPerBlock + grp;
-            const unsigned ta = PROF ? ticks32() : 0u;
-            double pin[3];
-            if (it > 0 && has_meta) {  // running source point lives in LDS
-                pin[0] = meta->s[0];
-                pin[1] = meta->s[1];
-                pin[2] = meta->s[2];
-            } else {
-                const double *src = (it == 0) ? P.frame : P.work;
-                pin[0] = src[3 * p];
-                pin[1] = src[3 * p + 1];
-                pin[2] = src[3 * p + 2];
-            }
-            double s[3];
-            se3_act(est, pin, s);
-            const int vx = voxel_coord_fast(s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(s[1], m.voxel_size, inv_voxel),
-                      vz = voxel_coord_fast(s[2], m.voxel_size, inv_voxel);
-            const int v[3] = {vx, vy, vz};
-            bool cached = false;
-            if (has_meta && meta->valid)  // is the 27-neighbourhood of (vx, vy, vz) inside the staged window?
-                cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
-                         meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
-                         meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
-            if (lane == 0) {
+        // ---- association + accumulation, in three phases per chunk of kIcpChunk local points ---------------
+        //   A  one THREAD per point: s = est * s (TransformPoints), its voxel, is its staged window still good
+        //   B  one 32-lane GROUP per point: (re)stage the window if needed, closest neighbour (a2 / a3)
+        //   C  one THREAD per point: correspondence test, weight, the 16 products of J^T w J, J^T w r (a5);
+        //      then thread (g, k) adds term k of the points of group g in ascending local index -- the order
+        //      in which a group's lane 0 used to accumulate them, so the sums are bit for bit what they were
+        // A and C cost one instruction stream per WORKGROUP instead of one per point.
+        const int ck = tid % kIcpTerms, cg = tid / kIcpTerms;  // phase C: term and group of this thread
+        double acc = 0.0;
+        unsigned t_group = 0;
+        for (int base = 0; base < n_local; base += kIcpChunk) {
+            const int cn = min(kIcpChunk, n_local - base);
+            // ---- A -------------------------------------------------------------------------------------
+            if (tid < cn) {
+                const int j = base + tid;
+                const int p = (int)blockIdx.x + G * j;
+                const bool has_meta = j < n_meta;
+                IcpRegionMeta *meta = metas + (has_meta ? j : 0);
+                double pin[3];
+                if (it > 0 && has_meta) {  // running source point lives in LDS
+                    pin[0] = meta->s[0];
+                    pin[1] = meta->s[1];
+                    pin[2] = meta->s[2];
+                } else {
+                    const double *src = (it == 0) ? P.frame : P.work;
+                    pin[0] = src[3 * p];
+                    pin[1] = src[3 * p + 1];
+                    pin[2] = src[3 * p + 2];
+                }
+                double s[3];
+                se3_act(est, pin, s);
+                const int vx = voxel_coord_fast(s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(s[1], m.voxel_size, inv_voxel),
+                          vz = voxel_coord_fast(s[2], m.voxel_size, inv_voxel);
+                bool cached = false;
+                if (has_meta && meta->valid)  // is the 27-neighbourhood of (vx, vy, vz) inside the staged window?
+                    cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
+                             meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
+                             meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
                 if (has_meta) {
                     meta->s[0] = s[0];
                     meta->s[1] = s[1];
@@ -185,88 +209,138 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     P.work[3 * p + 1] = s[1];
                     P.work[3 * p + 2] = s[2];
                 }
+                IcpPoint &pt = sh.pts[tid];
+                pt.s[0] = s[0];
+                pt.s[1] = s[1];
+                pt.s[2] = s[2];
+                pt.v[0] = vx;
+                pt.v[1] = vy;
+                pt.v[2] = vz;
+                pt.flag = cached ? 0 : ((has_meta && meta->cap >= 0) ? 1 : 2);
             }
-            int path = cached ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
-            const unsigned tb = PROF ? ticks32() : 0u;
-            if (!cached && has_meta && meta->cap >= 0) {
-                cached = window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err);
-                if (cached) path = 2;
-            }
-            const unsigned tc = PROF ? ticks32() : 0u;
-            double nn[3];
-            double d2;
-            int E;
-            if (cached) {
-                // the scan list belongs to one voxel offset of the query inside its window; a query that has
-                // crossed into another voxel (a few times per launch at most) gets it rebuilt
-                const int dx = vx - meta->v[0], dy = vy - meta->v[1], dz = vz - meta->v[2];
-                if (dx != meta->d[0] || dy != meta->d[1] || dz != meta->d[2]) {
-                    WindowGeom g;
-                    g.lo0 = meta->lo[0];
-                    g.lo1 = meta->lo[1];
-                    g.lo2 = meta->lo[2];
-                    g.n0 = meta->hi[0] - g.lo0 + 1;
-                    g.n1 = meta->hi[1] - g.lo1 + 1;
-                    g.n2 = meta->hi[2] - g.lo2 + 1;
-                    g.dx = dx;
-                    g.dy = dy;
-                    g.dz = dz;
-                    window_index(pool + meta->base, meta->E, g, lane, reinterpret_cast<int *>(sh.cells[grp]), meta);
+            if (tid == 0) sh.next_point = kIcpGroupsPerBlock;  // points 0..15 go to the groups directly
+            __syncthreads();
+            // ---- B -------------------------------------------------------------------------------------
+            // Neighbourhoods differ by an order of magnitude in size (15 .. 540 points examined), so the groups
+            // do not take a fixed share: each takes the next unserved point when it is done.  Which group
+            // serves a point has no influence on the result (phase C adds in point order).
+            const unsigned tb0 = PROF ? ticks32() : 0u;
+            for (int t = grp; t < cn;) {
+                IcpPoint &pt = sh.pts[t];
+                const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
+                const int vx = pt.v[0], vy = pt.v[1], vz = pt.v[2];
+                const int v[3] = {vx, vy, vz};
+                int flag = pt.flag;
+                IcpRegionMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
+                int path = flag == 0 ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
+                const unsigned tb = PROF ? ticks32() : 0u;
+                if (flag == 1) {
+                    if (window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err)) {
+                        flag = 0;
+                        path = 2;
+                    } else {
+                        flag = 2;
+                    }
                 }
-                E = meta->examined;
-                d2 = scan_list(pool + meta->base, meta->E, E, s[0], s[1], s[2], lane, nn);
-                if (path == 0 && (meta->hi[0] - meta->lo[0]) * (meta->hi[1] - meta->lo[1]) * (meta->hi[2] - meta->lo[2]) != 8) path = 1;
-            } else {
-                const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
-                E = pr.E;
-                d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
-                                         : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
-            }
-            const unsigned td = PROF ? ticks32() : 0u;
-            if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && round == 0) {
-                // per-group record of this iteration (10 ns ticks): where the group's time went
-                unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
-                                               (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
-                r[0] = (unsigned)(ta - c0) | ((unsigned)(tb - ta) << 16);   // wait-in, transform + window test
-                r[1] = (unsigned)(tc - tb) | ((unsigned)(td - tc) << 16);   // window fill, scan
-                r[2] = (unsigned)(has_meta ? meta->E : 0) | ((unsigned)E << 16);  // staged points, examined
-                r[3] = (unsigned)path;
-            }
-            if (lane == 0) {
-                acc[17] += (double)E;
-                if (d2 < DBL_MAX && sqrt(d2) < max_dist) {
-                    const double rx = s[0] - nn[0], ry = s[1] - nn[1], rz = s[2] - nn[2];
-                    const double r2 = (rx * rx + ry * ry) + rz * rz;
-                    const double w = (ks * ks) / ((ks + r2) * (ks + r2));
-                    acc[0] += w;
-                    acc[1] += w * s[0];
-                    acc[2] += w * s[1];
-                    acc[3] += w * s[2];
-                    // w * hat(s)^T hat(s) = w * (|s|^2 I - s s^T), upper triangle
-                    acc[4] += w * (s[1] * s[1] + s[2] * s[2]);
-                    acc[5] += w * (-(s[0] * s[1]));
-                    acc[6] += w * (-(s[0] * s[2]));
-                    acc[7] += w * (s[0] * s[0] + s[2] * s[2]);
-                    acc[8] += w * (-(s[1] * s[2]));
-                    acc[9] += w * (s[0] * s[0] + s[1] * s[1]);
-                    acc[10] += w * rx;
-                    acc[11] += w * ry;
-                    acc[12] += w * rz;
-                    // w * (s x r)
-                    acc[13] += w * (s[1] * rz - s[2] * ry);
-                    acc[14] += w * (s[2] * rx - s[0] * rz);
-                    acc[15] += w * (s[0] * ry - s[1] * rx);
-                    acc[16] += 1.0;
+                const unsigned tc = PROF ? ticks32() : 0u;
+                double nn[3];
+                double d2;
+                int E;
+                if (flag == 0) {
+                    // the scan list belongs to one voxel offset of the query inside its window; a query that has
+                    // crossed into another voxel (a few times per launch at most) gets it rebuilt
+                    const int dx = vx - meta->v[0], dy = vy - meta->v[1], dz = vz - meta->v[2];
+                    if (dx != meta->d[0] || dy != meta->d[1] || dz != meta->d[2]) {
+                        WindowGeom g;
+                        g.lo0 = meta->lo[0];
+                        g.lo1 = meta->lo[1];
+                        g.lo2 = meta->lo[2];
+                        g.n0 = meta->hi[0] - g.lo0 + 1;
+                        g.n1 = meta->hi[1] - g.lo1 + 1;
+                        g.n2 = meta->hi[2] - g.lo2 + 1;
+                        g.dx = dx;
+                        g.dy = dy;
+                        g.dz = dz;
+                        window_index(pool + meta->base, meta->E, g, lane, reinterpret_cast<int *>(sh.cells[grp]), meta);
+                    }
+                    E = meta->examined;
+                    d2 = scan_list(pool + meta->base, meta->E, E, s[0], s[1], s[2], lane, nn);
+                    if (path == 0 && (meta->hi[0] - meta->lo[0]) * (meta->hi[1] - meta->lo[1]) * (meta->hi[2] - meta->lo[2]) != 8) path = 1;
+                } else {
+                    const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
+                    E = pr.E;
+                    d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
+                                             : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
                 }
+                if (lane == 0) {
+                    pt.nn[0] = nn[0];
+                    pt.nn[1] = nn[1];
+                    pt.nn[2] = nn[2];
+                    pt.d2 = d2;
+                    pt.E = E;
+                }
+                const unsigned td = PROF ? ticks32() : 0u;
+                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && t == grp) {
+                    // per-group record of this iteration (10 ns ticks): where the group's time went
+                    unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
+                                                   (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+                    r[0] = (unsigned)(tb0 - c0) | ((unsigned)(tb - tb0) << 16);  // phase A + barrier, wait inside B
+                    r[1] = (unsigned)(tc - tb) | ((unsigned)(td - tc) << 16);    // window fill, search
+                    r[2] = (unsigned)((base + t < n_meta) ? meta->E : 0) | ((unsigned)E << 16);  // staged points, examined
+                    r[3] = (unsigned)path;
+                }
+                int nt = 0;
+                if (lane == 0) nt = atomicAdd(&sh.next_point, 1);
+                t = __shfl(nt, 0, 32);
+            }
+            if (PROF) t_group += ticks32() - tb0;
+            __syncthreads();
+            // ---- C -------------------------------------------------------------------------------------
+            for (int sub = 0; sub < cn; sub += kIcpTermChunk) {
+                const int sn = min(kIcpTermChunk, cn - sub);
+                if (tid < sn) {
+                    const IcpPoint &pt = sh.pts[sub + tid];
+                    const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
+                    const double d2 = pt.d2;
+                    double *T = terms[tid];
+#pragma unroll
+                    for (int k = 0; k < 17; ++k) T[k] = 0.0;
+                    T[17] = (double)pt.E;
+                    if (d2 < DBL_MAX && sqrt(d2) < max_dist) {  // Registration.cpp:72 (strict)
+                        const double rx = s[0] - pt.nn[0], ry = s[1] - pt.nn[1], rz = s[2] - pt.nn[2];
+                        const double r2 = (rx * rx + ry * ry) + rz * rz;
+                        const double w = (ks * ks) / ((ks + r2) * (ks + r2));
+                        T[0] = w;
+                        T[1] = w * s[0];
+                        T[2] = w * s[1];
+                        T[3] = w * s[2];
+                        // w * hat(s)^T hat(s) = w * (|s|^2 I - s s^T), upper triangle
+                        T[4] = w * (s[1] * s[1] + s[2] * s[2]);
+                        T[5] = w * (-(s[0] * s[1]));
+                        T[6] = w * (-(s[0] * s[2]));
+                        T[7] = w * (s[0] * s[0] + s[2] * s[2]);
+                        T[8] = w * (-(s[1] * s[2]));
+                        T[9] = w * (s[0] * s[0] + s[1] * s[1]);
+                        T[10] = w * rx;
+                        T[11] = w * ry;
+                        T[12] = w * rz;
+                        // w * (s x r)
+                        T[13] = w * (s[1] * rz - s[2] * ry);
+                        T[14] = w * (s[2] * rx - s[0] * rz);
+                        T[15] = w * (s[0] * ry - s[1] * rx);
+                        T[16] = 1.0;
+                    }
+                }
+                __syncthreads();
+                if (cg < kIcpGroupsPerBlock)
+                    for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += terms[i][ck];
+                __syncthreads();  // the terms alias the fill scratch of the next chunk's phase B
             }
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
         const unsigned c1 = PROF ? ticks32() : 0u;
-        acc[kIcpTickSlot] = (double)(c1 - c0);  // this group's association time (profiling, max-reduced)
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < kIcpSums; ++k) sh.part[grp][k] = acc[k];
-        }
+        if (cg < kIcpGroupsPerBlock) sh.part[cg][ck] = acc;
+        if (lane == 0) sh.part[grp][kIcpTickSlot] = (double)t_group;  // this group's search time (profiling, max-reduced)
         __syncthreads();
         const unsigned epoch = epoch_base + (unsigned)it + 1u;
         unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpSums);

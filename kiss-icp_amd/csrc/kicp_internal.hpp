@@ -161,8 +161,11 @@ constexpr int kIcpSolveThreads = 256;  // waves 0..3 (one per SIMD) solve the 6x
 constexpr int kIcpBookThread = kIcpThreads - 64;  // first lane of the last wave: pose / statistics bookkeeping
 constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gather of one scalar
 constexpr int kIcpMaxBlocks = 256;
-constexpr int kIcpMaxCachedRounds = 4;  // rounds of a group whose neighbourhood may be staged in LDS
 constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the whole LDS
+constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time
+constexpr int kIcpTermChunk = 48;  // points whose products are in LDS together (a multiple of the group count)
+constexpr int kIcpTerms = 18;      // 16 normal-equation scalars + correspondence count + examined count
+constexpr int kIcpMaxMeta = 320;   // local points of a workgroup that may keep a staged window (a 64-byte record each)
 constexpr size_t kIcpGroupProfileWords = (size_t)kIcpProfIters * kIcpMaxBlocks * kIcpGroupsPerBlock * 4;
 
 // LDS record of one (round, group) query of the persistent ICP kernel
@@ -179,13 +182,6 @@ struct IcpRegionMeta {
     unsigned short examined;   // staged points inside the query's 27 voxels for that offset
 };
 static_assert(sizeof(IcpRegionMeta) == 64, "keep the candidate pool 16-byte aligned");
-
-// fixed part of k_icp's dynamic LDS, in bytes (the candidate pool takes the rest)
-constexpr size_t kIcpFixedLds =
-    ((size_t)(kIcpGroupsPerBlock * kIcpSums + kIcpParts * kIcpSums + kIcpSums + 8 + 18) * sizeof(double) +  // sums + est + bookkeeping
-     8 * sizeof(int) +                                                                                   // control words
-     (size_t)kIcpGroupsPerBlock * 64 * 8 +                                                               // window cells
-     (size_t)kIcpMaxCachedRounds * kIcpGroupsPerBlock * sizeof(IcpRegionMeta) + 15) & ~(size_t)15;
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
@@ -205,7 +201,6 @@ struct IcpParams {
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
     int use_lds;           // stage candidate voxels in LDS (0 disables)
-    int groups_used;       // 1..16 groups of every workgroup take source points (default 16)
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int inject_timeout;    // test hook: behave like a launch whose workgroups never became co-resident
     const PrepState *prep;  // pipeline mode: this frame's counts (copied into the frame record), or nullptr
@@ -238,7 +233,6 @@ struct Options {
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
-    long icp_groups = 16;        // groups per workgroup that take source points
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
     long icp_lds_kib = 0;        // dynamic LDS per ICP workgroup in KiB (0: all 160)
     long icp_reserve_cus = 32;   // CUs left out of the ICP grid (one per shader engine) for the front stages of the next frame
