@@ -717,6 +717,9 @@ int kicp_registration_destroy(kicp_registration *r) {
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     r->frame.release();
     r->work.release();
+    r->sort_in.release();
+    r->sort_out.release();
+    r->sort_tmp.release();
     r->granules.release();
     r->state.release();
     if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -752,12 +755,27 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
     if (n) KICP_HIP(hipMemcpyAsync(r->frame.p, frame_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, r->stream));
     PipeState *st = r->state.as<PipeState>();
     KICP_HIP(hipMemcpyAsync(&st->guess, &guess, sizeof guess, hipMemcpyHostToDevice, r->stream));
+    // spatial order of the source cloud (see kicp_sort.hip)
+    const bool sorted = n > 0 && n <= ((size_t)1 << 24);
+    if (sorted) {
+        KICP_TRY(r->sort_in.reserve(n * sizeof(unsigned long long)));
+        KICP_TRY(r->sort_out.reserve(n * sizeof(unsigned long long)));
+        const size_t tb = tile_sort_temp_bytes(n);
+        KICP_TRY(r->sort_tmp.reserve(tb));
+        const int se = launch_tile_sort(r->frame.as<double>(), nullptr, (int)n, n, map->voxel_size, r->sort_in.as<unsigned long long>(),
+                                        r->sort_out.as<unsigned long long>(), r->sort_tmp.p, r->sort_tmp.bytes, r->stream);
+        if (se != 0) {
+            set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
+            return KICP_ERR_HIP;
+        }
+    }
     PipeState h;
     for (int attempt = 0, cap = 0;; ++attempt) {
         IcpParams P;
         memset(&P, 0, sizeof P);
         const int G = icp_fill_policy(r->device, P, n, cap);
         P.frame = r->frame.as<double>();
+        P.order = sorted ? r->sort_out.as<unsigned long long>() : nullptr;
         P.work = r->work.as<double>();
         P.n_ptr = nullptr;
         P.n_imm = (int)n;
@@ -1026,6 +1044,8 @@ struct kicp_pipeline {
     // fd (the 0.5 v cloud, read by the map update) and src (the 1.5 v cloud, read by the registration)
     // exist twice, indexed by frame parity; so do the upload targets raw / ts of the host-input path
     DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
+    DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
+    size_t sort_tmp_bytes = 0;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -1088,6 +1108,11 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->slot1.reserve(cap * sizeof(int)));
     KICP_TRY(p->slot2.reserve(cap * sizeof(int)));
     KICP_TRY(p->counts.reserve(3 * ((cap + 1023) / 1024 + 1) * sizeof(int)));
+    KICP_TRY(p->sort_in.reserve(cap * sizeof(unsigned long long)));
+    KICP_TRY(p->sort_out[0].reserve(cap * sizeof(unsigned long long)));
+    KICP_TRY(p->sort_out[1].reserve(cap * sizeof(unsigned long long)));
+    p->sort_tmp_bytes = tile_sort_temp_bytes(cap);
+    KICP_TRY(p->sort_tmp.reserve(p->sort_tmp_bytes));
     const uint32_t tcap = next_pow2(2 * cap);
     KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
@@ -1254,6 +1279,16 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     launch_ds_flags(D2, sp);
     launch_ds_scatter(D2, sp);
     KICP_HIP(hipGetLastError());
+    // --- spatial order of the source cloud: the ICP kernel hands every workgroup a compact patch of it ----
+    const bool sorted = n <= ((size_t)1 << 24);
+    if (sorted && n) {
+        const int se = launch_tile_sort(p->src[par].as<double>(), &prep->n_src, 0, n, c.voxel_size, p->sort_in.as<unsigned long long>(),
+                                        p->sort_out[par].as<unsigned long long>(), p->sort_tmp.p, p->sort_tmp_bytes, sp);
+        if (se != 0) {
+            set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
+            return KICP_ERR_HIP;
+        }
+    }
     KICP_HIP(hipEventRecord(p->ev_prep_done[par], sp));
 
     // ===== stream: the serial chain =================================================================
@@ -1266,6 +1301,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     const size_t n_src_hint = p->have_last ? (size_t)p->last.st.n_src : n / 32;
     const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap);
     I.frame = p->src[par].as<double>();
+    I.order = sorted ? p->sort_out[par].as<unsigned long long>() : nullptr;
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
     I.prep = prep;
@@ -1496,7 +1532,8 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     p->pool = nullptr;
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
-                      &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep})
+                      &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
+                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp})
         b->release();
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);

@@ -58,14 +58,15 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     unsigned long long ncorr_last, ncorr_total, examined_total;
     double pad2;
     int fail;
-    int bump;  // doubles handed out from the candidate pool
-    int next_point;  // phase B: next unserved point of the chunk
-    int pad[5];
-    int2 cells[kIcpGroupsPerBlock][64];  // per-group scratch of window_fill; phase C reuses it for the terms
+    int tile_points;  // points handed out from the tile's store
+    int next_point;   // phase B: next unserved point of the chunk
+    int origin[3];    // voxel with relative tile coordinates (0, 0, 0)
+    int any_fill;     // phase A: some query of the chunk is outside its known window
+    int pad[1];
+    double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
-static_assert(sizeof(IcpShared) % 16 == 0, "the region records behind it must stay 16-byte aligned");
-static_assert(kIcpTermChunk * kIcpTerms * sizeof(double) <= sizeof(int2) * kIcpGroupsPerBlock * 64, "terms alias the cell scratch");
+static_assert(sizeof(IcpShared) % 16 == 0, "the query records behind it must stay 16-byte aligned");
 
 // low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
 __device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
     // shift its base off 8/16-byte alignment)
     IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
-    IcpRegionMeta *metas = reinterpret_cast<IcpRegionMeta *>(smem + sizeof(IcpShared));
+    IcpQueryMeta *metas = reinterpret_cast<IcpQueryMeta *>(smem + sizeof(IcpShared));
 
     const int tid = threadIdx.x;
     const int lane = tid & (kIcpGroup - 1);
@@ -102,14 +103,27 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                : (n + kIcpGroupsPerBlock * P.points_per_group - 1) / (kIcpGroupsPerBlock * P.points_per_group);
     G = max(1, min(G, (int)gridDim.x));
     if ((int)blockIdx.x >= G) return;
-    // Point p belongs to workgroup p % G (consecutive source points -- neighbours in the scan, hence similar
-    // neighbourhood sizes -- go to different workgroups); its LOCAL index there is j = p / G.  A workgroup
-    // owns n_local points; the first n_meta of them may keep a staged window in LDS, the rest search HBM.
-    const int n_local = ((int)blockIdx.x < n) ? (n - (int)blockIdx.x + G - 1) / G : 0;
-    const int n_meta = (P.use_lds && m.max_points <= 32) ? min((n + G - 1) / G, kIcpMaxMeta) : 0;
-    double *pool = reinterpret_cast<double *>(smem + sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpRegionMeta));
-    const int kPoolDoubles = (int)(((size_t)P.lds_bytes - sizeof(IcpShared) - (size_t)n_meta * sizeof(IcpRegionMeta)) / sizeof(double));
-    double(*terms)[kIcpTerms] = reinterpret_cast<double(*)[kIcpTerms]>(&sh.cells[0][0]);
+    // The source cloud is taken in its spatial order (P.order: sorted {Morton code of the point's cell, index}
+    // keys); workgroup b serves the contiguous run [b * n_run, (b + 1) * n_run) of it -- a compact patch of
+    // the scene, so that the map voxels its points can reach fit in the workgroup's LDS tile.  The first
+    // n_meta points of a run use the tile; any beyond that search HBM directly.
+    const int n_run = (n + G - 1) / G;
+    const int q0 = (int)blockIdx.x * n_run;
+    const int n_local = max(0, min(n_run, n - q0));
+    const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_run, kIcpMaxMeta) : 0;
+    Tile tile;
+    {
+        char *q = smem + sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpQueryMeta);
+        tile.keys = reinterpret_cast<unsigned *>(q);
+        tile.vals = tile.keys + kIcpTileSlots;
+        tile.points = reinterpret_cast<double *>(q + (size_t)2 * kIcpTileSlots * sizeof(unsigned));
+        const long room = (long)P.lds_bytes - (long)(sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpQueryMeta) +
+                                                    (size_t)2 * kIcpTileSlots * sizeof(unsigned));
+        tile.cap_points = n_meta > 0 && room > 0 ? (int)(room / (3 * sizeof(double))) : 0;
+        tile.count = &sh.tile_points;
+        tile.ox = tile.oy = tile.oz = 0;  // set once the first point's voxel is known
+    }
+    double(*terms)[kIcpTerms] = sh.terms;
     const unsigned epoch_base = st->epoch_base;
     unsigned t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
     unsigned gather_passes = 0;
@@ -132,7 +146,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 
     if (tid == 0) {
         sh.fail = 0;
-        sh.bump = 0;
+        sh.tile_points = 0;
+        sh.any_fill = 0;
         const SE3 id = se3_identity();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -146,12 +161,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
     }
-    for (int i = tid; i < n_meta; i += kIcpThreads) {
-        metas[i].valid = 0;
-        metas[i].cap = 0;
-        metas[i].base = 0;
-        metas[i].E = 0;
-    }
+    for (int i = tid; i < n_meta; i += kIcpThreads) metas[i].valid = 0;
+    if (n_meta > 0)
+        for (int i = tid; i < kIcpTileSlots; i += kIcpThreads) {
+            tile.keys[i] = kTileEmpty;
+            tile.vals[i] = 0u;
+        }
     __syncthreads();
 
     SE3 est = guess;
@@ -177,9 +192,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // ---- A -------------------------------------------------------------------------------------
             if (tid < cn) {
                 const int j = base + tid;
-                const int p = (int)blockIdx.x + G * j;
+                const int p = P.order ? (int)(P.order[q0 + j] & 0xFFFFFFull) : q0 + j;
                 const bool has_meta = j < n_meta;
-                IcpRegionMeta *meta = metas + (has_meta ? j : 0);
+                IcpQueryMeta *meta = metas + (has_meta ? j : 0);
                 double pin[3];
                 if (it > 0 && has_meta) {  // running source point lives in LDS
                     pin[0] = meta->s[0];
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const int vx = voxel_coord_fast(s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(s[1], m.voxel_size, inv_voxel),
                           vz = voxel_coord_fast(s[2], m.voxel_size, inv_voxel);
                 bool cached = false;
-                if (has_meta && meta->valid)  // is the 27-neighbourhood of (vx, vy, vz) inside the staged window?
+                if (has_meta && meta->valid > 0)  // is the 27-neighbourhood of (vx, vy, vz) inside the known window?
                     cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
                              meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
                              meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
@@ -216,10 +231,36 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 pt.v[0] = vx;
                 pt.v[1] = vy;
                 pt.v[2] = vz;
-                pt.flag = cached ? 0 : ((has_meta && meta->cap >= 0) ? 1 : 2);
+                pt.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
+                if (pt.flag == 1) sh.any_fill = 1;
+                if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
+                    sh.origin[0] = vx - kTileSpan / 2;
+                    sh.origin[1] = vy - kTileSpan / 2;
+                    sh.origin[2] = vz - kTileSpan / 2;
+                }
             }
             if (tid == 0) sh.next_point = kIcpGroupsPerBlock;  // points 0..15 go to the groups directly
             __syncthreads();
+            tile.ox = sh.origin[0];
+            tile.oy = sh.origin[1];
+            tile.oz = sh.origin[2];
+            // ---- B0: queries that are outside their known window (all of them in the first iteration, a few
+            // now and then later) establish a new one.  Kept apart from the searches: a voxel one group is
+            // still fetching may be the neighbour another group is about to look for.
+            const unsigned tb00 = PROF ? ticks32() : 0u;
+            if (sh.any_fill) {
+                for (int t = grp; t < cn; t += kIcpGroupsPerBlock) {
+                    IcpPoint &pt = sh.pts[t];
+                    if (pt.flag != 1) continue;
+                    const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
+                    const int v[3] = {pt.v[0], pt.v[1], pt.v[2]};
+                    const bool ok = tile_fill(m, tile, s, v, lane, metas + base + t, range_err);
+                    if (lane == 0) pt.flag = ok ? 0 : 2;
+                }
+                __syncthreads();
+                if (tid == 0) sh.any_fill = 0;
+            }
+            const unsigned t_fill = PROF ? ticks32() - tb00 : 0u;
             // ---- B -------------------------------------------------------------------------------------
             // Neighbourhoods differ by an order of magnitude in size (15 .. 540 points examined), so the groups
             // do not take a fixed share: each takes the next unserved point when it is done.  Which group
@@ -229,44 +270,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 IcpPoint &pt = sh.pts[t];
                 const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
                 const int vx = pt.v[0], vy = pt.v[1], vz = pt.v[2];
-                const int v[3] = {vx, vy, vz};
                 int flag = pt.flag;
-                IcpRegionMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
-                int path = flag == 0 ? 0 : 3;  // profiling: 0 staged window, 1 .. widened, 2 staged just now, 3 HBM search
+                IcpQueryMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
+                int path = flag == 0 ? 0 : 3;  // profiling: 0 tile, 3 HBM search
                 const unsigned tb = PROF ? ticks32() : 0u;
-                if (flag == 1) {
-                    if (window_fill(m, s, v, lane, sh.cells[grp], pool, kPoolDoubles, &sh.bump, meta, range_err)) {
-                        flag = 0;
-                        path = 2;
-                    } else {
+                const unsigned tc = tb;
+                double nn[3];
+                double d2 = DBL_MAX;
+                int E = 0;
+                if (flag == 0) {
+                    int bad;
+                    d2 = tile_scan(tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad);
+                    if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is
+                                // being fetched by another group this very moment -> HBM this once
+                        if (bad == 2 && lane == 0) meta->valid = -1;
                         flag = 2;
+                        path = 3;
                     }
                 }
-                const unsigned tc = PROF ? ticks32() : 0u;
-                double nn[3];
-                double d2;
-                int E;
-                if (flag == 0) {
-                    // the scan list belongs to one voxel offset of the query inside its window; a query that has
-                    // crossed into another voxel (a few times per launch at most) gets it rebuilt
-                    const int dx = vx - meta->v[0], dy = vy - meta->v[1], dz = vz - meta->v[2];
-                    if (dx != meta->d[0] || dy != meta->d[1] || dz != meta->d[2]) {
-                        WindowGeom g;
-                        g.lo0 = meta->lo[0];
-                        g.lo1 = meta->lo[1];
-                        g.lo2 = meta->lo[2];
-                        g.n0 = meta->hi[0] - g.lo0 + 1;
-                        g.n1 = meta->hi[1] - g.lo1 + 1;
-                        g.n2 = meta->hi[2] - g.lo2 + 1;
-                        g.dx = dx;
-                        g.dy = dy;
-                        g.dz = dz;
-                        window_index(pool + meta->base, meta->E, g, lane, reinterpret_cast<int *>(sh.cells[grp]), meta);
-                    }
-                    E = meta->examined;
-                    d2 = scan_list(pool + meta->base, meta->E, E, s[0], s[1], s[2], lane, nn);
-                    if (path == 0 && (meta->hi[0] - meta->lo[0]) * (meta->hi[1] - meta->lo[1]) * (meta->hi[2] - meta->lo[2]) != 8) path = 1;
-                } else {
+                if (flag != 0) {
                     const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
                     E = pr.E;
                     d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
@@ -285,8 +307,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
                                                    (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
                     r[0] = (unsigned)(tb0 - c0) | ((unsigned)(tb - tb0) << 16);  // phase A + barrier, wait inside B
-                    r[1] = (unsigned)(tc - tb) | ((unsigned)(td - tc) << 16);    // window fill, search
-                    r[2] = (unsigned)((base + t < n_meta) ? meta->E : 0) | ((unsigned)E << 16);  // staged points, examined
+                    r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)(td - tc) << 16);  // window phase of the chunk, search
+                    r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)E << 16);  // points in the tile so far, examined
                     r[3] = (unsigned)path;
                 }
                 int nt = 0;
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 __syncthreads();
                 if (cg < kIcpGroupsPerBlock)
                     for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += terms[i][ck];
-                __syncthreads();  // the terms alias the fill scratch of the next chunk's phase B
+                __syncthreads();
             }
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------

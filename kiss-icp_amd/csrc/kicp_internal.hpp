@@ -163,28 +163,25 @@ constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gathe
 constexpr int kIcpMaxBlocks = 256;
 constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the whole LDS
 constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time
-constexpr int kIcpTermChunk = 48;  // points whose products are in LDS together (a multiple of the group count)
+constexpr int kIcpTermChunk = 64;  // points whose products are in LDS together (a multiple of the group count)
 constexpr int kIcpTerms = 18;      // 16 normal-equation scalars + correspondence count + examined count
-constexpr int kIcpMaxMeta = 320;   // local points of a workgroup that may keep a staged window (a 64-byte record each)
+constexpr int kIcpMaxMeta = 512;   // local points of a workgroup that may use the workgroup's voxel tile (48 bytes each)
+constexpr int kIcpTileSlots = 4096;  // slots of the workgroup's voxel table (occupied voxels only; power of two)
 constexpr size_t kIcpGroupProfileWords = (size_t)kIcpProfIters * kIcpMaxBlocks * kIcpGroupsPerBlock * 4;
 
-// LDS record of one (round, group) query of the persistent ICP kernel
-struct IcpRegionMeta {
+// LDS record of one source point ("query") of a workgroup of the persistent ICP kernel
+struct IcpQueryMeta {
     double s[3];  // running transformed source point
-    int v[3];     // centre voxel of the staged window
-    int E;        // points staged in the window
-    int base;     // first double of the region inside the candidate pool
-    int cap;      // doubles the region owns
-    int valid;    // window complete
-    signed char lo[3], hi[3];  // window extent per axis, in voxels relative to v (-2..-1, 1..2)
-    signed char d[3];          // voxel of the query relative to v for which the staged keys were computed
+    int v[3];     // voxel the known window is centred on
+    signed char lo[3], hi[3];  // extent of the known window per axis, in voxels relative to v (-2..-1, 1..2)
+    signed char valid;  // 1: every occupied voxel of the window is in the tile; 0: not looked yet; -1: cannot use the tile
     char pad;
-    unsigned short examined;   // staged points inside the query's 27 voxels for that offset
 };
-static_assert(sizeof(IcpRegionMeta) == 64, "keep the candidate pool 16-byte aligned");
+static_assert(sizeof(IcpQueryMeta) == 48, "IcpQueryMeta layout");
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
+    const unsigned long long *order;  // sorted tile keys (low 24 bits: index into frame) or nullptr (identity)
     double *work;         // N x 3 transformed source, private to the launch
     const int *n_ptr;     // device count (pipeline) or nullptr
     int n_imm;            // count when n_ptr == nullptr
@@ -288,7 +285,7 @@ struct kicp_registration {
     hipStream_t stream = nullptr;
     int max_iters = 500;
     double conv = 1e-4;
-    kicp::DevBuf frame, work, granules, state;
+    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

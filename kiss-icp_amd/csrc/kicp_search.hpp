@@ -302,44 +302,54 @@ __device__ __forceinline__ double scan_hits_wide(const MapView &m, const Probe &
     return group_argmin(best, bkey, bx, by, bz, lane, nn);
 }
 
-// GetClosestNeighbor over candidates already staged in LDS by a previous iteration (same voxel
-// neighbourhood): 32 lanes stride over the packed list; the candidate number is the tie-break key.
-__device__ __forceinline__ double scan_lds(const double *cand, int stride, int E, double sx, double sy,
-                                           double sz, int lane, double nn[3]) {
-    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
-    int bkey = 0x7FFFFFFF;
-    for (int c = lane; c < E; c += 32) {
-        const double x = cand[c], y = cand[stride + c], z = cand[2 * stride + c];
-        const double dx = x - sx, dy = y - sy, dz = z - sz;
-        const double d = (dx * dx + dy * dy) + dz * dz;
-        if (d < best) {
-            best = d;
-            bx = x;
-            by = y;
-            bz = z;
-            bkey = c;
-        }
-    }
-    return group_argmin(best, bkey, bx, by, bz, lane, nn);
-}
-
 // ------------------------------------------------------------------------------------------
-// LDS-staged neighbourhoods of the ICP kernel.
+// The workgroup's voxel TILE.
 //
-// A query's 27-voxel neighbourhood is copied once into an LDS region and reused by the following
-// ICP iterations (the map does not change during AlignPointsToMap).  The source point moves a
-// little every iteration and sooner or later crosses a voxel face; re-fetching from HBM then costs
-// three dependent memory round trips, and with thousands of queries SOME query crosses in nearly
-// every iteration -- and every workgroup waits for the slowest one.  So the staged window is
-// widened by one voxel layer on every side the query is close to (within kWindowMargin of the
-// face): 3..4 voxels per axis.  Each staged point carries a tag {voxel offset from the window's
-// centre voxel, index inside its voxel}; a scan for a query now in voxel v' visits exactly the
-// candidates whose voxel lies in [v'-1, v'+1]^3 -- the reference's 27 voxels, no more -- and breaks
-// distance ties by (position of the voxel in the reference's shift table, index in the voxel) like
-// the reference's nested strict '<' loops (VoxelHashMap.cpp:46-70).
+// A workgroup of the ICP kernel serves a spatially compact run of source points.  The map voxels those
+// points can reach are copied ONCE into the workgroup's LDS -- a small open-addressed table {relative voxel
+// key -> first point, point count} over a store of xyz triples -- and every iteration's nearest-neighbour
+// search runs against that tile: the map does not change during AlignPointsToMap, neighbouring queries share
+// most of their voxels (so a voxel is fetched once per workgroup, not once per query), and nothing is staged
+// per query.  What a query has established is its KNOWN WINDOW: the 27 voxels around the voxel it was in
+// when it last looked, widened by one layer on every side it was close to (within kWindowMargin of the
+// face) -- every occupied voxel of the window is in the tile, so as long as the query's current 27 voxels lie
+// inside the window a table miss MEANS an empty voxel.  A query that leaves its window looks again (global
+// probes for the new window's voxels; voxels already in the tile are not fetched again).
 // ------------------------------------------------------------------------------------------
 constexpr double kWindowMargin = 0.125;  // fraction of a voxel
-constexpr int kFillChunk = 12;            // voxels whose points are in flight together during a fill
+constexpr int kFillChunk = 8;             // voxels whose points are in flight together during a fill
+constexpr unsigned kTileEmpty = 0xFFFFFFFFu;
+constexpr unsigned kTileReady = 0x80000000u;     // the voxel's points are in the store
+constexpr unsigned kTileOverflow = 0x40000000u;  // the store was full: queries that need this voxel search HBM
+constexpr int kTileSpan = 1024;                  // relative voxel coordinates 0 .. 1023 per axis
+
+struct Tile {
+    unsigned *keys;  // [kIcpTileSlots] relative voxel key (10 bits per axis) or kTileEmpty
+    unsigned *vals;  // [kIcpTileSlots] first point (bits 0..15) | points (bits 16..21) | flags
+    double *points;  // xyz triples
+    int cap_points;
+    int *count;      // points handed out so far
+    int ox, oy, oz;  // voxel with relative coordinates (0, 0, 0)
+};
+__device__ __forceinline__ bool tile_rel(const Tile &t, int qx, int qy, int qz, unsigned &key) {
+    const unsigned rx = (unsigned)(qx - t.ox), ry = (unsigned)(qy - t.oy), rz = (unsigned)(qz - t.oz);
+    key = (rx << 20) | (ry << 10) | rz;
+    return rx < (unsigned)kTileSpan && ry < (unsigned)kTileSpan && rz < (unsigned)kTileSpan;
+}
+__device__ __forceinline__ unsigned tile_hash(unsigned key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
+static_assert(kIcpTileSlots == 4096, "tile_hash returns 12 bits");
+// slot of a key or -1 (LDS loads; other waves may be inserting: relaxed workgroup-scope atomics keep the
+// compiler from caching them)
+__device__ __forceinline__ int tile_find(const Tile &t, unsigned key) {
+    unsigned s = tile_hash(key);
+    for (int probes = 0; probes < kIcpTileSlots; ++probes) {
+        const unsigned k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == key) return (int)s;
+        if (k == kTileEmpty) return -1;
+        s = (s + 1) & (kIcpTileSlots - 1);
+    }
+    return -1;
+}
 
 // two independent lookups, the first kProbeAhead slots of both chains in flight together
 __device__ __forceinline__ void map_find_pair(const MapView &m, bool ok0, unsigned long long key0, bool ok1,
@@ -368,224 +378,6 @@ __device__ __forceinline__ void group_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ------------------------------------------------------------------------------------------
-// Staged windows.  A query's region (doubles out of its workgroup's pool) holds
-//   P[E]   the E map points of the window's voxels as xyz triples (24 bytes each), voxel after voxel in
-//          window order (x-major, z fastest);
-//   C[64]  per window cell {first point (bits 6..), points (bits 0..5)};
-//   I[..]  the SCAN LIST: positions (into P) of the points of the query's 27 voxels, in exactly the order the
-//          reference visits them (shift table VoxelHashMap.cpp:35-41, then index inside the voxel), 16 bits
-//          each.  The per-iteration search strides over this list and nothing else: no geometry, no tags, no
-//          filtering, and strict '<' alone reproduces the reference's tie rules because the list is in its
-//          order.  The list is rebuilt (from C, no HBM access) only when the query moves to another voxel of
-//          its window -- a few times per launch.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int region_doubles(int E) { return 3 * E + 32 + (E + 3) / 4; }
-__device__ __forceinline__ unsigned *region_cells(double *region, int E) {
-    return reinterpret_cast<unsigned *>(region + 3 * E);
-}
-__device__ __forceinline__ unsigned short *region_list(double *region, int E) {
-    return reinterpret_cast<unsigned short *>(region + 3 * E + 32);
-}
-
-struct WindowGeom {
-    int lo0, lo1, lo2;  // window extent (voxels relative to the centre voxel), low corner
-    int n0, n1, n2;     // cells along x, y, z (3 or 4)
-    int dx, dy, dz;     // query voxel relative to the centre voxel
-};
-__device__ __forceinline__ int div34(int w, int n) { return n == 4 ? (w >> 2) : ((w * 43) >> 7); }  // w < 128
-
-// (Re)build the scan list of a region for the query offset g.d*; `scratch` = 32 ints of this group.
-// Lane l answers for the window cells l and l + 32.
-__device__ __forceinline__ void window_index(double *region, int E, const WindowGeom &g, int lane, int *scratch,
-                                             IcpRegionMeta *meta) {
-    const unsigned *C = region_cells(region, E);
-    unsigned short *I = region_list(region, E);
-    const int W = g.n0 * g.n1 * g.n2;
-    int so[2], cnt[2], off[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int w = lane + 32 * h;
-        const unsigned c = C[w];
-        cnt[h] = (int)(c & 63u);
-        off[h] = (int)(c >> 6);
-        const int t = div34(w, g.n2), iz = w - t * g.n2;
-        const int ix = div34(t, g.n1), iy = t - ix * g.n1;
-        const int ox = g.lo0 + ix - g.dx, oy = g.lo1 + iy - g.dy, oz = g.lo2 + iz - g.dz;
-        const bool in = w < W && (unsigned)(ox + 1) < 3u && (unsigned)(oy + 1) < 3u && (unsigned)(oz + 1) < 3u;
-        so[h] = in ? shift_order((ox + 1) * 9 + (oy + 1) * 3 + (oz + 1)) : 31;
-    }
-    // point counts by position in the shift table -> where each voxel's run starts in the list
-    scratch[lane] = 0;
-    group_lds_sync();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-        if (so[h] != 31) scratch[so[h]] = cnt[h];  // the 27 positions are distinct cells
-    group_lds_sync();
-    const int mine = scratch[lane];  // entries 27..31 stay 0
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        const int up = __shfl_up(incl, o, 32);
-        if (lane >= o) incl += up;
-    }
-    const int examined = __shfl(incl, 31, 32);
-    group_lds_sync();  // everybody has read its count
-    scratch[lane] = incl - mine;
-    group_lds_sync();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-        if (so[h] != 31) {
-            const int k0 = scratch[so[h]];
-            for (int j = 0; j < cnt[h]; ++j) I[k0 + j] = (unsigned short)(off[h] + j);
-        }
-    if (lane == 0) {
-        meta->d[0] = (signed char)g.dx;
-        meta->d[1] = (signed char)g.dy;
-        meta->d[2] = (signed char)g.dz;
-        meta->examined = (unsigned short)examined;
-    }
-    group_lds_sync();
-}
-
-// Stage the (widened) neighbourhood of the query s (voxel v) into an LDS region described by *meta;
-// `cells` is this group's scratch of 64 int2.  Returns false when the workgroup's pool is exhausted
-// (the caller then searches HBM directly).  Needs max_points_per_voxel <= 32.
-__device__ __forceinline__ bool window_fill(const MapView &m, const double s[3], const int v[3], int lane,
-                                            int2 *cells, double *pool, int pool_doubles, int *bump,
-                                            IcpRegionMeta *meta, int &range_err) {
-    int lo[3], nn[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double f = s[a] / m.voxel_size - (double)v[a];  // position inside the voxel, [0, 1)
-        lo[a] = (f < kWindowMargin) ? -2 : -1;
-        const int hi = (f > 1.0 - kWindowMargin) ? 2 : 1;
-        nn[a] = hi - lo[a] + 1;
-    }
-    const int W = nn[0] * nn[1] * nn[2];  // <= 64
-    bool ok[2];
-    unsigned long long key[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int w = lane + 32 * h;
-        ok[h] = false;
-        key[h] = 0;
-        if (w < W) {
-            const int iz = w % nn[2], t = w / nn[2], iy = t % nn[1], ix = t / nn[1];
-            const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
-            const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
-            if (voxel_in_range(qx, qy, qz)) {
-                ok[h] = true;
-                key[h] = pack_voxel(qx, qy, qz);
-            } else if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) {
-                range_err = 1;
-            }
-        }
-    }
-    int blk[2], cnt[2];
-    map_find_pair(m, ok[0], key[0], ok[1], key[1], blk[0], cnt[0], blk[1], cnt[1]);
-    // staging order: window order, cells 0..31 first
-    int incl0 = cnt[0], incl1 = cnt[1];
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const int o0 = __shfl_up(incl0, off, 32), o1 = __shfl_up(incl1, off, 32);
-        if (lane >= off) {
-            incl0 += o0;
-            incl1 += o1;
-        }
-    }
-    const int tot0 = __shfl(incl0, 31, 32);
-    const int E = tot0 + __shfl(incl1, 31, 32);
-    const int offs0 = incl0 - cnt[0], offs1 = tot0 + incl1 - cnt[1];
-    cells[lane] = make_int2(blk[0], cnt[0] | (offs0 << 6));
-    cells[lane + 32] = make_int2(blk[1], cnt[1] | (offs1 << 6));
-    // a region of exactly E points: reuse the old allocation when it is large enough,
-    // otherwise take a new one from the workgroup's pool (never freed within a launch)
-    const int need = region_doubles(E);
-    int base = meta->base, cap = meta->cap;
-    if (need > cap) {
-        int nb = -1;
-        if (lane == 0) {
-            nb = atomicAdd(bump, need);
-            if (nb + need > pool_doubles) {
-                atomicAdd(bump, -need);
-                nb = -1;
-            }
-        }
-        nb = __shfl(nb, 0, 32);
-        if (nb < 0) {  // pool exhausted: this query searches HBM directly from now on
-            if (lane == 0) {
-                meta->valid = 0;
-                meta->cap = -1;
-            }
-            return false;
-        }
-        base = nb;
-        cap = need;
-    }
-    double *P = pool + base;
-    unsigned *C = region_cells(P, E);
-    C[lane] = (unsigned)(cnt[0] | (offs0 << 6));
-    C[lane + 32] = (unsigned)(cnt[1] | (offs1 << 6));
-    group_lds_sync();  // cells[] visible to the whole group
-    const int half_shift = threadIdx.x & 32;
-    unsigned long long hits = (unsigned long long)(unsigned)(__ballot(blk[0] >= 0) >> half_shift) |
-                              ((unsigned long long)(unsigned)(__ballot(blk[1] >= 0) >> half_shift) << 32);
-    while (hits) {
-        double2 xy[kFillChunk];
-        double zz[kFillChunk];
-        int info[kFillChunk];
-#pragma unroll
-        for (int u = 0; u < kFillChunk; ++u) {
-            info[u] = -1;
-            if (hits) {
-                const int j = __ffsll((long long)hits) - 1;
-                hits &= hits - 1;
-                const int2 c = cells[j];
-                if (lane < (c.y & 63)) {
-                    info[u] = c.y;
-                    xy[u] = block_xy(m, c.x)[lane];
-                    zz[u] = block_z(m, c.x)[lane];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kFillChunk; ++u) {
-            if (info[u] >= 0) {
-                double *q = P + 3 * ((info[u] >> 6) + lane);
-                q[0] = xy[u].x;
-                q[1] = xy[u].y;
-                q[2] = zz[u];
-            }
-        }
-    }
-    if (lane == 0) {
-        meta->v[0] = v[0];
-        meta->v[1] = v[1];
-        meta->v[2] = v[2];
-        meta->lo[0] = (signed char)lo[0];
-        meta->lo[1] = (signed char)lo[1];
-        meta->lo[2] = (signed char)lo[2];
-        meta->hi[0] = (signed char)(lo[0] + nn[0] - 1);
-        meta->hi[1] = (signed char)(lo[1] + nn[1] - 1);
-        meta->hi[2] = (signed char)(lo[2] + nn[2] - 1);
-        meta->E = E;
-        meta->base = base;
-        meta->cap = cap;
-        meta->valid = 1;
-    }
-    WindowGeom g;
-    g.lo0 = lo[0];
-    g.lo1 = lo[1];
-    g.lo2 = lo[2];
-    g.n0 = nn[0];
-    g.n1 = nn[1];
-    g.n2 = nn[2];
-    g.dx = g.dy = g.dz = 0;  // the query sits in the window's centre voxel right now
-    window_index(P, E, g, lane, reinterpret_cast<int *>(cells), meta);  // (ends with a group sync: points, cells, list, meta visible)
-    return true;
 }
 
 // minimum of (distance, key) over the 32 lanes of a group, lexicographic; every lane ends with the winner.
@@ -618,48 +410,224 @@ __device__ __forceinline__ void group_min_dist_key(double &best, int &key) {
     key = k;
 }
 
-// GetClosestNeighbor over a staged window: 32 lanes stride over the scan list, four candidates per lane in
-// flight per trip, no divergent control flow.  A lane meets its candidates in the reference's order, so
-// strict '<' keeps the reference's choice among equal distances; across lanes the smaller list position wins.
-// Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
-__device__ __forceinline__ double scan_list(const double *region, int E, int examined, double sx, double sy, double sz,
-                                            int lane, double nn[3]) {
-    constexpr int U = 4;
-    const double *P = region;
-    const unsigned short *I = region_list(const_cast<double *>(region), E);
-    double best = DBL_MAX;
-    int bi = 0x7FFFFFFF;
-    for (int i0 = lane; __ballot(i0 < examined) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
-        int pos[U];
+// Establish the known window of the query s (voxel v): make sure every occupied voxel of the window is in
+// the tile.  Lane l answers for the window cells l and l + 32.  Returns false when the query cannot use the
+// tile (a voxel outside the tile's coordinate span, table or store full): it then searches HBM directly.
+__device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, const double s[3], const int v[3], int lane,
+                                          IcpQueryMeta *meta, int &range_err) {
+    int lo[3], nn[3];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 32 * u;
-            pos[u] = (int)I[i < examined ? i : 0];
+    for (int a = 0; a < 3; ++a) {
+        const double f = s[a] / m.voxel_size - (double)v[a];  // position inside the voxel, [0, 1)
+        lo[a] = (f < kWindowMargin) ? -2 : -1;
+        const int hi = (f > 1.0 - kWindowMargin) ? 2 : 1;
+        nn[a] = hi - lo[a] + 1;
+    }
+    const int W = nn[0] * nn[1] * nn[2];  // <= 64
+    bool need[2];             // this cell must be looked up in the map (HBM)
+    unsigned long long key[2];
+    unsigned rkey[2];
+    bool fail = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int w = lane + 32 * h;
+        need[h] = false;
+        key[h] = 0;
+        rkey[h] = 0;
+        if (w < W) {
+            const int iz = w % nn[2], t = w / nn[2], iy = t % nn[1], ix = t / nn[1];
+            const int ox = lo[0] + ix, oy = lo[1] + iy, oz = lo[2] + iz;
+            const int qx = v[0] + ox, qy = v[1] + oy, qz = v[2] + oz;
+            if (voxel_in_range(qx, qy, qz)) {
+                if (!tile_rel(tile, qx, qy, qz, rkey[h])) {
+                    fail = true;  // outside the span of the relative keys
+                } else {
+                    const int slot = tile_find(tile, rkey[h]);
+                    if (slot < 0) {
+                        need[h] = true;
+                        key[h] = pack_voxel(qx, qy, qz);
+                    } else if (__hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kTileOverflow) {
+                        fail = true;
+                    }
+                }
+            } else if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) {
+                range_err = 1;
+            }
         }
+    }
+    const int half_shift = threadIdx.x & 32;
+    if ((unsigned)(__ballot(fail) >> half_shift) != 0u) {
+        if (lane == 0) meta->valid = -1;  // do not try again
+        return false;
+    }
+    // the voxels the tile does not know yet: one map lookup each, both of a lane's in flight together
+    int blk[2], cnt[2];
+    map_find_pair(m, need[0], key[0], need[1], key[1], blk[0], cnt[0], blk[1], cnt[1]);
+    // occupied ones enter the table; whoever claims the slot also fetches the points (another query of this
+    // workgroup may be asking for the same voxel at the same moment)
+    bool won[2];
+    int slot[2], off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        won[h] = false;
+        slot[h] = -1;
+        off[h] = 0;
+        if (need[h] && blk[h] >= 0 && cnt[h] > 0) {
+            unsigned sidx = tile_hash(rkey[h]);
+            bool placed = false;
+            for (int probes = 0; probes < kIcpTileSlots; ++probes) {
+                const unsigned old = atomicCAS(&tile.keys[sidx], kTileEmpty, rkey[h]);
+                if (old == kTileEmpty) {
+                    won[h] = true;
+                    slot[h] = (int)sidx;
+                    placed = true;
+                    break;
+                }
+                if (old == rkey[h]) {
+                    placed = true;  // somebody else is bringing it in
+                    break;
+                }
+                sidx = (sidx + 1) & (kIcpTileSlots - 1);
+            }
+            if (!placed) fail = true;  // table full
+            if (won[h]) {
+                off[h] = atomicAdd(tile.count, cnt[h]);
+                if (off[h] + cnt[h] > tile.cap_points || off[h] + cnt[h] > 0xFFFF) {  // store full
+                    __hip_atomic_store(&tile.vals[slot[h]], kTileOverflow | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    won[h] = false;
+                    fail = true;
+                }
+            }
+        }
+    }
+    // the group copies the voxels its lanes have won: lane i fetches point i (one 16-byte + one 8-byte load,
+    // coalesced), kFillChunk voxels in flight
+    unsigned long long todo = (unsigned long long)(unsigned)(__ballot(won[0]) >> half_shift) |
+                              ((unsigned long long)(unsigned)(__ballot(won[1]) >> half_shift) << 32);
+    while (todo) {
+        double2 xy[kFillChunk];
+        double zz[kFillChunk];
+        int dst[kFillChunk];
+#pragma unroll
+        for (int u = 0; u < kFillChunk; ++u) {
+            dst[u] = -1;
+            if (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int src = j & 31;
+                const int b0 = __shfl(blk[0], src, 32), b1 = __shfl(blk[1], src, 32);
+                const int c0 = __shfl(cnt[0], src, 32), c1 = __shfl(cnt[1], src, 32);
+                const int o0 = __shfl(off[0], src, 32), o1 = __shfl(off[1], src, 32);
+                const int bj = j < 32 ? b0 : b1, cj = j < 32 ? c0 : c1, oj = j < 32 ? o0 : o1;
+                if (lane < cj) {
+                    dst[u] = oj + lane;
+                    xy[u] = block_xy(m, bj)[lane];
+                    zz[u] = block_z(m, bj)[lane];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFillChunk; ++u) {
+            if (dst[u] >= 0) {
+                double *q = tile.points + 3 * dst[u];
+                q[0] = xy[u].x;
+                q[1] = xy[u].y;
+                q[2] = zz[u];
+            }
+        }
+    }
+    group_lds_sync();  // the points are in the store before their table entries say so
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (won[h])
+            __hip_atomic_store(&tile.vals[slot[h]], (unsigned)off[h] | ((unsigned)cnt[h] << 16) | kTileReady, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool failed = (unsigned)(__ballot(fail) >> half_shift) != 0u;
+    if (lane == 0) {
+        meta->v[0] = v[0];
+        meta->v[1] = v[1];
+        meta->v[2] = v[2];
+        meta->lo[0] = (signed char)lo[0];
+        meta->lo[1] = (signed char)lo[1];
+        meta->lo[2] = (signed char)lo[2];
+        meta->hi[0] = (signed char)(lo[0] + nn[0] - 1);
+        meta->hi[1] = (signed char)(lo[1] + nn[1] - 1);
+        meta->hi[2] = (signed char)(lo[2] + nn[2] - 1);
+        meta->valid = failed ? -1 : 1;
+    }
+    group_lds_sync();
+    return !failed;
+}
+
+// GetClosestNeighbor against the tile: lane j < 27 takes the j-th voxel of the reference's shift table
+// (VoxelHashMap.cpp:35-41), finds it in the table (a miss is an empty voxel: the query is inside its known
+// window) and walks its points in order.  A lane meets its points in the reference's order, so strict '<'
+// keeps the first minimum inside the voxel; across lanes the smaller shift position wins among equal
+// distances -- the reference's nested strict '<' loops.  The work per query is bounded by the fullest
+// voxel (max_points_per_voxel steps), not by the size of the neighbourhood.
+// Returns the squared distance (DBL_MAX: no candidate), the neighbour, the number of points examined;
+// bad = the tile cannot answer: 1 a voxel is still being fetched by a concurrent fill, 2 one did not fit.
+__device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz, int lane,
+                                            double nn[3], int &examined, int &bad) {
+    constexpr int U = 4;
+    int off = 0, cnt = 0;
+    int mybad = 0;
+    if (lane < 27) {
+        const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
+        const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
+        const int qz = vz + (int)((kShift.z >> (2 * lane)) & 3) - 1;
+        unsigned rkey;
+        if (tile_rel(tile, qx, qy, qz, rkey)) {
+            const int slot = tile_find(tile, rkey);
+            if (slot >= 0) {
+                const unsigned val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (val & kTileOverflow) mybad = 2;
+                else if (!(val & kTileReady)) mybad = 1;
+                off = (int)(val & 0xFFFFu);
+                cnt = (int)((val >> 16) & 63u);
+            }
+        } else {
+            mybad = 2;
+        }
+    }
+    const int half_shift = threadIdx.x & 32;
+    bad = (unsigned)(__ballot(mybad == 2) >> half_shift) != 0u ? 2 : ((unsigned)(__ballot(mybad == 1) >> half_shift) != 0u ? 1 : 0);
+    if (bad) cnt = 0;
+    int tot = cnt;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
+    examined = tot;
+    const double *P = tile.points + 3 * off;
+    double best = DBL_MAX;
+    int bk = 0;
+    for (int k0 = 0; __ballot(k0 < cnt) != 0ull; k0 += U) {  // wave-uniform trip count
         double x[U], y[U], z[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const double *q = P + 3 * pos[u];
+            const int k = (k0 + u < cnt) ? k0 + u : 0;
+            const double *q = P + 3 * k;
             x[u] = q[0];
             y[u] = q[1];
             z[u] = q[2];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + 32 * u;
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
             const double d = (ex * ex + ey * ey) + ez * ez;
-            const bool take = (i < examined) & (d < best);
+            const bool take = (k0 + u < cnt) & (d < best);
             best = take ? d : best;
-            bi = take ? i : bi;
+            bk = take ? k0 + u : bk;
         }
     }
-    group_min_dist_key(best, bi);
-    const int p = (int)I[bi != 0x7FFFFFFF ? bi : 0];
-    const bool found = bi != 0x7FFFFFFF;
-    nn[0] = found ? P[3 * p] : 0.0;
-    nn[1] = found ? P[3 * p + 1] : 0.0;
-    nn[2] = found ? P[3 * p + 2] : 0.0;
+    int key = (cnt > 0 && best < DBL_MAX) ? ((lane << 5) | bk) : 0x7FFFFFFF;
+    const int pos = off + bk;
+    group_min_dist_key(best, key);
+    const bool found = key != 0x7FFFFFFF;
+    const int wpos = __shfl(pos, found ? (key >> 5) : 0, 32);
+    const double *w = tile.points + 3 * (found ? wpos : 0);
+    nn[0] = found ? w[0] : 0.0;
+    nn[1] = found ? w[1] : 0.0;
+    nn[2] = found ? w[2] : 0.0;
     return best;
 }
 

@@ -1,0 +1,66 @@
+// kicp_sort.hip -- spatial order of the source cloud for the persistent ICP kernel.
+//
+// k_icp gives every workgroup a CONTIGUOUS run of the source cloud and keeps the map voxels that run
+// needs in LDS (its "tile").  For the tile to be small the run must be compact in space, so the cloud is
+// ordered by {Morton code of the point's 2-voxel cell in the sensor frame, original index}: the index
+// makes the keys unique, hence the order -- and with it every floating-point sum downstream --
+// deterministic.  Rigid motion preserves neighbourhoods, so the sensor frame is as good as the map frame
+// (and is available before the pose is).  The sort itself is rocPRIM's device radix sort (a plain library
+// sort; everything on the registration path proper is hand-written).
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "kicp_launch.hpp"
+
+namespace kicp {
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// keys[i] = morton30(cell of point i) << 24 | i for i < n, all ones behind (they sort to the end)
+__global__ __launch_bounds__(256) void k_tile_keys(const double *xyz, const int *n_ptr, int n_imm, int n_max, double inv_cell,
+                                                   unsigned long long *keys) {
+    const int n = n_ptr ? *n_ptr : n_imm;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_max; i += gridDim.x * blockDim.x) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            // 2-voxel cells, offset so that +-512 cells around the sensor map to 0..1023 (farther points clamp:
+            // only the quality of the order is at stake)
+            const double cx = floor(xyz[3 * i] * inv_cell) + 512.0, cy = floor(xyz[3 * i + 1] * inv_cell) + 512.0,
+                         cz = floor(xyz[3 * i + 2] * inv_cell) + 512.0;
+            const unsigned ux = (unsigned)fmin(fmax(cx, 0.0), 1023.0), uy = (unsigned)fmin(fmax(cy, 0.0), 1023.0),
+                           uz = (unsigned)fmin(fmax(cz, 0.0), 1023.0);
+            const unsigned long long m = (unsigned long long)(spread10(ux) | (spread10(uy) << 1) | (spread10(uz) << 2));
+            k = (m << 24) | (unsigned long long)(unsigned)i;
+        }
+        keys[i] = k;
+    }
+}
+
+size_t tile_sort_temp_bytes(size_t n_max) {
+    size_t bytes = 0;
+    unsigned long long *k = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, k, k, n_max ? n_max : 1, 0, 54, (hipStream_t) nullptr);
+    return bytes + 256;
+}
+
+int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_max, double voxel_size, unsigned long long *keys_in,
+                     unsigned long long *keys_out, void *temp, size_t temp_bytes, hipStream_t s) {
+    if (n_max == 0) return 0;
+    if (n_max > ((size_t)1 << 24)) return (int)hipErrorInvalidValue;  // 24 index bits
+    const int grid = (int)((n_max + 255) / 256 < 1024 ? (n_max + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_tile_keys, dim3(grid), dim3(256), 0, s, xyz, n_ptr, n_imm, (int)n_max, 1.0 / (2.0 * voxel_size), keys_in);
+    const hipError_t e = rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n_max, 0, 54, s);
+    return (int)e;
+}
+
+}  // namespace kicp

@@ -4,16 +4,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'kiss-icp_amd',
 import numpy as np
 from kiss_icp_amd import _cabi
 from kiss_icp_amd.config import load_config
-from kiss_icp_amd.datasets import generate_scans, kitti_like, kitti_like_vegetated
+from kiss_icp_amd.datasets import generate_scans, kitti_like, kitti_like_vegetated, livox_like
 from kiss_icp_amd.kiss_icp import KissICP
 opts = dict(a.split('=') for a in sys.argv[1:])
 street = opts.pop('street', '0') == '1'  # street=1: round 1's bare street scene
+livox = opts.pop('livox', '0') == '1'    # livox=1: the 1M-point / 0.1 m configuration
 opts.setdefault('icp_profile', '1')
 for k, v in opts.items():
     _cabi.set_option(k, int(v))
-nf = 14 if street else 30
-scans = generate_scans(kitti_like if street else kitti_like_vegetated, dict(seed=0, n_frames=nf), range(nf))
-k = KissICP(load_config(deskew=False))
+nf = 14 if street else (20 if livox else 30)
+scans = generate_scans(livox_like if livox else (kitti_like if street else kitti_like_vegetated), dict(seed=2 if livox else 0, n_frames=nf), range(nf))
+k = KissICP(load_config(deskew=False, voxel_size=0.1) if livox else load_config(deskew=False))
 for i in range(nf):
     k.register_frame_async(scans[i][0])
 k.sync()
