@@ -698,6 +698,7 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
         s = KICP_ERR_HIP;
     }
     if (s == KICP_OK) s = r->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
+    if (s == KICP_OK) s = r->tile_ext.reserve((size_t)kIcpMaxBlocks * kIcpTileExtPoints * 3 * sizeof(double));
     if (s != KICP_OK) {
         kicp_registration_destroy(r);
         return s;
@@ -720,6 +721,7 @@ int kicp_registration_destroy(kicp_registration *r) {
     r->sort_in.release();
     r->sort_out.release();
     r->sort_tmp.release();
+    r->tile_ext.release();
     r->granules.release();
     r->state.release();
     if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -776,6 +778,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         const int G = icp_fill_policy(r->device, P, n, cap);
         P.frame = r->frame.as<double>();
         P.order = sorted ? r->sort_out.as<unsigned long long>() : nullptr;
+        P.tile_ext = r->tile_ext.as<double>();
         P.work = r->work.as<double>();
         P.n_ptr = nullptr;
         P.n_imm = (int)n;
@@ -1045,6 +1048,7 @@ struct kicp_pipeline {
     // exist twice, indexed by frame parity; so do the upload targets raw / ts of the host-input path
     DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
     DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
+    DevBuf tile_ext;                        // HBM extension of the ICP workgroups' voxel tiles
     size_t sort_tmp_bytes = 0;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
@@ -1302,6 +1306,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap);
     I.frame = p->src[par].as<double>();
     I.order = sorted ? p->sort_out[par].as<unsigned long long>() : nullptr;
+    I.tile_ext = p->tile_ext.as<double>();
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
     I.prep = prep;
@@ -1504,6 +1509,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     }
     if (s == KICP_OK) s = p->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
     if (s == KICP_OK) s = p->prep.reserve(2 * sizeof(PrepState));
+    if (s == KICP_OK) s = p->tile_ext.reserve((size_t)kIcpMaxBlocks * kIcpTileExtPoints * 3 * sizeof(double));
     if (s == KICP_OK) s = pipe_reserve(p, 0);  // minimum buffers: the first scan may be empty
     if (s != KICP_OK) {
         if (s == KICP_ERR_HIP) set_error("pipeline resource creation failed");
@@ -1533,7 +1539,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
                       &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
-                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp})
+                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->tile_ext})
         b->release();
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);

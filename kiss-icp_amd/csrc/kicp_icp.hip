@@ -62,7 +62,9 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     int next_point;   // phase B: next unserved point of the chunk
     int origin[3];    // voxel with relative tile coordinates (0, 0, 0)
     int any_fill;     // phase A: some query of the chunk is outside its known window
-    int pad[1];
+    int ext_points;   // points handed out from the tile's extension
+    int list_entries; // entries handed out from the scan-list pool
+    int pad[3];
     double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
@@ -111,16 +113,24 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const int q0 = (int)blockIdx.x * n_run;
     const int n_local = max(0, min(n_run, n - q0));
     const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_run, kIcpMaxMeta) : 0;
+    const bool use_lists = n_meta > 0 && n_run <= kIcpListRunMax;
     Tile tile;
     {
         char *q = smem + sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpQueryMeta);
         tile.keys = reinterpret_cast<unsigned *>(q);
         tile.vals = tile.keys + kIcpTileSlots;
-        tile.points = reinterpret_cast<double *>(q + (size_t)2 * kIcpTileSlots * sizeof(unsigned));
-        const long room = (long)P.lds_bytes - (long)(sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpQueryMeta) +
-                                                    (size_t)2 * kIcpTileSlots * sizeof(unsigned));
-        tile.cap_points = n_meta > 0 && room > 0 ? (int)(room / (3 * sizeof(double))) : 0;
+        q += (size_t)2 * kIcpTileSlots * sizeof(unsigned);
+        tile.lists = use_lists ? reinterpret_cast<unsigned short *>(q) : nullptr;
+        tile.list_cap = use_lists ? kIcpListPool : 0;
+        tile.list_count = &sh.list_entries;
+        if (use_lists) q += (size_t)kIcpListPool * sizeof(unsigned short);
+        tile.points = reinterpret_cast<double *>(q);
+        const long room = (long)P.lds_bytes - (long)(q - smem);
+        tile.cap_points = n_meta > 0 && room > 0 ? (int)min((long)0xFFFF, room / (long)(3 * sizeof(double))) : 0;
         tile.count = &sh.tile_points;
+        tile.ext = (P.tile_ext && n_meta > 0) ? P.tile_ext + (size_t)blockIdx.x * kIcpTileExtPoints * 3 : nullptr;
+        tile.ext_cap = tile.ext ? kIcpTileExtPoints : 0;
+        tile.ext_count = &sh.ext_points;
         tile.ox = tile.oy = tile.oz = 0;  // set once the first point's voxel is known
     }
     double(*terms)[kIcpTerms] = sh.terms;
@@ -147,6 +157,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if (tid == 0) {
         sh.fail = 0;
         sh.tile_points = 0;
+        sh.ext_points = 0;
+        sh.list_entries = 0;
         sh.any_fill = 0;
         const SE3 id = se3_identity();
 #pragma unroll
@@ -161,7 +173,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
     }
-    for (int i = tid; i < n_meta; i += kIcpThreads) metas[i].valid = 0;
+    for (int i = tid; i < n_meta; i += kIcpThreads) {
+        metas[i].valid = 0;
+        metas[i].list_state = 0;
+        metas[i].list_base = 0;
+        metas[i].list_n = metas[i].list_cap = 0;
+    }
     if (n_meta > 0)
         for (int i = tid; i < kIcpTileSlots; i += kIcpThreads) {
             tile.keys[i] = kTileEmpty;
@@ -272,13 +289,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const int vx = pt.v[0], vy = pt.v[1], vz = pt.v[2];
                 int flag = pt.flag;
                 IcpQueryMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
-                int path = flag == 0 ? 0 : 3;  // profiling: 0 tile, 3 HBM search
+                int path = flag == 0 ? 0 : 3;  // profiling: 0 tile (lane per voxel), 1 tile (scan list), 3 HBM search
                 const unsigned tb = PROF ? ticks32() : 0u;
                 const unsigned tc = tb;
                 double nn[3];
                 double d2 = DBL_MAX;
                 int E = 0;
-                if (flag == 0) {
+                bool listed = false;
+                if (flag == 0 && use_lists && meta->list_state >= 0) {
+                    // the scan list belongs to the voxel the query was in when it was built
+                    if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz)
+                        tile_list_build(tile, vx, vy, vz, lane, meta);
+                    if (meta->list_state == 1) {
+                        E = meta->list_n;
+                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn);
+                        listed = true;
+                        path = 1;
+                    }
+                }
+                if (flag == 0 && !listed) {
                     int bad;
                     d2 = tile_scan(tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad);
                     if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is

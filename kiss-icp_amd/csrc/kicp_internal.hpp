@@ -165,8 +165,11 @@ constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the wh
 constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time
 constexpr int kIcpTermChunk = 64;  // points whose products are in LDS together (a multiple of the group count)
 constexpr int kIcpTerms = 18;      // 16 normal-equation scalars + correspondence count + examined count
-constexpr int kIcpMaxMeta = 512;   // local points of a workgroup that may use the workgroup's voxel tile (48 bytes each)
+constexpr int kIcpMaxMeta = 448;   // local points of a workgroup that may use the workgroup's voxel tile (64 bytes each)
 constexpr int kIcpTileSlots = 4096;  // slots of the workgroup's voxel table (occupied voxels only; power of two)
+constexpr int kIcpListRunMax = 64;   // workgroups that serve at most this many points keep a scan list per point
+constexpr int kIcpListPool = 12288;  // 16-bit entries of the scan-list pool (24 KiB)
+constexpr int kIcpTileExtPoints = 16384;  // points of a workgroup's tile extension in HBM (voxels that do not fit in LDS)
 constexpr size_t kIcpGroupProfileWords = (size_t)kIcpProfIters * kIcpMaxBlocks * kIcpGroupsPerBlock * 4;
 
 // LDS record of one source point ("query") of a workgroup of the persistent ICP kernel
@@ -174,15 +177,19 @@ struct IcpQueryMeta {
     double s[3];  // running transformed source point
     int v[3];     // voxel the known window is centred on
     signed char lo[3], hi[3];  // extent of the known window per axis, in voxels relative to v (-2..-1, 1..2)
-    signed char valid;  // 1: every occupied voxel of the window is in the tile; 0: not looked yet; -1: cannot use the tile
-    char pad;
+    signed char valid;       // 1: every occupied voxel of the window is in the tile; 0: not looked yet; -1: cannot use the tile
+    signed char list_state;  // 1: the scan list is current for voxel lv; 0: none yet; -1: cannot have one
+    int lv[3];               // voxel of the query the scan list was built for
+    int list_base;           // first entry of the list in the pool
+    unsigned short list_n, list_cap;
 };
-static_assert(sizeof(IcpQueryMeta) == 48, "IcpQueryMeta layout");
+static_assert(sizeof(IcpQueryMeta) == 64, "IcpQueryMeta layout");
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
     const unsigned long long *order;  // sorted tile keys (low 24 bits: index into frame) or nullptr (identity)
     double *work;         // N x 3 transformed source, private to the launch
+    double *tile_ext;     // [gridDim.x][kIcpTileExtPoints] xyz triples: tile extension of each workgroup, or nullptr
     const int *n_ptr;     // device count (pipeline) or nullptr
     int n_imm;            // count when n_ptr == nullptr
     MapView map;
@@ -285,7 +292,7 @@ struct kicp_registration {
     hipStream_t stream = nullptr;
     int max_iters = 500;
     double conv = 1e-4;
-    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp;
+    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, tile_ext;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

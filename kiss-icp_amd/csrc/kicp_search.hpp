@@ -320,17 +320,30 @@ constexpr double kWindowMargin = 0.125;  // fraction of a voxel
 constexpr int kFillChunk = 8;             // voxels whose points are in flight together during a fill
 constexpr unsigned kTileEmpty = 0xFFFFFFFFu;
 constexpr unsigned kTileReady = 0x80000000u;     // the voxel's points are in the store
-constexpr unsigned kTileOverflow = 0x40000000u;  // the store was full: queries that need this voxel search HBM
+constexpr unsigned kTileOverflow = 0x40000000u;  // neither store had room: queries that need this voxel search HBM
+constexpr unsigned kTileExt = 0x20000000u;       // the points are in the tile's extension in HBM, not in LDS
 constexpr int kTileSpan = 1024;                  // relative voxel coordinates 0 .. 1023 per axis
 
 struct Tile {
     unsigned *keys;  // [kIcpTileSlots] relative voxel key (10 bits per axis) or kTileEmpty
     unsigned *vals;  // [kIcpTileSlots] first point (bits 0..15) | points (bits 16..21) | flags
-    double *points;  // xyz triples
+    double *points;  // xyz triples in LDS
     int cap_points;
-    int *count;      // points handed out so far
+    int *count;      // LDS points handed out so far
+    double *ext;     // xyz triples in HBM (this workgroup's slice), or nullptr
+    int ext_cap;
+    int *ext_count;
+    unsigned short *lists;  // pool of scan lists (small runs only), or nullptr
+    int list_cap;
+    int *list_count;
     int ox, oy, oz;  // voxel with relative coordinates (0, 0, 0)
 };
+// a point of the extension: written by another wave of this workgroup earlier in the launch; agent-scope
+// loads bypass this CU's L1, which may hold the line from before the write
+__device__ __forceinline__ double ext_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
 __device__ __forceinline__ bool tile_rel(const Tile &t, int qx, int qy, int qz, unsigned &key) {
     const unsigned rx = (unsigned)(qx - t.ox), ry = (unsigned)(qy - t.oy), rz = (unsigned)(qz - t.oz);
     key = (rx << 20) | (ry << 10) | rz;
@@ -465,11 +478,12 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
     map_find_pair(m, need[0], key[0], need[1], key[1], blk[0], cnt[0], blk[1], cnt[1]);
     // occupied ones enter the table; whoever claims the slot also fetches the points (another query of this
     // workgroup may be asking for the same voxel at the same moment)
-    bool won[2];
+    bool won[2], in_ext[2];
     int slot[2], off[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         won[h] = false;
+        in_ext[h] = false;
         slot[h] = -1;
         off[h] = 0;
         if (need[h] && blk[h] >= 0 && cnt[h] > 0) {
@@ -492,10 +506,16 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
             if (!placed) fail = true;  // table full
             if (won[h]) {
                 off[h] = atomicAdd(tile.count, cnt[h]);
-                if (off[h] + cnt[h] > tile.cap_points || off[h] + cnt[h] > 0xFFFF) {  // store full
-                    __hip_atomic_store(&tile.vals[slot[h]], kTileOverflow | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    won[h] = false;
-                    fail = true;
+                if (off[h] + cnt[h] > tile.cap_points) {  // LDS store full: the voxel goes to the extension in HBM
+                    const int g = tile.ext ? atomicAdd(tile.ext_count, cnt[h]) : tile.ext_cap;
+                    if (g + cnt[h] <= tile.ext_cap) {
+                        off[h] = g;
+                        in_ext[h] = true;
+                    } else {  // nowhere to put it
+                        __hip_atomic_store(&tile.vals[slot[h]], kTileOverflow | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        won[h] = false;
+                        fail = true;
+                    }
                 }
             }
         }
@@ -517,10 +537,10 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
                 const int src = j & 31;
                 const int b0 = __shfl(blk[0], src, 32), b1 = __shfl(blk[1], src, 32);
                 const int c0 = __shfl(cnt[0], src, 32), c1 = __shfl(cnt[1], src, 32);
-                const int o0 = __shfl(off[0], src, 32), o1 = __shfl(off[1], src, 32);
+                const int o0 = __shfl(off[0] | (in_ext[0] ? 0x40000000 : 0), src, 32), o1 = __shfl(off[1] | (in_ext[1] ? 0x40000000 : 0), src, 32);
                 const int bj = j < 32 ? b0 : b1, cj = j < 32 ? c0 : c1, oj = j < 32 ? o0 : o1;
                 if (lane < cj) {
-                    dst[u] = oj + lane;
+                    dst[u] = oj + lane;  // bit 30: extension
                     xy[u] = block_xy(m, bj)[lane];
                     zz[u] = block_z(m, bj)[lane];
                 }
@@ -529,19 +549,20 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 #pragma unroll
         for (int u = 0; u < kFillChunk; ++u) {
             if (dst[u] >= 0) {
-                double *q = tile.points + 3 * dst[u];
+                double *q = (dst[u] & 0x40000000) ? tile.ext + 3 * (dst[u] & 0xFFFF) : tile.points + 3 * dst[u];
                 q[0] = xy[u].x;
                 q[1] = xy[u].y;
                 q[2] = zz[u];
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);  // (stores to the extension have left the CU)
     group_lds_sync();  // the points are in the store before their table entries say so
 #pragma unroll
     for (int h = 0; h < 2; ++h)
         if (won[h])
-            __hip_atomic_store(&tile.vals[slot[h]], (unsigned)off[h] | ((unsigned)cnt[h] << 16) | kTileReady, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&tile.vals[slot[h]], (unsigned)off[h] | ((unsigned)cnt[h] << 16) | kTileReady | (in_ext[h] ? kTileExt : 0u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const bool failed = (unsigned)(__ballot(fail) >> half_shift) != 0u;
     if (lane == 0) {
         meta->v[0] = v[0];
@@ -554,6 +575,7 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
         meta->hi[1] = (signed char)(lo[1] + nn[1] - 1);
         meta->hi[2] = (signed char)(lo[2] + nn[2] - 1);
         meta->valid = failed ? -1 : 1;
+        meta->list_state = 0;  // whatever list there was belongs to the old window
     }
     group_lds_sync();
     return !failed;
@@ -572,6 +594,7 @@ __device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double 
     constexpr int U = 4;
     int off = 0, cnt = 0;
     int mybad = 0;
+    bool ext = false;
     if (lane < 27) {
         const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
         const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
@@ -585,6 +608,7 @@ __device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double 
                 else if (!(val & kTileReady)) mybad = 1;
                 off = (int)(val & 0xFFFFu);
                 cnt = (int)((val >> 16) & 63u);
+                ext = (val & kTileExt) != 0u;
             }
         } else {
             mybad = 2;
@@ -597,37 +621,188 @@ __device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double 
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
     examined = tot;
-    const double *P = tile.points + 3 * off;
     double best = DBL_MAX;
     int bk = 0;
-    for (int k0 = 0; __ballot(k0 < cnt) != 0ull; k0 += U) {  // wave-uniform trip count
+    {   // voxels held in LDS
+        const double *P = tile.points + 3 * off;
+        const int c = ext ? 0 : cnt;
+        for (int k0 = 0; __ballot(k0 < c) != 0ull; k0 += U) {  // wave-uniform trip count
+            double x[U], y[U], z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double *q = P + 3 * ((k0 + u < c) ? k0 + u : 0);
+                x[u] = q[0];
+                y[u] = q[1];
+                z[u] = q[2];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const bool take = (k0 + u < c) & (d < best);
+                best = take ? d : best;
+                bk = take ? k0 + u : bk;
+            }
+        }
+    }
+    if (__ballot(ext && cnt > 0) != 0ull) {  // voxels held in the extension (HBM / L2): same walk, global loads
+        const double *P = tile.ext + 3 * (ext ? off : 0);
+        const int c = ext ? cnt : 0;
+        for (int k0 = 0; __ballot(k0 < c) != 0ull; k0 += U) {
+            double x[U], y[U], z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double *q = P + 3 * ((k0 + u < c) ? k0 + u : 0);
+                x[u] = c > 0 ? ext_load(q) : 0.0;
+                y[u] = c > 0 ? ext_load(q + 1) : 0.0;
+                z[u] = c > 0 ? ext_load(q + 2) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const bool take = (k0 + u < c) & (d < best);
+                best = take ? d : best;
+                bk = take ? k0 + u : bk;
+            }
+        }
+    }
+    // every lane fetches its own best point again; the winner's then goes to the whole group
+    double bx = 0.0, by = 0.0, bz = 0.0;
+    if (cnt > 0) {
+        if (ext) {
+            const double *q = tile.ext + 3 * (off + bk);
+            bx = ext_load(q);
+            by = ext_load(q + 1);
+            bz = ext_load(q + 2);
+        } else {
+            const double *q = tile.points + 3 * (off + bk);
+            bx = q[0];
+            by = q[1];
+            bz = q[2];
+        }
+    }
+    int key = (cnt > 0 && best < DBL_MAX) ? ((lane << 5) | bk) : 0x7FFFFFFF;
+    group_min_dist_key(best, key);
+    const bool found = key != 0x7FFFFFFF;
+    const int wl = found ? (key >> 5) : 0;
+    nn[0] = __shfl(bx, wl, 32);
+    nn[1] = __shfl(by, wl, 32);
+    nn[2] = __shfl(bz, wl, 32);
+    return best;
+}
+
+// Scan lists (workgroups with few points, i.e. full-size voxels and long neighbourhoods): the positions, in
+// the LDS store, of the points of a query's 27 voxels in exactly the order the reference visits them, 16 bits
+// each.  The search then strides over the list with all 32 lanes -- ~3x fewer steps than one lane per voxel
+// when voxels hold 20 points -- and strict '<' plus "smaller list position wins" reproduces the reference's
+// tie rules.  Built from the table (no HBM access) whenever the query enters another voxel.  Returns false
+// when the query cannot have a list (a voxel in the extension or missing from the tile, pool exhausted).
+__device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy, int vz, int lane, IcpQueryMeta *meta) {
+    int off = 0, cnt = 0;
+    bool mybad = false;
+    if (lane < 27) {
+        const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
+        const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
+        const int qz = vz + (int)((kShift.z >> (2 * lane)) & 3) - 1;
+        unsigned rkey;
+        if (tile_rel(tile, qx, qy, qz, rkey)) {
+            const int slot = tile_find(tile, rkey);
+            if (slot >= 0) {
+                const unsigned val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((val & (kTileOverflow | kTileExt)) || !(val & kTileReady)) mybad = true;
+                off = (int)(val & 0xFFFFu);
+                cnt = (int)((val >> 16) & 63u);
+            }
+        } else {
+            mybad = true;
+        }
+    }
+    const int half_shift = threadIdx.x & 32;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int up = __shfl_up(incl, o, 32);
+        if (lane >= o) incl += up;
+    }
+    const int total = __shfl(incl, 31, 32);
+    bool fail = (unsigned)(__ballot(mybad) >> half_shift) != 0u || total > 0xFFFF;
+    int base = meta->list_base;
+    if (!fail && total > (int)meta->list_cap) {  // a longer list than before: new room from the pool (the old one is abandoned)
+        int nb = -1;
+        const int want = total + 16;
+        if (lane == 0) {
+            nb = atomicAdd(tile.list_count, want);
+            if (nb + want > tile.list_cap) nb = -1;
+        }
+        nb = __shfl(nb, 0, 32);
+        if (nb < 0) {
+            fail = true;
+        } else {
+            base = nb;
+            if (lane == 0) {
+                meta->list_base = nb;
+                meta->list_cap = (unsigned short)want;
+            }
+        }
+    }
+    if (fail) {
+        if (lane == 0) meta->list_state = -1;
+        group_lds_sync();
+        return false;
+    }
+    unsigned short *I = tile.lists + base + (incl - cnt);
+    for (int i = 0; i < cnt; ++i) I[i] = (unsigned short)(off + i);
+    if (lane == 0) {
+        meta->lv[0] = vx;
+        meta->lv[1] = vy;
+        meta->lv[2] = vz;
+        meta->list_n = (unsigned short)total;
+        meta->list_state = 1;
+    }
+    group_lds_sync();
+    return true;
+}
+
+// GetClosestNeighbor over a scan list: 32 lanes stride over it, four candidates per lane in flight per trip,
+// no divergent control flow.  Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
+__device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigned short *I, int n, double sx, double sy, double sz,
+                                                 int lane, double nn[3]) {
+    constexpr int U = 4;
+    const double *P = tile.points;
+    double best = DBL_MAX;
+    int bi = 0x7FFFFFFF;
+    for (int i0 = lane; __ballot(i0 < n) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
+        int pos[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 32 * u;
+            pos[u] = (int)I[i < n ? i : 0];
+        }
         double x[U], y[U], z[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k = (k0 + u < cnt) ? k0 + u : 0;
-            const double *q = P + 3 * k;
+            const double *q = P + 3 * pos[u];
             x[u] = q[0];
             y[u] = q[1];
             z[u] = q[2];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const int i = i0 + 32 * u;
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
             const double d = (ex * ex + ey * ey) + ez * ez;
-            const bool take = (k0 + u < cnt) & (d < best);
+            const bool take = (i < n) & (d < best);
             best = take ? d : best;
-            bk = take ? k0 + u : bk;
+            bi = take ? i : bi;
         }
     }
-    int key = (cnt > 0 && best < DBL_MAX) ? ((lane << 5) | bk) : 0x7FFFFFFF;
-    const int pos = off + bk;
-    group_min_dist_key(best, key);
-    const bool found = key != 0x7FFFFFFF;
-    const int wpos = __shfl(pos, found ? (key >> 5) : 0, 32);
-    const double *w = tile.points + 3 * (found ? wpos : 0);
-    nn[0] = found ? w[0] : 0.0;
-    nn[1] = found ? w[1] : 0.0;
-    nn[2] = found ? w[2] : 0.0;
+    group_min_dist_key(best, bi);
+    const bool found = bi != 0x7FFFFFFF;
+    const int p = (int)I[found ? bi : 0];
+    nn[0] = found ? P[3 * p] : 0.0;
+    nn[1] = found ? P[3 * p + 1] : 0.0;
+    nn[2] = found ? P[3 * p + 2] : 0.0;
     return best;
 }
 
