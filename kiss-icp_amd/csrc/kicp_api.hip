@@ -698,7 +698,6 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
         s = KICP_ERR_HIP;
     }
     if (s == KICP_OK) s = r->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
-    if (s == KICP_OK) s = r->tile_ext.reserve((size_t)kIcpMaxBlocks * kIcpTileExtPoints * 3 * sizeof(double));
     if (s != KICP_OK) {
         kicp_registration_destroy(r);
         return s;
@@ -721,7 +720,9 @@ int kicp_registration_destroy(kicp_registration *r) {
     r->sort_in.release();
     r->sort_out.release();
     r->sort_tmp.release();
-    r->tile_ext.release();
+    r->run_w.release();
+    r->run_prefix.release();
+    r->scan_tmp.release();
     r->granules.release();
     r->state.release();
     if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -770,6 +771,15 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
             set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
             return KICP_ERR_HIP;
         }
+        KICP_TRY(r->run_w.reserve(n * sizeof(int)));
+        KICP_TRY(r->run_prefix.reserve(n * sizeof(int)));
+        KICP_TRY(r->scan_tmp.reserve(tile_scan_temp_bytes(n)));
+        const int we = launch_tile_weights(r->sort_out.as<unsigned long long>(), r->frame.as<double>(), nullptr, (int)n, n, map->view(), st, 0,
+                                           r->run_w.as<int>(), r->run_prefix.as<int>(), r->scan_tmp.p, r->scan_tmp.bytes, r->stream);
+        if (we != 0) {
+            set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
+            return KICP_ERR_HIP;
+        }
     }
     PipeState h;
     for (int attempt = 0, cap = 0;; ++attempt) {
@@ -778,7 +788,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         const int G = icp_fill_policy(r->device, P, n, cap);
         P.frame = r->frame.as<double>();
         P.order = sorted ? r->sort_out.as<unsigned long long>() : nullptr;
-        P.tile_ext = r->tile_ext.as<double>();
+        P.wprefix = sorted ? r->run_prefix.as<int>() : nullptr;
         P.work = r->work.as<double>();
         P.n_ptr = nullptr;
         P.n_imm = (int)n;
@@ -1048,8 +1058,8 @@ struct kicp_pipeline {
     // exist twice, indexed by frame parity; so do the upload targets raw / ts of the host-input path
     DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
     DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
-    DevBuf tile_ext;                        // HBM extension of the ICP workgroups' voxel tiles
-    size_t sort_tmp_bytes = 0;
+    DevBuf run_w, run_prefix, scan_tmp;     // weights of the sorted points, their inclusive prefix, rocPRIM scratch
+    size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -1117,6 +1127,10 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->sort_out[1].reserve(cap * sizeof(unsigned long long)));
     p->sort_tmp_bytes = tile_sort_temp_bytes(cap);
     KICP_TRY(p->sort_tmp.reserve(p->sort_tmp_bytes));
+    KICP_TRY(p->run_w.reserve(cap * sizeof(int)));
+    KICP_TRY(p->run_prefix.reserve(cap * sizeof(int)));
+    p->scan_tmp_bytes = tile_scan_temp_bytes(cap);
+    KICP_TRY(p->scan_tmp.reserve(p->scan_tmp_bytes));
     const uint32_t tcap = next_pow2(2 * cap);
     KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
@@ -1306,7 +1320,17 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap);
     I.frame = p->src[par].as<double>();
     I.order = sorted ? p->sort_out[par].as<unsigned long long>() : nullptr;
-    I.tile_ext = p->tile_ext.as<double>();
+    if (sorted && n) {
+        // weights of the sorted points under this frame's initial guess (which the previous frame's registration
+        // has just left in the device state), and their prefix: runs of equal weight
+        const int we = launch_tile_weights(I.order, p->src[par].as<double>(), &prep->n_src, 0, n, m->view(), st, 1, p->run_w.as<int>(),
+                                           p->run_prefix.as<int>(), p->scan_tmp.p, p->scan_tmp_bytes, s);
+        if (we != 0) {
+            set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
+            return KICP_ERR_HIP;
+        }
+        I.wprefix = p->run_prefix.as<int>();
+    }
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
     I.prep = prep;
@@ -1509,7 +1533,6 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     }
     if (s == KICP_OK) s = p->granules.reserve(icp_granule_words(kIcpMaxBlocks) * sizeof(unsigned long long));
     if (s == KICP_OK) s = p->prep.reserve(2 * sizeof(PrepState));
-    if (s == KICP_OK) s = p->tile_ext.reserve((size_t)kIcpMaxBlocks * kIcpTileExtPoints * 3 * sizeof(double));
     if (s == KICP_OK) s = pipe_reserve(p, 0);  // minimum buffers: the first scan may be empty
     if (s != KICP_OK) {
         if (s == KICP_ERR_HIP) set_error("pipeline resource creation failed");
@@ -1539,7 +1562,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
                       &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
-                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->tile_ext})
+                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_w, &p->run_prefix, &p->scan_tmp})
         b->release();
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);

@@ -62,9 +62,10 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     int next_point;   // phase B: next unserved point of the chunk
     int origin[3];    // voxel with relative tile coordinates (0, 0, 0)
     int any_fill;     // phase A: some query of the chunk is outside its known window
-    int ext_points;   // points handed out from the tile's extension
+    int tile_entries;  // occupied slots of the tile's table
     int list_entries; // entries handed out from the scan-list pool
-    int pad[3];
+    int run[2];       // first sorted position of this workgroup's run, and of the next workgroup's
+    int pad[1];
     double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
@@ -109,11 +110,41 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // keys); workgroup b serves the contiguous run [b * n_run, (b + 1) * n_run) of it -- a compact patch of
     // the scene, so that the map voxels its points can reach fit in the workgroup's LDS tile.  The first
     // n_meta points of a run use the tile; any beyond that search HBM directly.
-    const int n_run = (n + G - 1) / G;
-    const int q0 = (int)blockIdx.x * n_run;
-    const int n_local = max(0, min(n_run, n - q0));
-    const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_run, kIcpMaxMeta) : 0;
-    const bool use_lists = n_meta > 0 && n_run <= kIcpListRunMax;
+    int q0, n_local;
+    if (P.wprefix && n >= kIcpWeightedMin && P.force_blocks <= 0) {
+        // runs of equal WEIGHT (kicp_sort.hip): the point at sorted position q goes to workgroup
+        // floor(E[q] * G / W), E = exclusive weight prefix, W = total weight.  Waves 0 and 1 find the two ends of
+        // this workgroup's run by a 64-ary search over the inclusive prefix (three memory round trips).
+        if (tid < 128) {
+            const int which = tid >> 6, l = tid & 63;
+            const long long total = P.wprefix[n - 1];
+            const long long target = (((long long)blockIdx.x + which) * total) / G;  // first exclusive prefix of the run / of the next run
+            int lo = 0, hi = n;  // answer = number of inclusive prefixes < target (+ 1 unless target == 0)
+            while (hi > lo) {
+                const int step = (hi - lo + 63) / 64;
+                const int idx = lo + l * step;
+                const bool less = idx < hi && (long long)P.wprefix[idx] < target;
+                const int c = __popcll(__ballot(less));
+                if (c == 0) {
+                    hi = lo;
+                } else {
+                    const int nlo = lo + (c - 1) * step + 1, nhi = min(hi, lo + c * step);
+                    lo = nlo;
+                    hi = nhi;
+                }
+            }
+            if (l == 0) sh.run[which] = (which == 1 && (int)blockIdx.x == G - 1) ? n : (target <= 0 ? 0 : min(n, lo + 1));
+        }
+        __syncthreads();
+        q0 = sh.run[0];
+        n_local = max(0, sh.run[1] - q0);
+    } else {
+        const int n_run = (n + G - 1) / G;
+        q0 = (int)blockIdx.x * n_run;
+        n_local = max(0, min(n_run, n - q0));
+    }
+    const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, kIcpMaxMeta) : 0;
+    const bool use_lists = n_meta > 0 && n_local <= kIcpListRunMax;
     Tile tile;
     {
         char *q = smem + sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpQueryMeta);
@@ -128,9 +159,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         const long room = (long)P.lds_bytes - (long)(q - smem);
         tile.cap_points = n_meta > 0 && room > 0 ? (int)min((long)0xFFFF, room / (long)(3 * sizeof(double))) : 0;
         tile.count = &sh.tile_points;
-        tile.ext = (P.tile_ext && n_meta > 0) ? P.tile_ext + (size_t)blockIdx.x * kIcpTileExtPoints * 3 : nullptr;
-        tile.ext_cap = tile.ext ? kIcpTileExtPoints : 0;
-        tile.ext_count = &sh.ext_points;
+        tile.entries = &sh.tile_entries;
         tile.ox = tile.oy = tile.oz = 0;  // set once the first point's voxel is known
     }
     double(*terms)[kIcpTerms] = sh.terms;
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if (tid == 0) {
         sh.fail = 0;
         sh.tile_points = 0;
-        sh.ext_points = 0;
+        sh.tile_entries = 0;
         sh.list_entries = 0;
         sh.any_fill = 0;
         const SE3 id = se3_identity();
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
                 if (flag == 0 && !listed) {
                     int bad;
-                    d2 = tile_scan(tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad);
+                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad);
                     if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is
                                 // being fetched by another group this very moment -> HBM this once
                         if (bad == 2 && lane == 0) meta->valid = -1;

@@ -168,8 +168,8 @@ constexpr int kIcpTerms = 18;      // 16 normal-equation scalars + correspondenc
 constexpr int kIcpMaxMeta = 448;   // local points of a workgroup that may use the workgroup's voxel tile (64 bytes each)
 constexpr int kIcpTileSlots = 4096;  // slots of the workgroup's voxel table (occupied voxels only; power of two)
 constexpr int kIcpListRunMax = 64;   // workgroups that serve at most this many points keep a scan list per point
+constexpr int kIcpWeightedMin = 2048;  // source clouds of at least this many points are cut into runs of equal weight
 constexpr int kIcpListPool = 12288;  // 16-bit entries of the scan-list pool (24 KiB)
-constexpr int kIcpTileExtPoints = 16384;  // points of a workgroup's tile extension in HBM (voxels that do not fit in LDS)
 constexpr size_t kIcpGroupProfileWords = (size_t)kIcpProfIters * kIcpMaxBlocks * kIcpGroupsPerBlock * 4;
 
 // LDS record of one source point ("query") of a workgroup of the persistent ICP kernel
@@ -188,8 +188,8 @@ static_assert(sizeof(IcpQueryMeta) == 64, "IcpQueryMeta layout");
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
     const unsigned long long *order;  // sorted tile keys (low 24 bits: index into frame) or nullptr (identity)
+    const int *wprefix;   // inclusive prefix of the sorted points' weights (runs of equal weight), or nullptr (equal length)
     double *work;         // N x 3 transformed source, private to the launch
-    double *tile_ext;     // [gridDim.x][kIcpTileExtPoints] xyz triples: tile extension of each workgroup, or nullptr
     const int *n_ptr;     // device count (pipeline) or nullptr
     int n_imm;            // count when n_ptr == nullptr
     MapView map;
@@ -292,7 +292,7 @@ struct kicp_registration {
     hipStream_t stream = nullptr;
     int max_iters = 500;
     double conv = 1e-4;
-    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, tile_ext;
+    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_w, run_prefix, scan_tmp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

@@ -319,31 +319,27 @@ __device__ __forceinline__ double scan_hits_wide(const MapView &m, const Probe &
 constexpr double kWindowMargin = 0.125;  // fraction of a voxel
 constexpr int kFillChunk = 8;             // voxels whose points are in flight together during a fill
 constexpr unsigned kTileEmpty = 0xFFFFFFFFu;
-constexpr unsigned kTileReady = 0x80000000u;     // the voxel's points are in the store
-constexpr unsigned kTileOverflow = 0x40000000u;  // neither store had room: queries that need this voxel search HBM
-constexpr unsigned kTileExt = 0x20000000u;       // the points are in the tile's extension in HBM, not in LDS
+// table value: bits 0..23 first point in the LDS store, or (kTileGlobal) the voxel's block id in the map;
+// bits 24..29 point count; bit 30 kTileGlobal; bit 31 kTileReady
+constexpr unsigned kTileReady = 0x80000000u;   // the entry is complete (LDS voxels: the points are in the store)
+constexpr unsigned kTileGlobal = 0x40000000u;  // the LDS store was full: the points are read from the map block in HBM / L2
+constexpr unsigned kTileOverflow = 0xFFFFFFFEu;  // block id beyond 24 bits: queries that need this voxel search HBM
 constexpr int kTileSpan = 1024;                  // relative voxel coordinates 0 .. 1023 per axis
 
 struct Tile {
     unsigned *keys;  // [kIcpTileSlots] relative voxel key (10 bits per axis) or kTileEmpty
-    unsigned *vals;  // [kIcpTileSlots] first point (bits 0..15) | points (bits 16..21) | flags
+    unsigned *vals;  // [kIcpTileSlots]
     double *points;  // xyz triples in LDS
     int cap_points;
     int *count;      // LDS points handed out so far
-    double *ext;     // xyz triples in HBM (this workgroup's slice), or nullptr
-    int ext_cap;
-    int *ext_count;
+    int *entries;    // occupied table slots
     unsigned short *lists;  // pool of scan lists (small runs only), or nullptr
     int list_cap;
     int *list_count;
     int ox, oy, oz;  // voxel with relative coordinates (0, 0, 0)
 };
-// a point of the extension: written by another wave of this workgroup earlier in the launch; agent-scope
-// loads bypass this CU's L1, which may hold the line from before the write
-__device__ __forceinline__ double ext_load(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
-}
+__device__ __forceinline__ int tile_ref(unsigned val) { return (int)(val & 0xFFFFFFu); }
+__device__ __forceinline__ int tile_cnt(unsigned val) { return (int)((val >> 24) & 63u); }
 __device__ __forceinline__ bool tile_rel(const Tile &t, int qx, int qy, int qz, unsigned &key) {
     const unsigned rx = (unsigned)(qx - t.ox), ry = (unsigned)(qy - t.oy), rz = (unsigned)(qz - t.oz);
     key = (rx << 20) | (ry << 10) | rz;
@@ -353,9 +349,10 @@ __device__ __forceinline__ unsigned tile_hash(unsigned key) { return (key * 0x9E
 static_assert(kIcpTileSlots == 4096, "tile_hash returns 12 bits");
 // slot of a key or -1 (LDS loads; other waves may be inserting: relaxed workgroup-scope atomics keep the
 // compiler from caching them)
+constexpr int kTileMaxProbes = 32;  // the table is kept at most 3/4 full; a chain this long means "not here"
 __device__ __forceinline__ int tile_find(const Tile &t, unsigned key) {
     unsigned s = tile_hash(key);
-    for (int probes = 0; probes < kIcpTileSlots; ++probes) {
+    for (int probes = 0; probes < kTileMaxProbes; ++probes) {
         const unsigned k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k == key) return (int)s;
         if (k == kTileEmpty) return -1;
@@ -459,7 +456,7 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
                     if (slot < 0) {
                         need[h] = true;
                         key[h] = pack_voxel(qx, qy, qz);
-                    } else if (__hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kTileOverflow) {
+                    } else if (__hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kTileOverflow) {
                         fail = true;
                     }
                 }
@@ -478,20 +475,22 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
     map_find_pair(m, need[0], key[0], need[1], key[1], blk[0], cnt[0], blk[1], cnt[1]);
     // occupied ones enter the table; whoever claims the slot also fetches the points (another query of this
     // workgroup may be asking for the same voxel at the same moment)
-    bool won[2], in_ext[2];
+    bool won[2];
     int slot[2], off[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         won[h] = false;
-        in_ext[h] = false;
         slot[h] = -1;
         off[h] = 0;
         if (need[h] && blk[h] >= 0 && cnt[h] > 0) {
             unsigned sidx = tile_hash(rkey[h]);
             bool placed = false;
-            for (int probes = 0; probes < kIcpTileSlots; ++probes) {
+            // (a chain longer than tile_find follows, or a table more than 3/4 full, counts as "table full")
+            const bool room = __hip_atomic_load(tile.entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (kIcpTileSlots * 3) / 4;
+            for (int probes = 0; room && probes < kTileMaxProbes; ++probes) {
                 const unsigned old = atomicCAS(&tile.keys[sidx], kTileEmpty, rkey[h]);
                 if (old == kTileEmpty) {
+                    atomicAdd(tile.entries, 1);
                     won[h] = true;
                     slot[h] = (int)sidx;
                     placed = true;
@@ -506,16 +505,14 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
             if (!placed) fail = true;  // table full
             if (won[h]) {
                 off[h] = atomicAdd(tile.count, cnt[h]);
-                if (off[h] + cnt[h] > tile.cap_points) {  // LDS store full: the voxel goes to the extension in HBM
-                    const int g = tile.ext ? atomicAdd(tile.ext_count, cnt[h]) : tile.ext_cap;
-                    if (g + cnt[h] <= tile.ext_cap) {
-                        off[h] = g;
-                        in_ext[h] = true;
-                    } else {  // nowhere to put it
-                        __hip_atomic_store(&tile.vals[slot[h]], kTileOverflow | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        won[h] = false;
-                        fail = true;
-                    }
+                if (off[h] + cnt[h] > tile.cap_points) {
+                    // LDS store full: the table remembers where the voxel is in the map instead (the lookup is
+                    // saved, the points are read from HBM / L2 at every search)
+                    const unsigned val = (unsigned)blk[h] < 0x1000000u ? ((unsigned)blk[h] | ((unsigned)cnt[h] << 24) | kTileGlobal | kTileReady)
+                                                                       : kTileOverflow;
+                    __hip_atomic_store(&tile.vals[slot[h]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    won[h] = false;
+                    if (val == kTileOverflow) fail = true;
                 }
             }
         }
@@ -537,10 +534,10 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
                 const int src = j & 31;
                 const int b0 = __shfl(blk[0], src, 32), b1 = __shfl(blk[1], src, 32);
                 const int c0 = __shfl(cnt[0], src, 32), c1 = __shfl(cnt[1], src, 32);
-                const int o0 = __shfl(off[0] | (in_ext[0] ? 0x40000000 : 0), src, 32), o1 = __shfl(off[1] | (in_ext[1] ? 0x40000000 : 0), src, 32);
+                const int o0 = __shfl(off[0], src, 32), o1 = __shfl(off[1], src, 32);
                 const int bj = j < 32 ? b0 : b1, cj = j < 32 ? c0 : c1, oj = j < 32 ? o0 : o1;
                 if (lane < cj) {
-                    dst[u] = oj + lane;  // bit 30: extension
+                    dst[u] = oj + lane;
                     xy[u] = block_xy(m, bj)[lane];
                     zz[u] = block_z(m, bj)[lane];
                 }
@@ -549,20 +546,19 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 #pragma unroll
         for (int u = 0; u < kFillChunk; ++u) {
             if (dst[u] >= 0) {
-                double *q = (dst[u] & 0x40000000) ? tile.ext + 3 * (dst[u] & 0xFFFF) : tile.points + 3 * dst[u];
+                double *q = tile.points + 3 * dst[u];
                 q[0] = xy[u].x;
                 q[1] = xy[u].y;
                 q[2] = zz[u];
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0);  // (stores to the extension have left the CU)
     group_lds_sync();  // the points are in the store before their table entries say so
 #pragma unroll
     for (int h = 0; h < 2; ++h)
         if (won[h])
-            __hip_atomic_store(&tile.vals[slot[h]], (unsigned)off[h] | ((unsigned)cnt[h] << 16) | kTileReady | (in_ext[h] ? kTileExt : 0u),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&tile.vals[slot[h]], (unsigned)off[h] | ((unsigned)cnt[h] << 24) | kTileReady, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
     const bool failed = (unsigned)(__ballot(fail) >> half_shift) != 0u;
     if (lane == 0) {
         meta->v[0] = v[0];
@@ -589,12 +585,12 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 // voxel (max_points_per_voxel steps), not by the size of the neighbourhood.
 // Returns the squared distance (DBL_MAX: no candidate), the neighbour, the number of points examined;
 // bad = the tile cannot answer: 1 a voxel is still being fetched by a concurrent fill, 2 one did not fit.
-__device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz, int lane,
-                                            double nn[3], int &examined, int &bad) {
+__device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz,
+                                            int lane, double nn[3], int &examined, int &bad) {
     constexpr int U = 4;
-    int off = 0, cnt = 0;
+    int ref = 0, cnt = 0;
     int mybad = 0;
-    bool ext = false;
+    bool glob = false;
     if (lane < 27) {
         const int qx = vx + (int)((kShift.x >> (2 * lane)) & 3) - 1;
         const int qy = vy + (int)((kShift.y >> (2 * lane)) & 3) - 1;
@@ -604,11 +600,15 @@ __device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double 
             const int slot = tile_find(tile, rkey);
             if (slot >= 0) {
                 const unsigned val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (val & kTileOverflow) mybad = 2;
-                else if (!(val & kTileReady)) mybad = 1;
-                off = (int)(val & 0xFFFFu);
-                cnt = (int)((val >> 16) & 63u);
-                ext = (val & kTileExt) != 0u;
+                if (val == kTileOverflow) {
+                    mybad = 2;
+                } else if (!(val & kTileReady)) {
+                    mybad = 1;
+                } else {
+                    ref = tile_ref(val);
+                    cnt = tile_cnt(val);
+                    glob = (val & kTileGlobal) != 0u;
+                }
             }
         } else {
             mybad = 2;
@@ -621,11 +621,12 @@ __device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double 
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
     examined = tot;
+    // ---- voxels held in LDS: every lane walks its own voxel
     double best = DBL_MAX;
     int bk = 0;
-    {   // voxels held in LDS
-        const double *P = tile.points + 3 * off;
-        const int c = ext ? 0 : cnt;
+    {
+        const double *P = tile.points + 3 * (glob ? 0 : ref);
+        const int c = glob ? 0 : cnt;
         for (int k0 = 0; __ballot(k0 < c) != 0ull; k0 += U) {  // wave-uniform trip count
             double x[U], y[U], z[U];
 #pragma unroll
@@ -645,47 +646,58 @@ __device__ __forceinline__ double tile_scan(const Tile &tile, double sx, double 
             }
         }
     }
-    if (__ballot(ext && cnt > 0) != 0ull) {  // voxels held in the extension (HBM / L2): same walk, global loads
-        const double *P = tile.ext + 3 * (ext ? off : 0);
-        const int c = ext ? cnt : 0;
-        for (int k0 = 0; __ballot(k0 < c) != 0ull; k0 += U) {
-            double x[U], y[U], z[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double *q = P + 3 * ((k0 + u < c) ? k0 + u : 0);
-                x[u] = c > 0 ? ext_load(q) : 0.0;
-                y[u] = c > 0 ? ext_load(q + 1) : 0.0;
-                z[u] = c > 0 ? ext_load(q + 2) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
-                const double d = (ex * ex + ey * ey) + ez * ez;
-                const bool take = (k0 + u < c) & (d < best);
-                best = take ? d : best;
-                bk = take ? k0 + u : bk;
-            }
-        }
-    }
-    // every lane fetches its own best point again; the winner's then goes to the whole group
+    int key = (!glob && cnt > 0 && best < DBL_MAX) ? ((lane << 5) | bk) : 0x7FFFFFFF;
     double bx = 0.0, by = 0.0, bz = 0.0;
-    if (cnt > 0) {
-        if (ext) {
-            const double *q = tile.ext + 3 * (off + bk);
-            bx = ext_load(q);
-            by = ext_load(q + 1);
-            bz = ext_load(q + 2);
-        } else {
-            const double *q = tile.points + 3 * (off + bk);
-            bx = q[0];
-            by = q[1];
-            bz = q[2];
+    if (key != 0x7FFFFFFF) {
+        const double *q = tile.points + 3 * (ref + bk);
+        bx = q[0];
+        by = q[1];
+        bz = q[2];
+    }
+    // ---- voxels left in the map (HBM / L2): the group reads them together, lane i point i, kChunk voxels in
+    // flight (one memory round trip per kChunk voxels instead of one per point)
+    unsigned gl = (unsigned)(__ballot(glob && cnt > 0) >> half_shift);
+    while (__ballot(gl != 0) != 0ull) {  // wave-uniform trip count
+        double2 xy[kChunk];
+        double zz[kChunk];
+        int kj[kChunk];
+        bool ld[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            const int j = gl ? (__ffs(gl) - 1) : -1;
+            gl &= gl - 1;  // (0 & -1) == 0
+            const int bj = __shfl(ref, j & 31, 32);
+            const int cj = __shfl(cnt, j & 31, 32);
+            kj[u] = j;
+            ld[u] = (j >= 0) && (lane < cj);
+            if (ld[u]) {
+                xy[u] = block_xy(m, bj)[lane];
+                zz[u] = block_z(m, bj)[lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            if (ld[u]) {
+                const double ex = xy[u].x - sx, ey = xy[u].y - sy, ez = zz[u] - sz;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const int k = (kj[u] << 5) | lane;  // {shift position of the voxel, index inside it}
+                if (d < best || (d == best && k < key)) {
+                    best = d;
+                    key = k;
+                    bx = xy[u].x;
+                    by = xy[u].y;
+                    bz = zz[u];
+                }
+            }
         }
     }
-    int key = (cnt > 0 && best < DBL_MAX) ? ((lane << 5) | bk) : 0x7FFFFFFF;
+    if (best == DBL_MAX) key = 0x7FFFFFFF;
+    const int mykey = key;
     group_min_dist_key(best, key);
     const bool found = key != 0x7FFFFFFF;
-    const int wl = found ? (key >> 5) : 0;
+    // the lane that holds the winner hands its coordinates to the group
+    const unsigned who = (unsigned)(__ballot(found && mykey == key) >> half_shift);
+    const int wl = who ? (__ffs(who) - 1) : 0;
     nn[0] = __shfl(bx, wl, 32);
     nn[1] = __shfl(by, wl, 32);
     nn[2] = __shfl(bz, wl, 32);
@@ -710,9 +722,9 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
             const int slot = tile_find(tile, rkey);
             if (slot >= 0) {
                 const unsigned val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((val & (kTileOverflow | kTileExt)) || !(val & kTileReady)) mybad = true;
-                off = (int)(val & 0xFFFFu);
-                cnt = (int)((val >> 16) & 63u);
+                if (val == kTileOverflow || (val & kTileGlobal) || !(val & kTileReady)) mybad = true;
+                off = tile_ref(val);
+                cnt = tile_cnt(val);
             }
         } else {
             mybad = true;

@@ -46,6 +46,62 @@ __global__ __launch_bounds__(256) void k_tile_keys(const double *xyz, const int 
     }
 }
 
+// ---- run weights -------------------------------------------------------------------------------------------
+// A workgroup's tile must hold the map voxels its run of source points can reach, and the map is far from
+// uniform: next to the sensor voxels are full (max_points_per_voxel), far away they hold a point or two.  Runs
+// of equal LENGTH would need tiles of very different sizes -- and an iteration is as slow as its slowest
+// workgroup.  So runs are cut to equal WEIGHT: a point weighs kWeightBase plus the number of map points in the
+// voxel it falls in under the initial guess (one lookup per point), and workgroup b takes the points whose
+// exclusive weight prefix lies in [b W / G, (b + 1) W / G).
+constexpr int kWeightBase = 4;
+
+__global__ __launch_bounds__(256) void k_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
+                                                      int n_max, MapView m, const PipeState *state, int pipeline_mode, int *w) {
+    const int n = n_ptr ? *n_ptr : n_imm;
+    const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_max; q += gridDim.x * blockDim.x) {
+        int wt = 0;
+        if (q < n) {
+            const int p = order ? (int)(order[q] & 0xFFFFFFull) : q;
+            const double pin[3] = {frame[3 * p], frame[3 * p + 1], frame[3 * p + 2]};
+            double s[3];
+            se3_act(guess, pin, s);
+            const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size), vz = voxel_coord(s[2], m.voxel_size);
+            int cnt = 0;
+            if (voxel_in_range(vx, vy, vz)) {
+                const unsigned long long key = pack_voxel(vx, vy, vz);
+                uint32_t sidx = hash_key(key, m.mask);
+                for (uint32_t probes = 0; probes <= m.mask; ++probes) {
+                    const unsigned long long k = m.slots[sidx].key;
+                    if (k == key) {
+                        cnt = m.slots[sidx].count;
+                        break;
+                    }
+                    if (k == kKeyEmpty) break;
+                    sidx = (sidx + 1) & m.mask;
+                }
+            }
+            wt = kWeightBase + cnt;
+        }
+        w[q] = wt;
+    }
+}
+
+size_t tile_scan_temp_bytes(size_t n_max) {
+    size_t bytes = 0;
+    int *p = nullptr;
+    (void)rocprim::inclusive_scan(nullptr, bytes, p, p, n_max ? n_max : 1, rocprim::plus<int>(), (hipStream_t) nullptr);
+    return bytes + 256;
+}
+
+int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
+                        const PipeState *state, int pipeline_mode, int *w, int *prefix, void *temp, size_t temp_bytes, hipStream_t s) {
+    if (n_max == 0) return 0;
+    const int grid = (int)((n_max + 255) / 256 < 1024 ? (n_max + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_tile_weights, dim3(grid), dim3(256), 0, s, order, frame, n_ptr, n_imm, (int)n_max, m, state, pipeline_mode, w);
+    return (int)rocprim::inclusive_scan(temp, temp_bytes, w, prefix, n_max, rocprim::plus<int>(), s);
+}
+
 size_t tile_sort_temp_bytes(size_t n_max) {
     size_t bytes = 0;
     unsigned long long *k = nullptr;
