@@ -261,6 +261,12 @@ int kicp_device_upload(int device_id, void *d_dst, const void *h_src, size_t byt
 int kicp_device_download(int device_id, void *h_dst, const void *d_src, size_t bytes);
 int kicp_device_synchronize(int device_id);
 
+/* Device self-test: n systems A x = b (A row-major 6x6, symmetric) solved by the ICP kernel's own solver (the
+ * scalar statement of Eigen 3.4.0's pivoted LDLT that Registration.cpp:156 calls), so that its arithmetic can be
+ * compared with the oracle's on the same inputs -- pivot order, zero-pivot rule and all -- without a registration
+ * around it (tests/test_gpu_paths.py). */
+int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t n, double *x);
+
 /* ------------------------------------------------------------------------------------------
  * tuning knobs (process-wide; read when a handle is created).  Unknown names are an error.
  *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src

@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <immintrin.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -200,6 +202,7 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             cur_ = &job;
             ++gen_;
+            gen_hint_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
         work(job);
@@ -229,6 +232,9 @@ private:
         unsigned long seen = 0;  // generation of the last job this helper worked on
         for (;;) {
             Job *j;
+            // at thousands of scans per second the next job is a fraction of a millisecond away: look for it for
+            // a while before going to sleep (waking a sleeping thread costs more than the copy it is woken for)
+            for (int spin = 0; spin < 20000 && gen_hint_.load(std::memory_order_acquire) == seen; ++spin) _mm_pause();
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return quit_ || (cur_ && gen_ != seen); });
@@ -246,12 +252,13 @@ private:
     std::vector<std::thread> threads_;
     Job *cur_ = nullptr;
     unsigned long gen_ = 0;
+    std::atomic<unsigned long> gen_hint_{0};  // copy of gen_ the helpers may read without the lock
     bool quit_ = false;
 };
 
 // f64 -> f32 narrowing of a block of coordinates; true iff every value survives the round trip, i.e. the
 // data came from a float32 sensor file (datasets/kitti.py:66, ROS PointCloud2) and nothing is lost
-static bool narrow_exact(const double *src, float *dst, size_t count) {
+static bool narrow_exact_scalar(const double *src, float *dst, size_t count) {
     bool ok = true;
     for (size_t i = 0; i < count; ++i) {
         const float f = (float)src[i];
@@ -259,6 +266,23 @@ static bool narrow_exact(const double *src, float *dst, size_t count) {
         ok &= ((double)f == src[i]);
     }
     return ok;
+}
+__attribute__((target("avx2"))) static bool narrow_exact_avx2(const double *src, float *dst, size_t count) {
+    __m256d all = _mm256_castsi256_pd(_mm256_set1_epi64x(-1));
+    size_t i = 0;
+    for (; i + 8 <= count; i += 8) {
+        const __m256d a = _mm256_loadu_pd(src + i), b = _mm256_loadu_pd(src + i + 4);
+        const __m128 fa = _mm256_cvtpd_ps(a), fb = _mm256_cvtpd_ps(b);
+        _mm_storeu_ps(dst + i, fa);
+        _mm_storeu_ps(dst + i + 4, fb);
+        all = _mm256_and_pd(all, _mm256_and_pd(_mm256_cmp_pd(_mm256_cvtps_pd(fa), a, _CMP_EQ_OQ), _mm256_cmp_pd(_mm256_cvtps_pd(fb), b, _CMP_EQ_OQ)));
+    }
+    bool ok = _mm256_movemask_pd(all) == 0xF;
+    return narrow_exact_scalar(src + i, dst + i, count - i) && ok;
+}
+static bool narrow_exact(const double *src, float *dst, size_t count) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? narrow_exact_avx2(src, dst, count) : narrow_exact_scalar(src, dst, count);
 }
 
 }  // namespace kicp
@@ -720,9 +744,7 @@ int kicp_registration_destroy(kicp_registration *r) {
     r->sort_in.release();
     r->sort_out.release();
     r->sort_tmp.release();
-    r->run_w.release();
     r->run_prefix.release();
-    r->scan_tmp.release();
     r->granules.release();
     r->state.release();
     if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -771,11 +793,9 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
             set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
             return KICP_ERR_HIP;
         }
-        KICP_TRY(r->run_w.reserve(n * sizeof(int)));
         KICP_TRY(r->run_prefix.reserve(n * sizeof(int)));
-        KICP_TRY(r->scan_tmp.reserve(tile_scan_temp_bytes(n)));
         const int we = launch_tile_weights(r->sort_out.as<unsigned long long>(), r->frame.as<double>(), nullptr, (int)n, n, map->view(), st, 0,
-                                           r->run_w.as<int>(), r->run_prefix.as<int>(), r->scan_tmp.p, r->scan_tmp.bytes, r->stream);
+                                           r->run_prefix.as<int>(), r->stream);
         if (we != 0) {
             set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
             return KICP_ERR_HIP;
@@ -1058,8 +1078,8 @@ struct kicp_pipeline {
     // exist twice, indexed by frame parity; so do the upload targets raw / ts of the host-input path
     DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
     DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
-    DevBuf run_w, run_prefix, scan_tmp;     // weights of the sorted points, their inclusive prefix, rocPRIM scratch
-    size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
+    DevBuf run_prefix;                      // inclusive prefix of the sorted points' weights
+    size_t sort_tmp_bytes = 0;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
     // per-frame records land in pinned host memory, one slot per frame in flight
@@ -1127,10 +1147,7 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->sort_out[1].reserve(cap * sizeof(unsigned long long)));
     p->sort_tmp_bytes = tile_sort_temp_bytes(cap);
     KICP_TRY(p->sort_tmp.reserve(p->sort_tmp_bytes));
-    KICP_TRY(p->run_w.reserve(cap * sizeof(int)));
     KICP_TRY(p->run_prefix.reserve(cap * sizeof(int)));
-    p->scan_tmp_bytes = tile_scan_temp_bytes(cap);
-    KICP_TRY(p->scan_tmp.reserve(p->scan_tmp_bytes));
     const uint32_t tcap = next_pow2(2 * cap);
     KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
@@ -1323,8 +1340,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     if (sorted && n) {
         // weights of the sorted points under this frame's initial guess (which the previous frame's registration
         // has just left in the device state), and their prefix: runs of equal weight
-        const int we = launch_tile_weights(I.order, p->src[par].as<double>(), &prep->n_src, 0, n, m->view(), st, 1, p->run_w.as<int>(),
-                                           p->run_prefix.as<int>(), p->scan_tmp.p, p->scan_tmp_bytes, s);
+        const int we = launch_tile_weights(I.order, p->src[par].as<double>(), &prep->n_src, 0, n, m->view(), st, 1, p->run_prefix.as<int>(), s);
         if (we != 0) {
             set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
             return KICP_ERR_HIP;
@@ -1562,7 +1578,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
                       &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
-                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_w, &p->run_prefix, &p->scan_tmp})
+                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_prefix})
         b->release();
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
@@ -1994,6 +2010,25 @@ int kicp_device_synchronize(int device_id) {
     KICP_HIP(hipDeviceSynchronize());
     return KICP_OK;
 }
+int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t n, double *x) {
+    if ((!A || !b || !x) && n) return KICP_ERR_INVALID_ARG;
+    KICP_TRY(check_device(device_id));
+    if (n == 0) return KICP_OK;
+    DevBuf dA, db, dx;
+    ScopedBufs sb;
+    sb.v = {&dA, &db, &dx};
+    KICP_TRY(dA.reserve(n * 36 * sizeof(double)));
+    KICP_TRY(db.reserve(n * 6 * sizeof(double)));
+    KICP_TRY(dx.reserve(n * 6 * sizeof(double)));
+    KICP_HIP(hipMemcpy(dA.p, A, n * 36 * sizeof(double), hipMemcpyHostToDevice));
+    KICP_HIP(hipMemcpy(db.p, b, n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    launch_selftest_solve(dA.as<double>(), db.as<double>(), (int)n, dx.as<double>(), nullptr);
+    KICP_HIP(hipGetLastError());
+    KICP_HIP(hipDeviceSynchronize());
+    KICP_HIP(hipMemcpy(x, dx.p, n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return KICP_OK;
+}
+
 int kicp_set_option(const char *name, long value) {
     if (!name) return KICP_ERR_INVALID_ARG;
     if (!strcmp(name, "icp_blocks")) {

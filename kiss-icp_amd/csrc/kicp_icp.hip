@@ -728,6 +728,23 @@ int icp_prepare(int device_id) {
     done[device_id] = true;
     return 0;
 }
+// device self-test of the 6x6 solve (kicp_selftest_solve): the kernel's ldlt6_solve on caller-supplied systems
+__global__ __launch_bounds__(64) void k_selftest_solve(const double *A, const double *b, int n, double *x) {
+    for (int c = threadIdx.x; c < n; c += 64) {
+        double M[36], rhs[6], xs[6];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) M[e] = A[36 * c + e];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) rhs[e] = b[6 * c + e];
+        ldlt6_solve(M, rhs, xs);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) x[6 * c + e] = xs[e];
+    }
+}
+void launch_selftest_solve(const double *A, const double *b, int n, double *x, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_solve, dim3(1), dim3(64), 0, s, A, b, n, x);
+}
+
 int icp_blocks_per_cu(int lds_bytes) {
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_icp<false>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a = 0;

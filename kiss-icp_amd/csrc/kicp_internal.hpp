@@ -292,7 +292,7 @@ struct kicp_registration {
     hipStream_t stream = nullptr;
     int max_iters = 500;
     double conv = 1e-4;
-    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_w, run_prefix, scan_tmp;
+    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_prefix;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

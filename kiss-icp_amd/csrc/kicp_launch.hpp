@@ -56,11 +56,11 @@ int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_ma
                      unsigned long long *keys_out, void *temp, size_t temp_bytes, hipStream_t s);
 // weights of the sorted source points (map points in the voxel each falls in under the initial guess) and their
 // inclusive prefix: k_icp cuts the cloud into runs of equal weight
-size_t tile_scan_temp_bytes(size_t n_max);
 int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
-                        const PipeState *state, int pipeline_mode, int *w, int *prefix, void *temp, size_t temp_bytes, hipStream_t s);
+                        const PipeState *state, int pipeline_mode, int *prefix, hipStream_t s);
 int icp_prepare(int device_id);
-int icp_blocks_per_cu(int lds_bytes);  // co-resident k_icp workgroups per CU (occupancy query, current device)
+int icp_blocks_per_cu(int lds_bytes);
+void launch_selftest_solve(const double *A, const double *b, int n, double *x, hipStream_t s);  // co-resident k_icp workgroups per CU (occupancy query, current device)
 size_t icp_granule_words(int G);
 void launch_icp(IcpParams P, int G, bool profile, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,

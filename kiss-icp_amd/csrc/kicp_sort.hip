@@ -55,51 +55,72 @@ __global__ __launch_bounds__(256) void k_tile_keys(const double *xyz, const int 
 // exclusive weight prefix lies in [b W / G, (b + 1) W / G).
 constexpr int kWeightBase = 4;
 
-__global__ __launch_bounds__(256) void k_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
-                                                      int n_max, MapView m, const PipeState *state, int pipeline_mode, int *w) {
+// weight of the point at sorted position q under the initial guess
+__device__ __forceinline__ int tile_weight(const unsigned long long *order, const double *frame, const MapView &m, const SE3 &guess, int q) {
+    const int p = order ? (int)(order[q] & 0xFFFFFFull) : q;
+    const double pin[3] = {frame[3 * p], frame[3 * p + 1], frame[3 * p + 2]};
+    double s[3];
+    se3_act(guess, pin, s);
+    const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size), vz = voxel_coord(s[2], m.voxel_size);
+    int cnt = 0;
+    if (voxel_in_range(vx, vy, vz)) {
+        const unsigned long long key = pack_voxel(vx, vy, vz);
+        uint32_t sidx = hash_key(key, m.mask);
+        for (uint32_t probes = 0; probes <= m.mask; ++probes) {
+            const unsigned long long k = m.slots[sidx].key;
+            if (k == key) {
+                cnt = m.slots[sidx].count;
+                break;
+            }
+            if (k == kKeyEmpty) break;
+            sidx = (sidx + 1) & m.mask;
+        }
+    }
+    return kWeightBase + cnt;
+}
+
+// weights and their inclusive prefix in ONE launch of one 1024-thread workgroup (the source cloud has a few
+// thousand points, at most ~10^5: a multi-kernel device scan would cost more in launches -- on the serial chain
+// of the frame, right in front of the registration -- than the work itself)
+__global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
+                                                            MapView m, const PipeState *state, int pipeline_mode, int *prefix) {
+    __shared__ int wave_sum[16];
     const int n = n_ptr ? *n_ptr : n_imm;
     const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_max; q += gridDim.x * blockDim.x) {
-        int wt = 0;
-        if (q < n) {
-            const int p = order ? (int)(order[q] & 0xFFFFFFull) : q;
-            const double pin[3] = {frame[3 * p], frame[3 * p + 1], frame[3 * p + 2]};
-            double s[3];
-            se3_act(guess, pin, s);
-            const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size), vz = voxel_coord(s[2], m.voxel_size);
-            int cnt = 0;
-            if (voxel_in_range(vx, vy, vz)) {
-                const unsigned long long key = pack_voxel(vx, vy, vz);
-                uint32_t sidx = hash_key(key, m.mask);
-                for (uint32_t probes = 0; probes <= m.mask; ++probes) {
-                    const unsigned long long k = m.slots[sidx].key;
-                    if (k == key) {
-                        cnt = m.slots[sidx].count;
-                        break;
-                    }
-                    if (k == kKeyEmpty) break;
-                    sidx = (sidx + 1) & m.mask;
-                }
-            }
-            wt = kWeightBase + cnt;
-        }
-        w[q] = wt;
+    const int t = threadIdx.x;
+    // pass 1 (coalesced): the weights themselves
+    for (int q = t; q < n; q += 1024) prefix[q] = tile_weight(order, frame, m, guess, q);
+    __threadfence_block();
+    __syncthreads();
+    // pass 2: thread t owns the contiguous slice [t E, (t + 1) E)
+    const int E = (n + 1023) / 1024;
+    const int a = min(n, t * E), b = min(n, a + E);
+    int sum = 0;
+    for (int q = a; q < b; ++q) sum += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // exclusive scan of the 1024 slice sums
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if ((t & 63) >= o) incl += up;
+    }
+    if ((t & 63) == 63) wave_sum[t >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) base += (w < (t >> 6)) ? wave_sum[w] : 0;
+    int run = base + incl - sum;
+    for (int q = a; q < b; ++q) {
+        run += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prefix[q] = run;
     }
 }
 
-size_t tile_scan_temp_bytes(size_t n_max) {
-    size_t bytes = 0;
-    int *p = nullptr;
-    (void)rocprim::inclusive_scan(nullptr, bytes, p, p, n_max ? n_max : 1, rocprim::plus<int>(), (hipStream_t) nullptr);
-    return bytes + 256;
-}
-
 int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
-                        const PipeState *state, int pipeline_mode, int *w, int *prefix, void *temp, size_t temp_bytes, hipStream_t s) {
+                        const PipeState *state, int pipeline_mode, int *prefix, hipStream_t s) {
     if (n_max == 0) return 0;
-    const int grid = (int)((n_max + 255) / 256 < 1024 ? (n_max + 255) / 256 : 1024);
-    hipLaunchKernelGGL(k_tile_weights, dim3(grid), dim3(256), 0, s, order, frame, n_ptr, n_imm, (int)n_max, m, state, pipeline_mode, w);
-    return (int)rocprim::inclusive_scan(temp, temp_bytes, w, prefix, n_max, rocprim::plus<int>(), s);
+    hipLaunchKernelGGL(k_tile_weights_scan, dim3(1), dim3(1024), 0, s, order, frame, n_ptr, n_imm, m, state, pipeline_mode, prefix);
+    return (int)hipGetLastError();
 }
 
 size_t tile_sort_temp_bytes(size_t n_max) {

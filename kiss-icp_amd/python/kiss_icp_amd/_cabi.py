@@ -114,6 +114,7 @@ SIGNATURES = {
     "kicp_device_upload": [_i, _vp, _vp, _sz],
     "kicp_device_download": [_i, _vp, _vp, _sz],
     "kicp_device_synchronize": [_i],
+    "kicp_selftest_solve": [_i, _vp, _vp, _sz, _vp],
 }
 _STRING_FUNCS = ("kicp_status_string", "kicp_last_error")
 
