@@ -1,7 +1,8 @@
 /*
  * kiss_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See kiss_oracle.h.
  *
- * PARITY UNPINNED (no reference golden vectors exist; reference not buildable here).
+ * Pinned against the reference's own sources built by oracle/ref_build (tests/test_ref_pins_oracle.py);
+ * PARITY UNPINNED for the third-party arithmetic (Eigen LDLT, Sophus SE3) only -- see kiss_oracle.h.
  *
  * Restates, from /root/reference (PRBonn/kiss-icp v1.2.3):
  *   cpp/kiss_icp/core/Registration.cpp:55-167      AlignPointsToMap + helpers

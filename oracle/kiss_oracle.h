@@ -5,12 +5,19 @@
  * stages either side of it, written from the reference's sources at /root/reference
  * (PRBonn/kiss-icp v1.2.3).  Every function cites the reference file:line it follows.
  *
- * PARITY UNPINNED: the reference ships no golden vectors / known-answer tests for this
- * path (python/tests/test_kiss_icp.py:1-4 is an import smoke test) and cannot be built in
- * this environment (Eigen 3.4.0 / Sophus 1.24.6 / tsl::robin_map 1.4.0 / oneTBB 2022.1.0 are
- * FetchContent'ed from the network).  The third-party arithmetic (pivoted LDLT, SE3 exp/log,
- * quaternion algebra) is restated here from the published algorithms of those pinned
- * versions and checked against scipy/numpy in tests/.
+ * PINNING.  The reference ships no golden vectors / known-answer tests for this path
+ * (python/tests/test_kiss_icp.py:1-4 is an import smoke test) and its own build needs Eigen
+ * 3.4.0 / Sophus 1.24.6 / tsl::robin_map 1.4.0 / oneTBB 2022.1.0 FetchContent'ed from the network.
+ *  - PINNED against the reference's own code: every line of cpp/kiss_icp/{core,pipeline}/*.cpp
+ *    on this path.  oracle/ref_build/ compiles those files UNMODIFIED from /root/reference
+ *    against stand-in third-party headers into oracle/_ref/libkiss_ref.so, and
+ *    tests/test_ref_pins_oracle.py holds this restatement to it (bit-exact survivors, map
+ *    content, neighbours, thresholds; poses to 1e-11); tests/golden/ *.npz come from it.
+ *  - PARITY UNPINNED for the third-party arithmetic only (Eigen's pivoted LDLT and its
+ *    zero-pivot rule, Sophus' SE3 exp / log / product branches): those libraries are absent, the
+ *    stand-in headers forward these operations to the restatement in this file, which is
+ *    written from the published algorithms of the pinned versions and checked against
+ *    scipy/numpy in tests/test_oracle.py.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library.  The product (kiss-icp_amd/) never links, imports or calls it.

@@ -1,6 +1,7 @@
 """ctypes front-end of the CPU oracle (oracle/kiss_oracle.c).
 
-TEST INFRASTRUCTURE -- PARITY UNPINNED (see kiss_oracle.h).  Only tests/,
+TEST INFRASTRUCTURE -- pinned against the reference's own sources (oracle/ref.py), PARITY UNPINNED for the
+third-party arithmetic only (see kiss_oracle.h).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
 package never does.
 
