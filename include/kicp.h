@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define KICP_VERSION_MAJOR 0
-#define KICP_VERSION_MINOR 2
+#define KICP_VERSION_MINOR 3
 
 typedef enum kicp_status {
     KICP_OK = 0,
@@ -250,6 +250,59 @@ int kicp_pipeline_icp_group_profile(kicp_pipeline *p, uint32_t *out, size_t cap_
                                     int *n_groups);
 /* the HIP stream (hipStream_t) the pipeline launches on, as an opaque pointer */
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-stream batch mode (new functionality; the reference registers one stream in one process).
+ * S independent LiDAR streams, one pipeline + one local map per GPU, one WORKER THREAD PER STREAM inside
+ * this library (each bound to its device with hipSetDevice), no collective on the data path: frame k of a
+ * stream needs pose k-1 and the map holding frame k-1 (pipeline/KissICP.cpp:47,61), so streams are the unit
+ * of parallelism.  The one exchange is the "pose-graph sync" of kicp_batch_sync(): an all-gather of the poses
+ * each stream completed since the previous sync, after which every rank holds all S trajectories.
+ *
+ * Ranks: a batch handle owns the n_local consecutive global ranks first_rank .. first_rank + n_local - 1 out of
+ * n_total.  All GPUs of a node in one process: n_local == n_total, first_rank 0.  One process per GPU
+ * (torchrun / MPI): n_local 1, first_rank = the process's rank, and the 128-byte id made by
+ * kicp_batch_unique_id() on one rank and distributed by the launcher's own means.
+ *
+ * The exchange: comm == NULL uses RCCL called directly (ncclCommInitRank / ncclAllGather from librccl,
+ * resolved with dlopen) on a stream of its own; one fixed-size block of 16 + 128 * frames_per_gather bytes per
+ * rank and gather (several gathers when a sync completed more frames; ranks in OTHER processes must then have
+ * queued the same number of frames).  A host may supply its own communicator (MPI, a test stub) instead.
+ * ---------------------------------------------------------------------------------------- */
+#define KICP_BATCH_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+typedef struct kicp_batch kicp_batch;
+typedef struct kicp_batch_comm {
+    void *ctx;
+    /* once per local rank, on that rank's worker thread, after its pipeline exists; may be NULL */
+    int (*init)(void *ctx, int rank, int n_ranks, int device_id);
+    /* gather `bytes` bytes from d_send of every rank into d_recv (n_ranks * bytes, rank order), ordered on the
+     * hipStream_t `stream`; both buffers are device memory of this rank's GPU; called concurrently by the
+     * local ranks' threads */
+    int (*all_gather)(void *ctx, int rank, const void *d_send, void *d_recv, size_t bytes, void *stream);
+    int (*finalize)(void *ctx, int rank); /* may be NULL */
+} kicp_batch_comm;
+int kicp_batch_unique_id(unsigned char id[KICP_BATCH_ID_BYTES]);
+/* devices[n_local]: the GPU of each local stream (the same device may appear more than once);
+ * unique_id: NULL when n_local == n_total; frames_per_gather: 0 = 64 */
+int kicp_batch_create(const kicp_config *cfg, const int *devices, int n_local, int first_rank, int n_total,
+                      const unsigned char *unique_id, const kicp_batch_comm *comm, size_t frames_per_gather,
+                      kicp_batch **out);
+int kicp_batch_destroy(kicp_batch *b);
+/* one host scan per local stream (xyz[i] == NULL: stream i has no frame this round), handed to that
+ * stream's kicp_pipeline_register_frame_async by its worker thread; returns when every scan has been staged
+ * (the buffers are free again), not when it has been registered */
+int kicp_batch_register_frames(kicp_batch *b, const double *const *xyz, const size_t *n,
+                               const double *const *timestamps, const size_t *n_timestamps);
+int kicp_batch_register_frames_f32(kicp_batch *b, const float *const *xyz, const size_t *n,
+                                   const double *const *timestamps, const size_t *n_timestamps);
+/* wait for every queued frame of every local stream, then all-gather the new poses */
+int kicp_batch_sync(kicp_batch *b);
+/* poses (row-major 4x4) that GLOBAL rank `rank` completed between the last two syncs, oldest first */
+int kicp_batch_poses(kicp_batch *b, int rank, double *T_out, size_t cap_frames, size_t *n_frames);
+/* borrowed handle of a local stream's pipeline (map, outputs, stats); use it between syncs only */
+int kicp_batch_pipeline(kicp_batch *b, int local_stream, kicp_pipeline **pipe);
+/* wall time the last kicp_batch_sync spent in the pose exchange (upload, all-gather, download; all ranks) */
+int kicp_batch_gather_seconds(kicp_batch *b, double *seconds);
 
 /* ------------------------------------------------------------------------------------------
  * Device-memory helpers for hosts without a HIP binding of their own (cgo / JNI / ctypes): enough

@@ -1,0 +1,293 @@
+// kicp_batch.hpp -- multi-stream batch mode, host side: S independent LiDAR streams, one pipeline and one local
+// map per GPU, ONE WORKER THREAD PER STREAM (each bound to its device), and after every batch of frames one
+// all-gather of the new poses so that every rank holds all S trajectories ("pose-graph sync").
+//
+// A stream cannot be sharded over frames (frame k needs pose k-1 and the map holding frame k-1:
+// cpp/kiss_icp/pipeline/KissICP.cpp:47,61), so streams are the unit of parallelism and the data path needs no
+// collective.  The reference has no such mode.
+//
+// This header is plain host C++ (no HIP): the driver is a template over the per-stream pipeline type so that the
+// orchestration -- worker threads, ragged batches, chunked gathers, error propagation -- is the same code whether
+// it drives HIP pipelines with RCCL (kicp_batch.hip) or stand-ins in a CPU test (tests/cpp/test_batch_stub.cpp).
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kicp.h"
+
+namespace kicp_mstream {
+
+struct Frame {
+    const void *xyz = nullptr;  // n x 3, float64 or float32 (xyz_f32)
+    int xyz_f32 = 0;
+    size_t n = 0;
+    const double *timestamps = nullptr;
+    size_t n_timestamps = 0;
+    bool skip = false;  // this stream has no frame in this round
+};
+
+// What the driver needs from a per-stream pipeline (all called on the stream's own worker thread):
+//   int  open(int rank, int device)                 bind the thread to the device, create the pipeline and two
+//                                                   exchange buffers of block_bytes / n_total * block_bytes
+//   int  enqueue(const Frame&)                      queue one frame, do not wait for it
+//   int  sync()                                     wait for everything queued
+//   int  new_poses(double*, size_t cap, size_t *n)  poses completed by the last sync, oldest first
+//   void *send_buffer(), *recv_buffer(), *stream()  exchange buffers (memory the communicator can address)
+//   int  put(const void *host, size_t bytes)        host -> send buffer, ordered on stream()
+//   int  get(void *host, size_t bytes)              recv buffer -> host, after the stream drained
+//   void close()
+// Status codes are kicp_status; the text of a failure is fetched with last_error().
+
+// One block per rank and gather: a count and `cap` poses.  Fixed size, so that ranks in different processes
+// need not agree on anything but the number of sync calls.
+inline size_t block_doubles(size_t cap) { return 2 + 16 * cap; }
+
+template <class Pipe>
+class Driver {
+public:
+    Driver(int n_local, int first_rank, int n_total, size_t frames_per_gather, const kicp_batch_comm &comm)
+        : n_local_(n_local), first_rank_(first_rank), n_total_(n_total), cap_(frames_per_gather), comm_(comm),
+          workers_(n_local) {}
+
+    ~Driver() { stop(); }
+
+    template <class Make>
+    int start(const int *devices, Make make_pipe) {
+        for (int i = 0; i < n_local_; ++i) {
+            Worker &w = workers_[i];
+            w.index = i;
+            w.device = devices[i];
+            w.pipe = make_pipe(i);
+            w.block.assign(block_doubles(cap_), 0.0);
+            w.gathered.assign(block_doubles(cap_) * n_total_, 0.0);
+            w.thread = std::thread([this, &w] { run(w); });
+        }
+        started_ = true;
+        // pipelines first, the communicator only when every stream has one: a rendezvous that some rank never
+        // joins would not return
+        int rc = post_all(Cmd::Open);
+        if (rc == KICP_OK) rc = post_all(Cmd::OpenComm);
+        if (rc != KICP_OK) {
+            const std::string keep = error_;
+            stop();
+            error_ = keep;
+        }
+        return rc;
+    }
+
+    // one frame (or none) per local stream; returns when every stream has taken its frame
+    int register_frames(const Frame *frames) {
+        if (!started_) return fail(KICP_ERR_INVALID_ARG, "batch not started");
+        for (int i = 0; i < n_local_; ++i) workers_[i].frame = frames[i];
+        return post_all(Cmd::Enqueue);
+    }
+
+    // wait for every queued frame of every local stream, then exchange the new poses.  Afterwards
+    // poses(rank) holds what global rank `rank` completed since the previous sync.
+    int sync() {
+        if (!started_) return fail(KICP_ERR_INVALID_ARG, "batch not started");
+        int rc = post_all(Cmd::Sync);
+        if (rc != KICP_OK) return rc;
+        // more frames than one block carries: several gathers.  Ranks of other processes must have queued the
+        // same number of frames per sync (documented in kicp.h); the local ones are known here.
+        size_t most = 0;
+        for (auto &w : workers_) most = std::max(most, w.fresh.size() / 16);
+        size_t rounds = std::max<size_t>(1, (most + cap_ - 1) / cap_);
+        all_poses_.assign(n_total_, {});
+        gather_seconds_ = 0.0;
+        for (size_t r = 0; r < rounds; ++r) {
+            for (auto &w : workers_) w.round = r;
+            const auto t0 = std::chrono::steady_clock::now();
+            rc = post_all(Cmd::Gather);
+            gather_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rc != KICP_OK) return rc;
+            // every local rank received the same blocks; rank 0 of this process is the one read out, the others
+            // are compared against it in debug builds of the test
+            const Worker &w0 = workers_[0];
+            for (int g = 0; g < n_total_; ++g) {
+                const double *blk = w0.gathered.data() + size_t(g) * block_doubles(cap_);
+                size_t cnt = size_t(blk[0]);
+                if (cnt > cap_) return fail(KICP_ERR_INVALID_ARG, "gathered block carries an impossible count");
+                all_poses_[g].insert(all_poses_[g].end(), blk + 2, blk + 2 + 16 * cnt);
+            }
+        }
+        ++syncs_;
+        return KICP_OK;
+    }
+
+    int n_local() const { return n_local_; }
+    int n_total() const { return n_total_; }
+    int first_rank() const { return first_rank_; }
+    size_t syncs() const { return syncs_; }
+    const std::vector<double> &poses(int global_rank) const { return all_poses_[global_rank]; }
+    // what local rank i itself received in the last gather round (the test checks all ranks agree)
+    const std::vector<double> &received(int local) const { return workers_[local].gathered; }
+    Pipe &pipe(int local) { return *workers_[local].pipe; }
+    const std::string &last_error() const { return error_; }
+    double last_gather_seconds() const { return gather_seconds_; }
+
+    void stop() {
+        if (!started_) return;
+        post_all(Cmd::Close);
+        for (auto &w : workers_) {
+            {
+                std::lock_guard<std::mutex> lk(w.m);
+                w.cmd = Cmd::Exit;
+                w.pending = true;
+            }
+            w.cv.notify_one();
+            if (w.thread.joinable()) w.thread.join();
+        }
+        started_ = false;
+    }
+
+private:
+    enum class Cmd { None, Open, OpenComm, Enqueue, Sync, Gather, Close, Exit };
+
+    struct Worker {
+        int index = 0, device = 0;
+        std::unique_ptr<Pipe> pipe;
+        std::thread thread;
+        std::mutex m;
+        std::condition_variable cv;
+        Cmd cmd = Cmd::None;
+        bool pending = false, done = false;
+        int rc = KICP_OK;
+        std::string err;
+        Frame frame;
+        std::vector<double> fresh;     // poses completed by the last sync (16 doubles each)
+        std::vector<double> block;     // what this rank contributes to one gather
+        std::vector<double> gathered;  // n_total blocks
+        size_t round = 0;
+        bool open = false, comm_open = false;
+    };
+
+    int fail(int rc, const char *what) {
+        error_ = what;
+        return rc;
+    }
+
+    int post_all(Cmd c) {
+        for (auto &w : workers_) {
+            {
+                std::lock_guard<std::mutex> lk(w.m);
+                w.cmd = c;
+                w.pending = true;
+                w.done = false;
+            }
+            w.cv.notify_one();
+        }
+        int rc = KICP_OK;
+        for (auto &w : workers_) {
+            std::unique_lock<std::mutex> lk(w.m);
+            w.cv.wait(lk, [&] { return w.done; });
+            if (w.rc != KICP_OK && rc == KICP_OK) {
+                rc = w.rc;
+                error_ = "stream " + std::to_string(first_rank_ + w.index) + ": " + w.err;
+            }
+        }
+        return rc;
+    }
+
+    int step(Worker &w, Cmd c) {
+        Pipe &p = *w.pipe;
+        const int rank = first_rank_ + w.index;
+        switch (c) {
+        case Cmd::Open: {
+            w.open = true;  // close() also releases what a failing open() left behind
+            int rc = p.open(rank, w.device, block_doubles(cap_) * sizeof(double), n_total_);
+            if (rc != KICP_OK) return rc;
+            return KICP_OK;
+        }
+        case Cmd::OpenComm: {
+            if (comm_.init) {
+                int rc = comm_.init(comm_.ctx, rank, n_total_, w.device);
+                if (rc != KICP_OK) {
+                    w.err = "communicator init failed";
+                    return rc;
+                }
+            }
+            w.comm_open = true;
+            return KICP_OK;
+        }
+        case Cmd::Enqueue:
+            return w.frame.skip ? KICP_OK : p.enqueue(w.frame);
+        case Cmd::Sync: {
+            int rc = p.sync();
+            if (rc != KICP_OK) return rc;
+            size_t n = 0;
+            rc = p.new_poses(nullptr, 0, &n);
+            if (rc != KICP_OK) return rc;
+            w.fresh.assign(16 * n, 0.0);
+            return n ? p.new_poses(w.fresh.data(), n, &n) : KICP_OK;
+        }
+        case Cmd::Gather: {
+            const size_t have = w.fresh.size() / 16;
+            const size_t lo = std::min(have, w.round * cap_), hi = std::min(have, lo + cap_);
+            std::fill(w.block.begin(), w.block.end(), std::numeric_limits<double>::quiet_NaN());
+            w.block[0] = double(hi - lo);
+            w.block[1] = double(rank);
+            if (hi > lo) std::memcpy(w.block.data() + 2, w.fresh.data() + 16 * lo, (hi - lo) * 16 * sizeof(double));
+            const size_t bytes = w.block.size() * sizeof(double);
+            int rc = p.put(w.block.data(), bytes);
+            if (rc != KICP_OK) return rc;
+            rc = comm_.all_gather(comm_.ctx, rank, p.send_buffer(), p.recv_buffer(), bytes, p.stream());
+            if (rc != KICP_OK) {
+                w.err = "all_gather failed";
+                return rc;
+            }
+            return p.get(w.gathered.data(), bytes * n_total_);
+        }
+        case Cmd::Close:
+            if (w.comm_open && comm_.finalize) comm_.finalize(comm_.ctx, rank);
+            w.comm_open = false;
+            if (w.open) p.close();
+            w.open = false;
+            return KICP_OK;
+        default:
+            return KICP_OK;
+        }
+    }
+
+    void run(Worker &w) {
+        for (;;) {
+            Cmd c;
+            {
+                std::unique_lock<std::mutex> lk(w.m);
+                w.cv.wait(lk, [&] { return w.pending; });
+                w.pending = false;
+                c = w.cmd;
+            }
+            if (c == Cmd::Exit) return;
+            w.err.clear();
+            int rc = step(w, c);
+            if (rc != KICP_OK && w.err.empty()) w.err = w.pipe->last_error();
+            {
+                std::lock_guard<std::mutex> lk(w.m);
+                w.rc = rc;
+                w.done = true;
+            }
+            w.cv.notify_all();
+        }
+    }
+
+    int n_local_, first_rank_, n_total_;
+    size_t cap_;
+    kicp_batch_comm comm_;
+    std::vector<Worker> workers_;
+    std::vector<std::vector<double>> all_poses_;
+    std::string error_;
+    bool started_ = false;
+    size_t syncs_ = 0;
+    double gather_seconds_ = 0.0;
+};
+
+}  // namespace kicp_mstream

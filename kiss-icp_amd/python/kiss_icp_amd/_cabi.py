@@ -115,7 +115,26 @@ SIGNATURES = {
     "kicp_device_download": [_i, _vp, _vp, _sz],
     "kicp_device_synchronize": [_i],
     "kicp_selftest_solve": [_i, _vp, _vp, _sz, _vp],
+    "kicp_batch_unique_id": [_vp],
+    "kicp_batch_create": [C.POINTER(Config), C.POINTER(_i), _i, _i, _i, _vp, _vp, _sz, C.POINTER(_vp)],
+    "kicp_batch_destroy": [_vp],
+    "kicp_batch_register_frames": [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz)],
+    "kicp_batch_register_frames_f32": [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz)],
+    "kicp_batch_sync": [_vp],
+    "kicp_batch_poses": [_vp, _i, _vp, _sz, C.POINTER(_sz)],
+    "kicp_batch_pipeline": [_vp, _i, C.POINTER(_vp)],
+    "kicp_batch_gather_seconds": [_vp, _dp],
 }
+
+
+class BatchComm(C.Structure):
+    """kicp_batch_comm (include/kicp.h): a communicator supplied by the host instead of RCCL"""
+    INIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+    ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    FINALIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+    _fields_ = [("ctx", C.c_void_p), ("init", INIT), ("all_gather", ALL_GATHER), ("finalize", FINALIZE)]
+
+
 _STRING_FUNCS = ("kicp_status_string", "kicp_last_error")
 
 _lib = None

@@ -36,6 +36,7 @@ if has pmc; then
   done
 fi
 if has 2rank; then ( timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --backend gloo --device 0 --workload kitti-street > gpurun_out/${TAG}_bench_2rank_gloo.json 2> gpurun_out/${TAG}_bench_2rank.err ); fi
+if has rccl; then ( timeout 300 python scripts/rccl_probe.py > gpurun_out/${TAG}_rccl_probe.json 2> gpurun_out/${TAG}_rccl_probe.err ); fi
 if has extra; then ( timeout ${EXTRA_TIMEOUT:-600} bash -c "${EXTRA_CMD}" > gpurun_out/${TAG}_extra.log 2>&1 ); fi
 for f in gpurun_out/${TAG}_*.log gpurun_out/${TAG}_*.json gpurun_out/${TAG}_*.txt; do [ -f "$f" ] && { echo "== $f"; tail -c 2500 "$f"; echo; }; done
 for f in gpurun_out/${TAG}_*.err; do [ -s "$f" ] && { echo "== $f"; tail -5 "$f"; }; done

@@ -76,7 +76,7 @@ def test_struct_layouts_match_header(cabi):
 def test_version_and_status_strings(cabi):
     mj, mn = C.c_int(-1), C.c_int(-1)
     assert cabi.lib().kicp_version(C.byref(mj), C.byref(mn)) == 0
-    assert (mj.value, mn.value) == (0, 2)
+    assert (mj.value, mn.value) == (0, 3)
     assert cabi.lib().kicp_status_string(0) == b"ok"
     assert b"gfx950" in cabi.lib().kicp_status_string(7)
 

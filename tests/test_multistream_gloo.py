@@ -114,3 +114,33 @@ def test_single_process_degenerates_cleanly():
     assert multistream.gather_poses(poses).shape == (1, 3, 4, 4)
     assert multistream.max_over_ranks(2.5) == 2.5
     multistream.barrier(None)
+
+
+def test_cabi_batch_driver_with_stub_pipelines_and_communicator():
+    """the C-ABI's own batch entry (kicp_batch_*, thread per stream, direct RCCL on the GPU) shares its
+    orchestration with this CPU program, which instantiates the same driver over stand-in pipelines and a
+    stand-in communicator: rank-ordered gathers, ragged / empty / multi-block batches, ranks in two processes,
+    failures of a pipeline or the communicator (tests/cpp/test_batch_stub.cpp)"""
+    import subprocess
+
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", d, "test_batch_stub"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(d, "test_batch_stub")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
+def test_cabi_batch_entry_fails_loudly_without_a_device():
+    """no GPU here: the real entry must refuse (no CPU fallback), with a message naming the stream"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.config import KISSConfig
+    from kiss_icp_amd.multistream import StreamBatch
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+
+    comm = _cabi.BatchComm(None, _cabi.BatchComm.INIT(0), _cabi.BatchComm.ALL_GATHER(lambda *a: 0), _cabi.BatchComm.FINALIZE(0))
+    with pytest.raises(_cabi.KicpError) as e:
+        StreamBatch(KISSConfig(), [0, 0], comm=comm)
+    assert e.value.status == 7 and "stream 0" in str(e.value)
