@@ -53,10 +53,9 @@ __global__ __launch_bounds__(256) void k_tile_keys(const double *xyz, const int 
 // workgroup.  So runs are cut to equal WEIGHT: a point weighs kWeightBase plus the number of map points in the
 // voxel it falls in under the initial guess (one lookup per point), and workgroup b takes the points whose
 // exclusive weight prefix lies in [b W / G, (b + 1) W / G).
-constexpr int kWeightBase = 4;
 
 // weight of the point at sorted position q under the initial guess
-__device__ __forceinline__ int tile_weight(const unsigned long long *order, const double *frame, const MapView &m, const SE3 &guess, int q) {
+__device__ __forceinline__ int tile_weight(const unsigned long long *order, const double *frame, const MapView &m, const SE3 &guess, int q, int weight_base) {
     const int p = order ? (int)(order[q] & 0xFFFFFFull) : q;
     const double pin[3] = {frame[3 * p], frame[3 * p + 1], frame[3 * p + 2]};
     double s[3];
@@ -76,20 +75,20 @@ __device__ __forceinline__ int tile_weight(const unsigned long long *order, cons
             sidx = (sidx + 1) & m.mask;
         }
     }
-    return kWeightBase + cnt;
+    return weight_base + cnt;
 }
 
 // weights and their inclusive prefix in ONE launch of one 1024-thread workgroup (the source cloud has a few
 // thousand points, at most ~10^5: a multi-kernel device scan would cost more in launches -- on the serial chain
 // of the frame, right in front of the registration -- than the work itself)
 __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
-                                                            MapView m, const PipeState *state, int pipeline_mode, int *prefix) {
+                                                            MapView m, const PipeState *state, int pipeline_mode, int weight_base, int *prefix) {
     __shared__ int wave_sum[16];
     const int n = n_ptr ? *n_ptr : n_imm;
     const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
     const int t = threadIdx.x;
     // pass 1 (coalesced): the weights themselves
-    for (int q = t; q < n; q += 1024) prefix[q] = tile_weight(order, frame, m, guess, q);
+    for (int q = t; q < n; q += 1024) prefix[q] = tile_weight(order, frame, m, guess, q, weight_base);
     __threadfence_block();
     __syncthreads();
     // pass 2: thread t owns the contiguous slice [t E, (t + 1) E)
@@ -117,9 +116,9 @@ __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long 
 }
 
 int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
-                        const PipeState *state, int pipeline_mode, int *prefix, hipStream_t s) {
+                        const PipeState *state, int pipeline_mode, int weight_base, int *prefix, hipStream_t s) {
     if (n_max == 0) return 0;
-    hipLaunchKernelGGL(k_tile_weights_scan, dim3(1), dim3(1024), 0, s, order, frame, n_ptr, n_imm, m, state, pipeline_mode, prefix);
+    hipLaunchKernelGGL(k_tile_weights_scan, dim3(1), dim3(1024), 0, s, order, frame, n_ptr, n_imm, m, state, pipeline_mode, weight_base, prefix);
     return (int)hipGetLastError();
 }
 

@@ -8,7 +8,7 @@
  * PINNING.  The reference ships no golden vectors / known-answer tests for this path
  * (python/tests/test_kiss_icp.py:1-4 is an import smoke test) and its own build needs Eigen
  * 3.4.0 / Sophus 1.24.6 / tsl::robin_map 1.4.0 / oneTBB 2022.1.0 FetchContent'ed from the network.
- *  - PINNED against the reference's own code: every line of cpp/kiss_icp/{core,pipeline}/*.cpp
+ *  - PINNED against the reference's own code: every line of cpp/kiss_icp/{core,pipeline} (.cpp files)
  *    on this path.  oracle/ref_build/ compiles those files UNMODIFIED from /root/reference
  *    against stand-in third-party headers into oracle/_ref/libkiss_ref.so, and
  *    tests/test_ref_pins_oracle.py holds this restatement to it (bit-exact survivors, map
