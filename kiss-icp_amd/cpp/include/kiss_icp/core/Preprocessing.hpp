@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "Linalg.hpp"
+#include "VoxelUtils.hpp"
 
 namespace kiss_icp {
 
@@ -20,6 +21,10 @@ struct Preprocessor {
     /// (the reference's std::vector::at, core/Preprocessing.cpp:76-77)
     std::vector<Eigen::Vector3d> Preprocess(const std::vector<Eigen::Vector3d> &frame,
                                             const std::vector<double> &timestamps,
+                                            const Sophus::SE3d &relative_motion) const;
+    std::vector<Eigen::Vector3d> Preprocess(PointSpan frame,
+                                            const double *timestamps,
+                                            std::size_t n_timestamps,
                                             const Sophus::SE3d &relative_motion) const;
     double max_range_;
     double min_range_;

@@ -26,6 +26,12 @@ struct Registration {
                                   const double max_correspondence_distance,
                                   const double kernel_scale);
 
+    Sophus::SE3d AlignPointsToMap(PointSpan frame,
+                                  const VoxelHashMap &voxel_map,
+                                  const Sophus::SE3d &initial_guess,
+                                  const double max_correspondence_distance,
+                                  const double kernel_scale);
+
     int max_num_iterations_;
     double convergence_criterion_;
     int max_num_threads_;  // kept for signature compatibility; the device schedules itself

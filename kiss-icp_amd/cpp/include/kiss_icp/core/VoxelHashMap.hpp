@@ -28,6 +28,9 @@ struct VoxelHashMap {
     void Update(const std::vector<Eigen::Vector3d> &points, const Eigen::Vector3d &origin);
     void Update(const std::vector<Eigen::Vector3d> &points, const Sophus::SE3d &pose);
     void AddPoints(const std::vector<Eigen::Vector3d> &points);
+    void Update(PointSpan points, const Eigen::Vector3d &origin);
+    void Update(PointSpan points, const Sophus::SE3d &pose);
+    void AddPoints(PointSpan points);
     void RemovePointsFarFromLocation(const Eigen::Vector3d &origin);
     std::vector<Eigen::Vector3d> Pointcloud() const;
     std::tuple<Eigen::Vector3d, double> GetClosestNeighbor(const Eigen::Vector3d &query) const;

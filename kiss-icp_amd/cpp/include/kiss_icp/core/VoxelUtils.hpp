@@ -24,6 +24,20 @@ inline Voxel PointToVoxel(const Eigen::Vector3d &point, const double voxel_size)
 
 /// Voxelize a point cloud keeping the original coordinates (first point of every voxel; output in
 /// ascending input order -- the reference's order is its hash map's bucket order, unspecified)
+/// A view of N packed points (N x 3 float64, row-major): what a numpy array, a DLPack tensor or a
+/// std::vector<Eigen::Vector3d> all are.  Every entry that takes a point vector also takes a span, so callers
+/// holding their points in another container reach the device without building a vector first (not in the
+/// reference, whose pybind layer copies an array into a vector: python/kiss_icp/pybind/stl_vector_eigen.h:67-80).
+struct PointSpan {
+    const double *xyz = nullptr;
+    std::size_t n = 0;
+    PointSpan() = default;
+    PointSpan(const double *p, std::size_t count) : xyz(count ? p : nullptr), n(count) {}
+    PointSpan(const std::vector<Eigen::Vector3d> &v)  // NOLINT: implicit on purpose
+        : xyz(v.empty() ? nullptr : reinterpret_cast<const double *>(v.data())), n(v.size()) {}
+};
+
+std::vector<Eigen::Vector3d> VoxelDownsample(PointSpan frame, const double voxel_size);
 std::vector<Eigen::Vector3d> VoxelDownsample(const std::vector<Eigen::Vector3d> &frame,
                                              const double voxel_size);
 

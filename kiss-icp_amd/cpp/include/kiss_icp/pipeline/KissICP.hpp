@@ -56,6 +56,15 @@ public:
     Vector3dVectorTuple RegisterFrame(const std::vector<Eigen::Vector3d> &frame,
                                       const std::vector<double> &timestamps);
     Vector3dVectorTuple Voxelize(const std::vector<Eigen::Vector3d> &frame) const;
+    // the same on a view of packed points (a numpy array, a DLPack tensor) ...
+    Vector3dVectorTuple RegisterFrame(PointSpan frame, const double *timestamps, std::size_t n_timestamps);
+    Vector3dVectorTuple Voxelize(PointSpan frame) const;
+    // ... and on a scan that already lies in THIS pipeline's HBM (N x 3 float64; timestamps there too or
+    // nullptr).  The producer's work on the buffers must have completed (hipStreamSynchronize /
+    // torch.cuda.synchronize); the call returns after the registration, so the buffers are free again.
+    Vector3dVectorTuple RegisterFrameDevice(const double *d_xyz, std::size_t n, const double *d_timestamps,
+                                            std::size_t n_timestamps);
+    int Device() const { return device_id_; }
 
     std::vector<Eigen::Vector3d> LocalMap() const { return local_map_.Pointcloud(); };
 
@@ -75,6 +84,8 @@ public:
     double LastSigma() const { return last_sigma_; }
 
 private:
+    void PushPoseEdits();
+    Vector3dVectorTuple CollectFrame();
     Sophus::SE3d last_pose_;
     Sophus::SE3d last_delta_;
     double dev_pose_[16];   // what the device holds (row-major), to detect edits through pose()/delta()

@@ -4,8 +4,14 @@
 // wrappers (python/kiss_icp/{registration,mapping,voxelization,preprocess,threshold}.py) and its
 // Python KissICP (python/kiss_icp/kiss_icp.py) run on this module unmodified.
 //
-//   _Vector3dVector      opaque std::vector<Eigen::Vector3d>, built from an (N,3) float64 array,
-//                        buffer protocol + __len__/__bool__ (stl_vector_eigen.h:44-117)
+//   _Vector3dVector      opaque std::vector<Eigen::Vector3d>: built from an (N,3) array or an iterable of 3-vectors,
+//                        buffer protocol, __repr__, copy, ==, and the list-like accessors / modifiers pybind11's
+//                        bind_vector machinery gives the reference's class (stl_vector_eigen.h:44-117)
+//   points arguments     every `points` / `frame` argument takes a _Vector3dVector (as in the reference), and ALSO,
+//                        without the copy into a vector, an (N,3) float64 C-contiguous numpy array or any object
+//                        with __dlpack__ on the host (zero-copy views straight into the C-ABI); other arrays /
+//                        sequences are converted like the reference's forcecast constructor.  _KissICP._register_frame
+//                        additionally takes a DLPack tensor in this GPU's HBM (torch ROCm tensor): no host trip.
 //   _VoxelHashMap, _Preprocessor, _Registration, _AdaptiveThreshold, _voxel_down_sample,
 //   _correct_kitti_scan  as in the reference (note the kwarg spelling max_correspondance_distance)
 //   _KissICP             extra: the fused device pipeline (pipeline::KissICP)
@@ -15,10 +21,15 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
 #include <stdexcept>
 #include <vector>
 
+#include "kicp.h"
 #include "kiss_icp/metrics/Metrics.hpp"
 #include "kiss_icp/pipeline/KissICP.hpp"
 
@@ -37,6 +48,116 @@ Vec3Vector from_array(const ArrayD &a) {
     if (!v.empty()) std::memcpy(static_cast<void *>(v.data()), a.data(), v.size() * sizeof(Eigen::Vector3d));
     return v;
 }
+
+// ---- points arguments ---------------------------------------------------------------------------------------------
+// minimal restatement of the DLPack ABI (dlpack.h v0.8: DLManagedTensor), enough to read a tensor's pointer, shape,
+// dtype and device
+struct DLDevice {
+    int32_t device_type, device_id;
+};
+struct DLDataType {
+    uint8_t code, bits;
+    uint16_t lanes;
+};
+struct DLTensor {
+    void *data;
+    DLDevice device;
+    int32_t ndim;
+    DLDataType dtype;
+    int64_t *shape, *strides;
+    uint64_t byte_offset;
+};
+struct DLManagedTensor {
+    DLTensor dl_tensor;
+    void *manager_ctx;
+    void (*deleter)(DLManagedTensor *);
+};
+enum { kDLCPU = 1, kDLCUDAHost = 3, kDLROCM = 10, kDLROCMHost = 11 };
+
+// What a points argument resolved to.  `keep` owns whatever the view points into for the duration of the call.
+struct Points {
+    kiss_icp::PointSpan span;      // host view (device == -1) or device pointer (device >= 0)
+    int device = -1;
+    py::object keep;
+    DLManagedTensor *managed = nullptr;
+    Points() = default;
+    Points(const Points &) = delete;
+    Points(Points &&o) noexcept : span(o.span), device(o.device), keep(std::move(o.keep)), managed(o.managed) { o.managed = nullptr; }
+    ~Points() {
+        if (managed && managed->deleter) managed->deleter(managed);
+    }
+};
+
+Points points_from_array(py::object obj) {
+    ArrayD a = ArrayD::ensure(obj);  // a view when obj is already float64 + C-contiguous, else the reference's forcecast copy
+    if (!a) throw py::cast_error("expected an (N, 3) array of points");
+    if (a.ndim() != 2 || a.shape(1) != 3) throw py::cast_error("expected an (N, 3) array of points");
+    Points p;
+    p.span = kiss_icp::PointSpan(a.data(), static_cast<size_t>(a.shape(0)));
+    p.keep = std::move(a);
+    return p;
+}
+
+Points resolve_points(py::handle h, bool allow_device) {
+    if (py::isinstance<Vec3Vector>(h)) {
+        Points p;
+        p.span = kiss_icp::PointSpan(h.cast<const Vec3Vector &>());
+        p.keep = py::reinterpret_borrow<py::object>(h);
+        return p;
+    }
+    py::object obj = py::reinterpret_borrow<py::object>(h);
+    if (!py::isinstance<py::array>(obj) && py::hasattr(obj, "__dlpack__") && py::hasattr(obj, "__dlpack_device__")) {
+        const py::tuple dev = obj.attr("__dlpack_device__")();
+        const int type = dev[0].cast<int>(), id = dev[1].cast<int>();
+        if (type == kDLCPU || type == kDLCUDAHost || type == kDLROCMHost)
+            return points_from_array(py::module_::import("numpy").attr("from_dlpack")(obj));
+        if (type != kDLROCM) throw py::type_error("points tensor lives on a device this library does not drive (DLPack device type " + std::to_string(type) + ")");
+        if (!allow_device) throw py::type_error("a tensor in GPU memory is accepted by _KissICP._register_frame only; pass host points here");
+        py::capsule cap = obj.attr("__dlpack__")();
+        auto *mt = static_cast<DLManagedTensor *>(PyCapsule_GetPointer(cap.ptr(), "dltensor"));
+        if (!mt) throw py::type_error("__dlpack__ did not return a 'dltensor' capsule");
+        PyCapsule_SetName(cap.ptr(), "used_dltensor");  // ownership taken: the deleter runs when the call is over
+        Points p;
+        p.managed = mt;
+        const DLTensor &t = mt->dl_tensor;
+        const bool f64 = t.dtype.code == 2 && t.dtype.bits == 64 && t.dtype.lanes == 1;
+        const bool shape_ok = t.ndim == 2 && t.shape[1] == 3;
+        const bool dense = !t.strides || (shape_ok && t.strides[1] == 1 && (t.strides[0] == 3 || t.shape[0] <= 1));
+        if (!f64 || !shape_ok || !dense) throw py::type_error("device points must be a contiguous (N, 3) float64 tensor");
+        p.span = kiss_icp::PointSpan(reinterpret_cast<const double *>(static_cast<const char *>(t.data) + t.byte_offset),
+                                     static_cast<size_t>(t.shape[0]));
+        p.device = id;
+        return p;
+    }
+    return points_from_array(obj);
+}
+Points host_points(py::handle h) { return resolve_points(h, false); }
+
+// timestamps: any sequence / array of floats (the reference takes std::vector<double>)
+ArrayD timestamps_array(py::object obj) {
+    ArrayD a = ArrayD::ensure(obj);
+    if (!a) throw py::cast_error("timestamps must be a sequence of floats");
+    return a;
+}
+
+Eigen::Vector3d vec3_from_object(py::handle h) {
+    ArrayD a = ArrayD::ensure(py::reinterpret_borrow<py::object>(h));
+    if (!a || a.size() != 3) throw py::cast_error("expected 3 values");
+    return Eigen::Vector3d(a.data()[0], a.data()[1], a.data()[2]);
+}
+py::array_t<double> vec3_to_array(const Eigen::Vector3d &v) {
+    py::array_t<double> out(3);
+    out.mutable_data()[0] = v.x();
+    out.mutable_data()[1] = v.y();
+    out.mutable_data()[2] = v.z();
+    return out;
+}
+size_t wrap_index(py::ssize_t i, size_t n) {
+    if (i < 0) i += static_cast<py::ssize_t>(n);
+    if (i < 0 || static_cast<size_t>(i) >= n) throw py::index_error();
+    return static_cast<size_t>(i);
+}
+bool same_point(const Eigen::Vector3d &a, const Eigen::Vector3d &b) { return a.x() == b.x() && a.y() == b.y() && a.z() == b.z(); }
 
 Sophus::SE3d se3_from_array(const ArrayD &T) {
     if (T.ndim() != 2 || T.shape(0) != 4 || T.shape(1) != 4) throw py::cast_error("expected a 4x4 float64 matrix");
@@ -73,10 +194,112 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
     py::class_<Vec3Vector>(m, "_Vector3dVector", py::buffer_protocol(), "std::vector<Eigen::Vector3d>")
         .def(py::init<>())
         .def(py::init(&from_array), "array"_a)
+        .def(py::init<const Vec3Vector &>(), "Copy constructor")
+        .def(py::init([](const py::iterable &it) {
+            auto v = std::make_unique<Vec3Vector>();
+            v->reserve(py::len_hint(it));
+            for (py::handle h : it) v->push_back(vec3_from_object(h));
+            return v;
+        }))
         .def("__len__", [](const Vec3Vector &v) { return v.size(); })
-        .def("__bool__", [](const Vec3Vector &v) { return !v.empty(); })
+        .def("__bool__", [](const Vec3Vector &v) { return !v.empty(); }, "Check whether the list is nonempty")
+        .def("__repr__",
+             [](const Vec3Vector &v) {
+                 return std::string("std::vector<Eigen::Vector3d> with ") + std::to_string(v.size()) +
+                        " elements.\nUse numpy.asarray() to access data.";
+             })
         .def("__copy__", [](const Vec3Vector &v) { return Vec3Vector(v); })
         .def("__deepcopy__", [](const Vec3Vector &v, py::dict) { return Vec3Vector(v); })
+        .def("__deepcopy__", [](const Vec3Vector &v) { return Vec3Vector(v); })
+        // equality (pybind11 vector_if_equal_operator)
+        .def("__eq__",
+             [](const Vec3Vector &a, const Vec3Vector &b) {
+                 return a.size() == b.size() && (a.empty() || std::memcmp(static_cast<const void *>(a.data()), static_cast<const void *>(b.data()),
+                                                                           a.size() * sizeof(Eigen::Vector3d)) == 0 ||
+                                                 std::equal(a.begin(), a.end(), b.begin(), same_point));
+             })
+        .def("__ne__",
+             [](const Vec3Vector &a, const Vec3Vector &b) {
+                 return !(a.size() == b.size() && std::equal(a.begin(), a.end(), b.begin(), same_point));
+             })
+        .def("count", [](const Vec3Vector &v, py::handle x) {
+            const auto p = vec3_from_object(x);
+            return std::count_if(v.begin(), v.end(), [&](const Eigen::Vector3d &q) { return same_point(p, q); });
+        }, "x"_a, "Return the number of times ``x`` appears in the list")
+        .def("remove", [](Vec3Vector &v, py::handle x) {
+            const auto p = vec3_from_object(x);
+            auto it = std::find_if(v.begin(), v.end(), [&](const Eigen::Vector3d &q) { return same_point(p, q); });
+            if (it == v.end()) throw py::value_error();
+            v.erase(it);
+        }, "x"_a, "Remove the first item from the list whose value is x. It is an error if there is no such item.")
+        .def("__contains__", [](const Vec3Vector &v, py::handle x) {
+            const auto p = vec3_from_object(x);
+            return std::any_of(v.begin(), v.end(), [&](const Eigen::Vector3d &q) { return same_point(p, q); });
+        }, "x"_a, "Return true the container contains ``x``")
+        // accessors (vector_accessor)
+        .def("__getitem__", [](const Vec3Vector &v, py::ssize_t i) { return vec3_to_array(v[wrap_index(i, v.size())]); })
+        .def("__getitem__", [](const Vec3Vector &v, const py::slice &sl) {
+            size_t start = 0, stop = 0, step = 0, len = 0;
+            if (!sl.compute(v.size(), &start, &stop, &step, &len)) throw py::error_already_set();
+            auto out = std::make_unique<Vec3Vector>();
+            out->reserve(len);
+            for (size_t i = 0; i < len; ++i, start += step) out->push_back(v[start]);
+            return out;
+        }, "Retrieve list elements using a slice object")
+        .def("__iter__", [](const Vec3Vector &v) {
+            py::list items;  // 3-vectors as numpy arrays, like the reference's Eigen caster hands them out
+            for (const auto &p : v) items.append(vec3_to_array(p));
+            return py::iter(items);
+        })
+        // modifiers (vector_modifiers)
+        .def("append", [](Vec3Vector &v, py::handle x) { v.push_back(vec3_from_object(x)); }, "x"_a, "Add an item to the end of the list")
+        .def("clear", [](Vec3Vector &v) { v.clear(); }, "Clear the contents")
+        .def("extend", [](Vec3Vector &v, const Vec3Vector &src) { v.insert(v.end(), src.begin(), src.end()); }, "L"_a,
+             "Extend the list by appending all the items in the given list")
+        .def("extend", [](Vec3Vector &v, const py::iterable &it) {
+            const size_t old = v.size();
+            try {
+                for (py::handle h : it) v.push_back(vec3_from_object(h));
+            } catch (...) {
+                v.resize(old);
+                throw;
+            }
+        }, "L"_a, "Extend the list by appending all the items in the given list")
+        .def("insert", [](Vec3Vector &v, py::ssize_t i, py::handle x) {
+            if (i < 0) i += static_cast<py::ssize_t>(v.size());
+            if (i < 0 || static_cast<size_t>(i) > v.size()) throw py::index_error();
+            v.insert(v.begin() + i, vec3_from_object(x));
+        }, "i"_a, "x"_a, "Insert an item at a given position.")
+        .def("pop", [](Vec3Vector &v) {
+            if (v.empty()) throw py::index_error();
+            auto t = vec3_to_array(v.back());
+            v.pop_back();
+            return t;
+        }, "Remove and return the last item")
+        .def("pop", [](Vec3Vector &v, py::ssize_t i) {
+            const size_t k = wrap_index(i, v.size());
+            auto t = vec3_to_array(v[k]);
+            v.erase(v.begin() + static_cast<py::ssize_t>(k));
+            return t;
+        }, "i"_a, "Remove and return the item at index ``i``")
+        .def("__setitem__", [](Vec3Vector &v, py::ssize_t i, py::handle x) { v[wrap_index(i, v.size())] = vec3_from_object(x); })
+        .def("__setitem__", [](Vec3Vector &v, const py::slice &sl, const Vec3Vector &value) {
+            size_t start = 0, stop = 0, step = 0, len = 0;
+            if (!sl.compute(v.size(), &start, &stop, &step, &len)) throw py::error_already_set();
+            if (len != value.size()) throw std::runtime_error("Left and right hand size of slice assignment have different sizes!");
+            for (size_t i = 0; i < len; ++i, start += step) v[start] = value[i];
+        }, "Assign list elements using a slice object")
+        .def("__delitem__", [](Vec3Vector &v, py::ssize_t i) { v.erase(v.begin() + static_cast<py::ssize_t>(wrap_index(i, v.size()))); },
+             "Delete the list elements at index ``i``")
+        .def("__delitem__", [](Vec3Vector &v, const py::slice &sl) {
+            size_t start = 0, stop = 0, step = 0, len = 0;
+            if (!sl.compute(v.size(), &start, &stop, &step, &len)) throw py::error_already_set();
+            if (step == 1) {
+                v.erase(v.begin() + static_cast<py::ssize_t>(start), v.begin() + static_cast<py::ssize_t>(start + len));
+            } else {
+                for (size_t i = 0; i < len; ++i, start += step - 1) v.erase(v.begin() + static_cast<py::ssize_t>(start));
+            }
+        }, "Delete list elements using a slice object")
         .def_buffer([](Vec3Vector &v) {
             return py::buffer_info(v.data(), sizeof(double), py::format_descriptor<double>::format(), 2,
                                    {static_cast<py::ssize_t>(v.size()), static_cast<py::ssize_t>(3)},
@@ -93,12 +316,13 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
         .def("_empty", &VoxelHashMap::Empty)
         .def(
             "_update",
-            [](VoxelHashMap &self, const Vec3Vector &points, const ArrayD &pose_or_origin) {
-                if (pose_or_origin.ndim() == 2) self.Update(points, se3_from_array(pose_or_origin));
-                else self.Update(points, vec3_from_array(pose_or_origin));
+            [](VoxelHashMap &self, py::object points, const ArrayD &pose_or_origin) {
+                const Points p = host_points(points);
+                if (pose_or_origin.ndim() == 2) self.Update(p.span, se3_from_array(pose_or_origin));
+                else self.Update(p.span, vec3_from_array(pose_or_origin));
             },
             "points"_a, "pose"_a)
-        .def("_add_points", &VoxelHashMap::AddPoints, "points"_a)
+        .def("_add_points", [](VoxelHashMap &self, py::object points) { self.AddPoints(host_points(points).span); }, "points"_a)
         .def(
             "_remove_far_away_points",
             [](VoxelHashMap &self, const ArrayD &origin) { self.RemovePointsFarFromLocation(vec3_from_array(origin)); },
@@ -110,8 +334,11 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
         .def(py::init<double, double, bool, int>(), "max_range"_a, "min_range"_a, "deskew"_a, "max_num_threads"_a)
         .def(
             "_preprocess",
-            [](Preprocessor &self, const Vec3Vector &points, const std::vector<double> &timestamps,
-               const ArrayD &relative_motion) { return self.Preprocess(points, timestamps, se3_from_array(relative_motion)); },
+            [](Preprocessor &self, py::object points, py::object timestamps, const ArrayD &relative_motion) {
+                const Points p = host_points(points);
+                const ArrayD ts = timestamps_array(timestamps);
+                return self.Preprocess(p.span, ts.data(), static_cast<size_t>(ts.size()), se3_from_array(relative_motion));
+            },
             "points"_a, "timestamps"_a, "relative_motion"_a);
 
     // Point Cloud registration
@@ -119,9 +346,10 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
         .def(py::init<int, double, int>(), "max_num_iterations"_a, "convergence_criterion"_a, "max_num_threads"_a)
         .def(
             "_align_points_to_map",
-            [](Registration &self, const Vec3Vector &points, const VoxelHashMap &voxel_map, const ArrayD &T_guess,
+            [](Registration &self, py::object points, const VoxelHashMap &voxel_map, const ArrayD &T_guess,
                double max_correspondence_distance, double kernel) {
-                return se3_to_array(self.AlignPointsToMap(points, voxel_map, se3_from_array(T_guess),
+                const Points p = host_points(points);
+                return se3_to_array(self.AlignPointsToMap(p.span, voxel_map, se3_from_array(T_guess),
                                                           max_correspondence_distance, kernel));
             },
             "points"_a, "voxel_map"_a, "initial_guess"_a, "max_correspondance_distance"_a, "kernel"_a)
@@ -137,14 +365,18 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
             "model_deviation"_a);
 
     // preprocessing modules
-    m.def("_voxel_down_sample", &VoxelDownsample, "frame"_a, "voxel_size"_a);
+    m.def(
+        "_voxel_down_sample", [](py::object frame, double voxel_size) { return VoxelDownsample(host_points(frame).span, voxel_size); },
+        "frame"_a, "voxel_size"_a);
     // KITTI-only scan correction (kiss_icp_pybind.cpp:127-138): rotate every point by 0.205 deg
     // about the axis pt x (0,0,1).  Host arithmetic, it runs once per scan in the dataloader.
     m.def(
         "_correct_kitti_scan",
-        [](const Vec3Vector &frame) {
+        [](py::object frame_obj) {
             constexpr double kVerticalAngleOffset = (0.205 * M_PI) / 180.0;
-            Vec3Vector out = frame;
+            const Points fp = host_points(frame_obj);
+            Vec3Vector out(fp.span.n);
+            if (fp.span.n) std::memcpy(static_cast<void *>(out.data()), fp.span.xyz, fp.span.n * sizeof(Eigen::Vector3d));
             const double c = std::cos(kVerticalAngleOffset), s = std::sin(kVerticalAngleOffset);
             for (auto &pt : out) {
                 // axis = normalize(pt x e_z) = (y, -x, 0) / |(x, y)|;  Rodrigues' formula
@@ -190,11 +422,37 @@ PYBIND11_MODULE(kiss_icp_pybind, m) {
         .def(py::init<const pipeline::KISSConfig &>(), "config"_a)
         .def(
             "_register_frame",
-            [](pipeline::KissICP &self, const Vec3Vector &frame, const std::vector<double> &timestamps) {
-                return self.RegisterFrame(frame, timestamps);
+            [](pipeline::KissICP &self, py::object frame, py::object timestamps) {
+                const Points p = resolve_points(frame, true);
+                if (p.device < 0) {
+                    const ArrayD ts = timestamps_array(timestamps);
+                    return self.RegisterFrame(p.span, ts.data(), static_cast<size_t>(ts.size()));
+                }
+                // a tensor in HBM: it has to be this pipeline's GPU, its timestamps (if any) a float64 tensor there too
+                if (p.device != self.Device()) throw py::value_error("the scan lives on GPU " + std::to_string(p.device) + ", the pipeline on GPU " + std::to_string(self.Device()));
+                const double *d_ts = nullptr;
+                size_t n_ts = 0;
+                Points tsp;
+                if (!timestamps.is_none() && py::len(timestamps) > 0) {
+                    if (!py::hasattr(timestamps, "__dlpack__")) throw py::type_error("with a scan in GPU memory the timestamps must be a float64 tensor on the same GPU (or empty)");
+                    py::capsule cap = timestamps.attr("__dlpack__")();
+                    auto *mt = static_cast<DLManagedTensor *>(PyCapsule_GetPointer(cap.ptr(), "dltensor"));
+                    if (!mt) throw py::type_error("__dlpack__ did not return a 'dltensor' capsule");
+                    PyCapsule_SetName(cap.ptr(), "used_dltensor");
+                    tsp.managed = mt;
+                    const DLTensor &t = mt->dl_tensor;
+                    if (t.device.device_type != kDLROCM || t.device.device_id != p.device || t.dtype.code != 2 || t.dtype.bits != 64 || t.ndim != 1 ||
+                        (t.strides && t.strides[0] != 1 && t.shape[0] > 1))
+                        throw py::type_error("timestamps must be a contiguous 1-d float64 tensor on the scan's GPU");
+                    d_ts = reinterpret_cast<const double *>(static_cast<const char *>(t.data) + t.byte_offset);
+                    n_ts = static_cast<size_t>(t.shape[0]);
+                }
+                // the producer (torch) may still be writing on a stream of its own
+                if (kicp_device_synchronize(p.device) != KICP_OK) throw std::runtime_error(kicp_last_error());
+                return self.RegisterFrameDevice(p.span.xyz, p.span.n, d_ts, n_ts);
             },
             "frame"_a, "timestamps"_a)
-        .def("_voxelize", &pipeline::KissICP::Voxelize, "frame"_a)
+        .def("_voxelize", [](const pipeline::KissICP &self, py::object frame) { return self.Voxelize(host_points(frame).span); }, "frame"_a)
         .def("_local_map", &pipeline::KissICP::LocalMap)
         .def("_pose", [](const pipeline::KissICP &self) { return se3_to_array(self.pose()); })
         .def("_delta", [](const pipeline::KissICP &self) { return se3_to_array(self.delta()); })

@@ -38,9 +38,12 @@ int DefaultDevice() { return g_default_device; }
 
 // ---- VoxelUtils ---------------------------------------------------------------------------------
 std::vector<Eigen::Vector3d> VoxelDownsample(const std::vector<Eigen::Vector3d> &frame, const double voxel_size) {
-    std::vector<Eigen::Vector3d> out(frame.size());
+    return VoxelDownsample(PointSpan(frame), voxel_size);
+}
+std::vector<Eigen::Vector3d> VoxelDownsample(PointSpan frame, const double voxel_size) {
+    std::vector<Eigen::Vector3d> out(frame.n);
     size_t n = 0;
-    check(kicp_voxel_downsample(xyz(frame), frame.size(), voxel_size, DefaultDevice(), xyz(out), &n), "VoxelDownsample");
+    check(kicp_voxel_downsample(frame.xyz, frame.n, voxel_size, DefaultDevice(), xyz(out), &n), "VoxelDownsample");
     out.resize(n);
     out.shrink_to_fit();
     return out;
@@ -91,15 +94,22 @@ std::size_t VoxelHashMap::NumVoxels() const {
     return nv;
 }
 void VoxelHashMap::Update(const std::vector<Eigen::Vector3d> &points, const Eigen::Vector3d &origin) {
-    check(kicp_map_update_origin(handle_, xyz(points), points.size(), origin.data()), "VoxelHashMap::Update");
+    Update(PointSpan(points), origin);
 }
 void VoxelHashMap::Update(const std::vector<Eigen::Vector3d> &points, const Sophus::SE3d &pose) {
+    Update(PointSpan(points), pose);
+}
+void VoxelHashMap::AddPoints(const std::vector<Eigen::Vector3d> &points) { AddPoints(PointSpan(points)); }
+void VoxelHashMap::Update(PointSpan points, const Eigen::Vector3d &origin) {
+    check(kicp_map_update_origin(handle_, points.xyz, points.n, origin.data()), "VoxelHashMap::Update");
+}
+void VoxelHashMap::Update(PointSpan points, const Sophus::SE3d &pose) {
     double T[16];
     detail::se3_to_rowmajor(pose, T);
-    check(kicp_map_update_pose(handle_, xyz(points), points.size(), T), "VoxelHashMap::Update");
+    check(kicp_map_update_pose(handle_, points.xyz, points.n, T), "VoxelHashMap::Update");
 }
-void VoxelHashMap::AddPoints(const std::vector<Eigen::Vector3d> &points) {
-    check(kicp_map_add_points(handle_, xyz(points), points.size()), "VoxelHashMap::AddPoints");
+void VoxelHashMap::AddPoints(PointSpan points) {
+    check(kicp_map_add_points(handle_, points.xyz, points.n), "VoxelHashMap::AddPoints");
 }
 void VoxelHashMap::RemovePointsFarFromLocation(const Eigen::Vector3d &origin) {
     check(kicp_map_remove_far(handle_, origin.data()), "VoxelHashMap::RemovePointsFarFromLocation");
@@ -146,10 +156,14 @@ Registration::~Registration() {
 Sophus::SE3d Registration::AlignPointsToMap(const std::vector<Eigen::Vector3d> &frame, const VoxelHashMap &voxel_map,
                                             const Sophus::SE3d &initial_guess,
                                             const double max_correspondence_distance, const double kernel_scale) {
+    return AlignPointsToMap(PointSpan(frame), voxel_map, initial_guess, max_correspondence_distance, kernel_scale);
+}
+Sophus::SE3d Registration::AlignPointsToMap(PointSpan frame, const VoxelHashMap &voxel_map, const Sophus::SE3d &initial_guess,
+                                            const double max_correspondence_distance, const double kernel_scale) {
     double guess[16], out[16];
     detail::se3_to_rowmajor(initial_guess, guess);
     kicp_icp_stats st;
-    check(kicp_align_points_to_map(handle_, xyz(frame), frame.size(), voxel_map.handle_, guess,
+    check(kicp_align_points_to_map(handle_, frame.xyz, frame.n, voxel_map.handle_, guess,
                                    max_correspondence_distance, kernel_scale, out, &st),
           "Registration::AlignPointsToMap");
     last_iterations_ = st.iterations;
@@ -166,12 +180,16 @@ Preprocessor::Preprocessor(const double max_range, const double min_range, const
 std::vector<Eigen::Vector3d> Preprocessor::Preprocess(const std::vector<Eigen::Vector3d> &frame,
                                                       const std::vector<double> &timestamps,
                                                       const Sophus::SE3d &relative_motion) const {
+    return Preprocess(PointSpan(frame), timestamps.empty() ? nullptr : timestamps.data(), timestamps.size(), relative_motion);
+}
+std::vector<Eigen::Vector3d> Preprocessor::Preprocess(PointSpan frame, const double *timestamps, std::size_t n_timestamps,
+                                                      const Sophus::SE3d &relative_motion) const {
     double T[16];
     detail::se3_to_rowmajor(relative_motion, T);
-    std::vector<Eigen::Vector3d> out(frame.size());
+    std::vector<Eigen::Vector3d> out(frame.n);
     size_t n = 0;
-    check(kicp_preprocess(xyz(frame), frame.size(), timestamps.empty() ? nullptr : timestamps.data(),
-                          timestamps.size(), T, max_range_, min_range_, deskew_ ? 1 : 0,
+    check(kicp_preprocess(frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps, T, max_range_, min_range_,
+                          deskew_ ? 1 : 0,
                           device_id_ >= 0 ? device_id_ : DefaultDevice(), xyz(out), &n),
           "Preprocessor::Preprocess");
     out.resize(n);
@@ -244,19 +262,16 @@ KissICP::~KissICP() {
     if (handle_) kicp_pipeline_destroy(handle_);
 }
 
-KissICP::Vector3dVectorTuple KissICP::RegisterFrame(const std::vector<Eigen::Vector3d> &frame,
-                                                    const std::vector<double> &timestamps) {
+void KissICP::PushPoseEdits() {
     // pose()/delta() hand out mutable references (KissICP.hpp:80-84): push edits to the device
     double T[16];
     detail::se3_to_rowmajor(last_pose_, T);
     if (std::memcmp(T, dev_pose_, sizeof T) != 0) check(kicp_pipeline_set_pose(handle_, T), "KissICP::pose");
     detail::se3_to_rowmajor(last_delta_, T);
     if (std::memcmp(T, dev_delta_, sizeof T) != 0) check(kicp_pipeline_set_delta(handle_, T), "KissICP::delta");
+}
 
-    check(kicp_pipeline_register_frame(handle_, xyz(frame), frame.size(),
-                                       timestamps.empty() ? nullptr : timestamps.data(), timestamps.size()),
-          "KissICP::RegisterFrame");
-
+KissICP::Vector3dVectorTuple KissICP::CollectFrame() {
     check(kicp_pipeline_pose(handle_, dev_pose_), "KissICP::pose");
     check(kicp_pipeline_delta(handle_, dev_delta_), "KissICP::delta");
     last_pose_ = detail::se3_from_rowmajor(dev_pose_);
@@ -277,17 +292,42 @@ KissICP::Vector3dVectorTuple KissICP::RegisterFrame(const std::vector<Eigen::Vec
     return {std::move(pre), std::move(source)};  // KissICP.cpp:67
 }
 
+KissICP::Vector3dVectorTuple KissICP::RegisterFrame(const std::vector<Eigen::Vector3d> &frame,
+                                                    const std::vector<double> &timestamps) {
+    return RegisterFrame(PointSpan(frame), timestamps.empty() ? nullptr : timestamps.data(), timestamps.size());
+}
+
+KissICP::Vector3dVectorTuple KissICP::RegisterFrame(PointSpan frame, const double *timestamps, std::size_t n_timestamps) {
+    PushPoseEdits();
+    check(kicp_pipeline_register_frame(handle_, frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps),
+          "KissICP::RegisterFrame");
+    return CollectFrame();
+}
+
+KissICP::Vector3dVectorTuple KissICP::RegisterFrameDevice(const double *d_xyz, std::size_t n, const double *d_timestamps,
+                                                          std::size_t n_timestamps) {
+    PushPoseEdits();
+    check(kicp_pipeline_register_frame_device(handle_, d_xyz, n, n_timestamps ? d_timestamps : nullptr, n_timestamps),
+          "KissICP::RegisterFrameDevice");
+    check(kicp_pipeline_sync(handle_), "KissICP::RegisterFrameDevice");
+    return CollectFrame();
+}
+
 KissICP::Vector3dVectorTuple KissICP::Voxelize(const std::vector<Eigen::Vector3d> &frame) const {
+    return Voxelize(PointSpan(frame));
+}
+
+KissICP::Vector3dVectorTuple KissICP::Voxelize(PointSpan frame) const {
     const auto voxel_size = config_.voxel_size;  // KissICP.cpp:70-75, on THIS pipeline's device
-    auto downsample = [this](const Vector3dVector &in, double v) {
-        Vector3dVector out(in.size());
+    auto downsample = [this](PointSpan in, double v) {
+        Vector3dVector out(in.n);
         size_t n = 0;
-        check(kicp_voxel_downsample(xyz(in), in.size(), v, device_id_, xyz(out), &n), "KissICP::Voxelize");
+        check(kicp_voxel_downsample(in.xyz, in.n, v, device_id_, xyz(out), &n), "KissICP::Voxelize");
         out.resize(n);
         return out;
     };
     auto frame_downsample = downsample(frame, voxel_size * 0.5);
-    auto source = downsample(frame_downsample, voxel_size * 1.5);
+    auto source = downsample(PointSpan(frame_downsample), voxel_size * 1.5);
     return {std::move(source), std::move(frame_downsample)};
 }
 

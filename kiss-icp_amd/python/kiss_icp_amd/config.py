@@ -1,8 +1,10 @@
 """KISSConfig -- field names and defaults of the reference's python/kiss_icp/config/config.py:28-48
-and pipeline/KissICP.hpp:36-54, as plain dataclasses (pydantic_settings is not available here; the
-YAML/env loading of config/parser.py is application glue outside the hot path)."""
+and pipeline/KissICP.hpp:36-54, as plain dataclasses (pydantic_settings is not available here), with the
+YAML loading / writing of config/parser.py:50-90 (environment-variable overrides are not restated)."""
+import dataclasses
 from dataclasses import dataclass, field
-from typing import Optional
+from pathlib import Path
+from typing import Optional, Union
 
 
 @dataclass
@@ -47,11 +49,30 @@ class KISSConfig:
             self.mapping.voxel_size = float(self.data.max_range / 100.0)
 
 
-def load_config(**overrides) -> KISSConfig:
-    """KISSConfig from flat keyword overrides, e.g. load_config(max_range=80, deskew=False);
-    voxel_size defaults to max_range / 100 like config/parser.py:78-79."""
+def load_config(config_file: Optional[Union[str, Path]] = None, **overrides) -> KISSConfig:
+    """KISSConfig from an optional YAML file with the reference's layout (config/parser.py:50-81: sections data /
+    registration / mapping / adaptive_threshold, and out_dir) and / or flat keyword overrides, e.g.
+    load_config(max_range=80, deskew=False); voxel_size defaults to max_range / 100 like config/parser.py:78-79."""
     sections = {"data": DataConfig(), "mapping": MappingConfig(), "registration": RegistrationConfig(),
                 "adaptive_threshold": AdaptiveThresholdConfig()}
+    out_dir = {}
+    if config_file is not None:
+        import yaml
+
+        with open(config_file) as f:
+            data = yaml.safe_load(f) or {}
+        for name, values in data.items():
+            if name == "out_dir":
+                out_dir["out_dir"] = str(values)
+            elif name in sections and isinstance(values, dict):
+                for k, v in values.items():
+                    if not hasattr(sections[name], k):
+                        raise KeyError(f"{name}.{k}")
+                    setattr(sections[name], k, v)
+            else:
+                raise KeyError(name)
+    if "out_dir" in overrides:
+        out_dir["out_dir"] = overrides.pop("out_dir")
     for k, v in overrides.items():
         for section in sections.values():
             if hasattr(section, k):
@@ -59,4 +80,12 @@ def load_config(**overrides) -> KISSConfig:
                 break
         else:
             raise KeyError(k)
-    return KISSConfig(**sections)
+    return KISSConfig(**out_dir, **sections)
+
+
+def write_config(config: KISSConfig = None, filename: str = "kiss_icp.yaml"):
+    """config/parser.py:84-90: the configuration as YAML"""
+    import yaml
+
+    with open(filename, "w") as outfile:
+        yaml.dump(dataclasses.asdict(config if config is not None else KISSConfig()), outfile, default_flow_style=False)

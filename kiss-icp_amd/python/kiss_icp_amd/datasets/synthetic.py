@@ -89,6 +89,20 @@ class SyntheticLidar:
         T[:3, :3], T[:3, 3] = R, t
         return T
 
+    # what the reference's dataloaders offer its OdometryPipeline (python/kiss_icp/pipeline.py:66-73,147-152)
+    @property
+    def gt_poses(self):
+        """(n_frames, 4, 4) ground-truth sensor poses, relative to the first one"""
+        T0_inv = np.linalg.inv(self.gt_pose(0))
+        return np.array([T0_inv @ self.gt_pose(k) for k in range(self.n_frames)])
+
+    @property
+    def sequence_id(self):
+        return "synthetic_%dx%d_seed%d" % (self.H, self.W, self.seed)
+
+    def get_frames_timestamps(self):
+        return 0.1 * np.arange(self.n_frames)  # a 10 Hz sensor
+
     # ---- terrain ---------------------------------------------------------------------
     def _lateral(self, x, y):
         """signed distance of (x, y) from the road axis (a line, or a circle of radius step / yaw)"""
