@@ -326,8 +326,9 @@ int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t 
  *                     on the device: ceil(N_src / (16 * icp_points_per_group)), at most 256)
  *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 1)
  *   "icp_weight_base" 1..1024: the workgroups take contiguous runs of the spatially sorted source cloud of equal
- *                     WEIGHT, a point weighing this + the population of its voxel (default 4; measured flat
- *                     between 4 and 16, worse above: profiles/r02_w_sweep.txt)
+ *                     WEIGHT, a point weighing this + the population of its voxel (default 16: on the 1M-point /
+ *                     0.1 m configuration 135 us per iteration against 175 at 4 and 146 at 64, flat on the
+ *                     KITTI-like one: profiles/r02_w_sweep.txt, r02_ab_sweep_weights.txt)
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         const int ck = tid % kIcpTerms, cg = tid / kIcpTerms;  // phase C: term and group of this thread
         double acc = 0.0;
         unsigned t_group = 0;
+        unsigned prof_path = 0;
         for (int base = 0; base < n_local; base += kIcpChunk) {
             const int cn = min(kIcpChunk, n_local - base);
             // ---- A -------------------------------------------------------------------------------------
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)(td - tc) << 16);  // window phase of the chunk, search
                     r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)E << 16);  // points in the tile so far, examined
                     r[3] = (unsigned)path;
+                    prof_path = (unsigned)path;
                 }
                 int nt = 0;
                 if (lane == 0) nt = atomicAdd(&sh.next_point, 1);
@@ -416,6 +418,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += terms[i][ck];
                 __syncthreads();
             }
+        }
+        if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters) {
+            // the group's record of this iteration, completed: its first point's path, the points of the workgroup's
+            // run, the time the group spent searching in all chunks
+            unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) + (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+            r[3] = (prof_path & 15u) | ((unsigned)min(n_local, 4095) << 4) | (min(t_group, 0xFFFFu) << 16);
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
         const unsigned c1 = PROF ? ticks32() : 0u;

@@ -242,7 +242,7 @@ struct Options {
     long icp_reserve_cus = 32;   // CUs left out of the ICP grid (one per shader engine) for the front stages of the next frame
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
-    long icp_weight_base = 4;    // run boundaries: a source point weighs this + the population of its voxel
+    long icp_weight_base = 16;   // run boundaries: a source point weighs this + the population of its voxel
     long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once
 };
 Options &options();

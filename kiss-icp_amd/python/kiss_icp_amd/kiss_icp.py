@@ -180,17 +180,19 @@ class KissICP:
         return a.value / 100.0, b.value / 100.0, n.value
 
     def icp_group_profile(self):
-        """(n_iters, n_groups, 7) int64 of the last ICP launch ("icp_profile" option on): 10 ns ticks
-        {wait-in, transform + window test, window fill, scan}, staged points, examined points, path"""
+        """(n_iters, n_groups, 9) int64 of the last ICP launch ("icp_profile" option on): 10 ns ticks
+        {wait-in, transform + window test, window fill, scan} of the group's first point, staged points, examined
+        points, path, points in the workgroup's run, ticks the group spent searching in the whole iteration"""
         buf = np.zeros(24 * 256 * 16 * 4, dtype=np.uint32)
         ni, ng = C.c_int(0), C.c_int(0)
         _cabi.check(_cabi.lib().kicp_pipeline_icp_group_profile(self._h, _cabi.ptr(buf), buf.size, C.byref(ni), C.byref(ng)))
         raw = buf[: ni.value * ng.value * 4].reshape(ni.value, ng.value, 4).astype(np.int64)
-        out = np.zeros((ni.value, ng.value, 7), dtype=np.int64)
+        out = np.zeros((ni.value, ng.value, 9), dtype=np.int64)
         out[..., 0], out[..., 1] = raw[..., 0] & 0xFFFF, raw[..., 0] >> 16
         out[..., 2], out[..., 3] = raw[..., 1] & 0xFFFF, raw[..., 1] >> 16
         out[..., 4], out[..., 5] = raw[..., 2] & 0xFFFF, raw[..., 2] >> 16
-        out[..., 6] = raw[..., 3]
+        out[..., 6] = raw[..., 3] & 15
+        out[..., 7], out[..., 8] = (raw[..., 3] >> 4) & 4095, raw[..., 3] >> 16
         return out
 
     def stream(self):

@@ -41,3 +41,19 @@ if gp.size:
         for w in worst:
             print('   slow group %4d (wg %3d): wait %5.2f xform %5.2f fill %5.2f scan %5.2f us staged %4d examined %4d path %d' % (
                 w, w // 16, g[w, 0] / 100, g[w, 1] / 100, g[w, 2] / 100, g[w, 3] / 100, g[w, 4], g[w, 5], g[w, 6]))
+
+    # per workgroup (iteration 6 or the last): points of its run, points in its tile, search time of its slowest group
+    it = min(6, gp.shape[0] - 1)
+    g = gp[it].reshape(-1, 16, 9)
+    wg_t = g[:, :, 8].max(axis=1) / 100.0
+    wg_n = g[:, 0, 7]
+    wg_staged = g[:, :, 4].max(axis=1)
+    wg_ex = g[:, :, 5].mean(axis=1)
+    used = wg_n > 0
+    print('per workgroup, iteration %d: %d workgroups with points; search time of the slowest group: mean %.2f  p50 %.2f  p90 %.2f  max %.2f us' % (
+        it, used.sum(), wg_t[used].mean(), np.percentile(wg_t[used], 50), np.percentile(wg_t[used], 90), wg_t[used].max()))
+    print('   correlation of that time with: run points %.2f   tile points %.2f   examined per first point %.2f' % (
+        np.corrcoef(wg_t[used], wg_n[used])[0, 1], np.corrcoef(wg_t[used], wg_staged[used])[0, 1], np.corrcoef(wg_t[used], wg_ex[used])[0, 1]))
+    order = np.argsort(-wg_t)
+    for w in list(order[:12]) + list(order[used.sum() // 2: used.sum() // 2 + 4]) + list(order[used.sum() - 6: used.sum()]):
+        print('   wg %3d: %6.2f us  run %4d points  tile %5d points  examined/first point %5.1f' % (w, wg_t[w], wg_n[w], wg_staged[w], wg_ex[w]))

@@ -16,6 +16,9 @@ name, values = sys.argv[1], [int(v) for v in sys.argv[2].split(',')]
 kw = dict(a.split('=') for a in sys.argv[3:])
 do_livox, do_kitti = kw.pop('livox', '0') == '1', kw.pop('kitti', '1') == '1'
 frames = int(kw.pop('frames', '0'))
+livox_frames = int(kw.pop('livox_frames', '16'))
+outer = kw.pop('outer', None)  # outer=name:v1,v2 -- a second option swept around the first
+outer_name, outer_vals = (outer.split(':')[0], [int(v) for v in outer.split(':')[1].split(',')]) if outer else (None, [None])
 for k, v in kw.items():
     _cabi.set_option(k, int(v))
 work = []
@@ -23,11 +26,13 @@ if do_kitti:
     nf = frames or 120
     work.append(('kitti', generate_scans(kitti_like_vegetated, dict(seed=0, n_frames=nf), range(nf)), load_config(deskew=False), nf // 2))
 if do_livox:
-    nf = 16
-    work.append(('livox', generate_scans(livox_like, dict(seed=2, n_frames=nf), range(nf)), load_config(deskew=False, voxel_size=0.1), 6))
+    nf = livox_frames
+    work.append(('livox', generate_scans(livox_like, dict(seed=2, n_frames=nf), range(nf)), load_config(deskew=False, voxel_size=0.1), max(6, nf // 2)))
 for wname, scans, cfg, warm in work:
     ref = None
-    for v in values:
+    for ov, v in [(ov, v) for ov in outer_vals for v in values]:
+        if outer_name:
+            _cabi.set_option(outer_name, ov)
         _cabi.set_option(name, v)
         k = KissICP(cfg)
         for i in range(warm):
@@ -44,6 +49,6 @@ for wname, scans, cfg, warm in work:
         pose = k.last_pose.copy()
         same = True if ref is None else bool(np.array_equal(ref, pose))
         ref = pose if ref is None else ref
-        print('%s %s=%-8d frame %.3f ms  k_icp %.3f ms/launch  %.2f us/iter  iters/frame %.1f  n_src %d  same_pose %s' % (
-            wname, name, v, 1e3 * wall / (len(scans) - warm), ms / launches, 1e3 * ms / iters, iters / launches, k.last_stats()['n_source'], same), flush=True)
+        print('%s%s %s=%-8d frame %.3f ms  k_icp %.3f ms/launch  %.2f us/iter  iters/frame %.1f  n_src %d  same_pose %s' % (
+            wname, (' %s=%d' % (outer_name, ov)) if outer_name else '', name, v, 1e3 * wall / (len(scans) - warm), ms / launches, 1e3 * ms / iters, iters / launches, k.last_stats()['n_source'], same), flush=True)
         del k
