@@ -23,7 +23,8 @@ if has pmc; then
   for wl in ${PMC_WORKLOADS:-kitti}; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       d=gpurun_out/${TAG}_pmc_${wl}_${ctr}
-      ( timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $d -o r -- python bench.py --workload $wl --no-cpu-baseline --no-extras --steps 10 --warmup 3 > /dev/null 2> $d.err )
+      # (--gen-procs 1: a worker pool torn down under rocprofv3 --pmc has hung the run before)
+      ( timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $d -o r -- python bench.py --workload $wl --no-cpu-baseline --no-extras --steps 12 --warmup 4 --gen-procs 1 > /dev/null 2> $d.err )
       f=$(find $d -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python scripts/pmc_summary.py "$f" > $d.txt 2>&1
       rm -rf $d
     done

@@ -210,7 +210,8 @@ def test_odometry_pipeline_writes_poses_and_metrics(gpu, built, tmp_path):
     single.run()
     assert np.array_equal(single.poses, queued.poses[:20])
     d = res.as_dict()
-    assert d["Absolute Trajectory Error (ATE)"] < 0.5 and d["Average Translation Error"] < 5.0 and d["Average Frequency"] > 50  # (32 beams, 2 cm range noise)
+    assert d["Absolute Trajectory Error (ATE)"] < 0.5 and d["Average Frequency"] > 50  # (32 beams, 2 cm range noise)
+    assert "Average Translation Error" in d  # (KITTI segment errors need >= 100 m of path: NaN on this 24 m drive, like the reference's)
     out = os.path.join(str(tmp_path / "results"), "latest")
     names = sorted(os.listdir(out))
     seq = ds.sequence_id
