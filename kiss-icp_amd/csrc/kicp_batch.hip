@@ -83,6 +83,7 @@ struct HipPipe {
         xchg = nullptr;
     }
     const char *last_error() const { return err.c_str(); }
+    const char *thread_error() const { return kicp_last_error(); }
 };
 
 // ---- RCCL, called directly ------------------------------------------------------------------------------------------
@@ -105,8 +106,17 @@ struct RcclApi {
 
     bool load() {
         if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // The ROCm installation's own library, by PATH, before the bare name: a process that has imported torch
+        // already holds torch's bundled librccl under the same soname, built against another HIP runtime than the
+        // one libkicp.so runs on -- a dlopen by soname would hand that one back (seen: ncclCommInitRank failing
+        // in a pytest process after `import torch`).
+        std::vector<std::string> names;
+        if (const char *root = getenv("ROCM_PATH")) names.push_back(std::string(root) + "/lib/librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        for (const std::string &name : names) {
+            lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
         }
         if (!lib) {

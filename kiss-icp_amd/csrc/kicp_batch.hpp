@@ -44,6 +44,8 @@ struct Frame {
 //   int  put(const void *host, size_t bytes)        host -> send buffer, ordered on stream()
 //   int  get(void *host, size_t bytes)              recv buffer -> host, after the stream drained
 //   void close()
+//   const char *last_error(), *thread_error()      text of the pipeline's last failure / of the calling thread's (what a
+//                                                   communicator running on this thread reported)
 // Status codes are kicp_status; the text of a failure is fetched with last_error().
 
 // One block per rank and gather: a count and `cap` poses.  Fixed size, so that ranks in different processes
@@ -211,7 +213,7 @@ private:
             if (comm_.init) {
                 int rc = comm_.init(comm_.ctx, rank, n_total_, w.device);
                 if (rc != KICP_OK) {
-                    w.err = "communicator init failed";
+                    w.err = std::string("communicator init failed: ") + p.thread_error();
                     return rc;
                 }
             }
@@ -241,7 +243,7 @@ private:
             if (rc != KICP_OK) return rc;
             rc = comm_.all_gather(comm_.ctx, rank, p.send_buffer(), p.recv_buffer(), bytes, p.stream());
             if (rc != KICP_OK) {
-                w.err = "all_gather failed";
+                w.err = std::string("all_gather failed: ") + p.thread_error();
                 return rc;
             }
             return p.get(w.gathered.data(), bytes * n_total_);

@@ -13,7 +13,7 @@
 
 #include <rocprim/rocprim.hpp>
 
-#include "kicp_launch.hpp"
+#include "kicp_search.hpp"
 
 namespace kicp {
 
@@ -54,48 +54,99 @@ __global__ __launch_bounds__(256) void k_tile_keys(const double *xyz, const int 
 // voxel it falls in under the initial guess (one lookup per point), and workgroup b takes the points whose
 // exclusive weight prefix lies in [b W / G, (b + 1) W / G).
 
-// weight of the point at sorted position q under the initial guess
-__device__ __forceinline__ int tile_weight(const unsigned long long *order, const double *frame, const MapView &m, const SE3 &guess, int q, int weight_base) {
-    const int p = order ? (int)(order[q] & 0xFFFFFFull) : q;
-    const double pin[3] = {frame[3 * p], frame[3 * p + 1], frame[3 * p + 2]};
-    double s[3];
-    se3_act(guess, pin, s);
-    const int vx = voxel_coord(s[0], m.voxel_size), vy = voxel_coord(s[1], m.voxel_size), vz = voxel_coord(s[2], m.voxel_size);
-    int cnt = 0;
-    if (voxel_in_range(vx, vy, vz)) {
-        const unsigned long long key = pack_voxel(vx, vy, vz);
-        uint32_t sidx = hash_key(key, m.mask);
-        for (uint32_t probes = 0; probes <= m.mask; ++probes) {
-            const unsigned long long k = m.slots[sidx].key;
-            if (k == key) {
-                cnt = m.slots[sidx].count;
-                break;
-            }
-            if (k == kKeyEmpty) break;
-            sidx = (sidx + 1) & m.mask;
-        }
-    }
-    return weight_base + cnt;
-}
-
 // weights and their inclusive prefix in ONE launch of one 1024-thread workgroup (the source cloud has a few
 // thousand points, at most ~10^5: a multi-kernel device scan would cost more in launches -- on the serial chain
 // of the frame, right in front of the registration -- than the work itself)
 __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
                                                             MapView m, const PipeState *state, int pipeline_mode, int weight_base, int *prefix) {
     __shared__ int wave_sum[16];
+    constexpr int kLdsWeights = 24576;
+    __shared__ unsigned short lds_w[kLdsWeights];  // (a weight is at most base + 255)
     const int n = n_ptr ? *n_ptr : n_imm;
     const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
     const int t = threadIdx.x;
-    // pass 1 (coalesced): the weights themselves
-    for (int q = t; q < n; q += 1024) prefix[q] = tile_weight(order, frame, m, guess, q, weight_base);
+    const bool in_lds = n <= kLdsWeights && weight_base <= 1024;
+    // pass 1 (coalesced): the weights themselves.  This launch sits on the serial chain of a frame, right in front
+    // of the registration, and a thread's lookups are chains of dependent loads (sort key -> point -> map slot):
+    // kBatch of them are kept in flight per thread, stage by stage, instead of one after the other.  (What is left
+    // of the ~19 us of this launch on a KITTI-like frame is the chain itself -- count, key, point, slot: four
+    // dependent round trips to memory written by other XCDs a moment ago -- and the launch.)
+    constexpr int kBatch = 8;
+    for (int q0 = t; q0 < n; q0 += 1024 * kBatch) {
+        int pidx[kBatch];
+        double pin[kBatch][3];
+        unsigned long long key[kBatch];
+        uint32_t sidx[kBatch];
+        int cnt[kBatch];
+        bool pend[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int q = q0 + 1024 * u;
+            pidx[u] = q < n ? (order ? (int)(order[q] & 0xFFFFFFull) : q) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+            if (pidx[u] >= 0) {
+                pin[u][0] = frame[3 * pidx[u]];
+                pin[u][1] = frame[3 * pidx[u] + 1];
+                pin[u][2] = frame[3 * pidx[u] + 2];
+            }
+        Slot first[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            cnt[u] = 0;
+            pend[u] = false;
+            first[u].key = kKeyEmpty;
+            first[u].count = 0;
+            if (pidx[u] >= 0) {
+                double sp[3];
+                se3_act(guess, pin[u], sp);
+                const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
+                if (voxel_in_range(vx, vy, vz)) {
+                    key[u] = pack_voxel(vx, vy, vz);
+                    sidx[u] = hash_key(key[u], m.mask);
+                    pend[u] = true;
+                    first[u] = load_slot(m.slots + sidx[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (pend[u]) {
+                if (first[u].key == key[u]) {
+                    cnt[u] = first[u].count;
+                } else if (first[u].key != kKeyEmpty) {  // the rare longer chain: walk it
+                    uint32_t si = (sidx[u] + 1) & m.mask;
+                    for (uint32_t probes = 1; probes <= m.mask; ++probes) {
+                        const Slot sl = load_slot(m.slots + si);
+                        if (sl.key == key[u]) {
+                            cnt[u] = sl.count;
+                            break;
+                        }
+                        if (sl.key == kKeyEmpty) break;
+                        si = (si + 1) & m.mask;
+                    }
+                }
+            }
+            const int q = q0 + 1024 * u;
+            if (q < n) {
+                if (in_lds) lds_w[q] = (unsigned short)(weight_base + cnt[u]);
+                else prefix[q] = weight_base + cnt[u];
+            }
+        }
+    }
     __threadfence_block();
     __syncthreads();
-    // pass 2: thread t owns the contiguous slice [t E, (t + 1) E)
+    // pass 2: thread t owns the contiguous slice [t E, (t + 1) E).  Up to kLdsWeights points (any full-size-voxel
+    // scan) the weights never leave the workgroup: re-reading them from L2 point by point was most of this launch.
     const int E = (n + 1023) / 1024;
     const int a = min(n, t * E), b = min(n, a + E);
     int sum = 0;
-    for (int q = a; q < b; ++q) sum += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (in_lds) {
+        for (int q = a; q < b; ++q) sum += (int)lds_w[q];
+    } else {
+        for (int q = a; q < b; ++q) sum += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // exclusive scan of the 1024 slice sums
     int incl = sum;
 #pragma unroll
@@ -109,9 +160,16 @@ __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long 
 #pragma unroll
     for (int w = 0; w < 16; ++w) base += (w < (t >> 6)) ? wave_sum[w] : 0;
     int run = base + incl - sum;
-    for (int q = a; q < b; ++q) {
-        run += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prefix[q] = run;
+    if (in_lds) {
+        for (int q = a; q < b; ++q) {
+            run += (int)lds_w[q];
+            prefix[q] = run;
+        }
+    } else {
+        for (int q = a; q < b; ++q) {
+            run += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prefix[q] = run;
+        }
     }
 }
 

@@ -84,6 +84,7 @@ struct StubPipe {
     void close() { closed = true; }
     bool closed = false;
     const char *last_error() const { return err.c_str(); }
+    const char *thread_error() const { return ""; }
 };
 
 // all ranks of all "processes" meet here: a counting barrier + a shared table of send pointers
