@@ -156,6 +156,11 @@ def main():
     icp = pipe.icp_timing()
     stats = pipe.last_stats()
 
+    if dist is not None:  # every rank leaves the process group together, before rank 0 goes on to report
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 -- a teardown problem must not cost the measurement
+            pass
     if rank != 0:
         return
 

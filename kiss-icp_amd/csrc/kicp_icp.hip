@@ -432,8 +432,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         __syncthreads();
         const unsigned epoch = epoch_base + (unsigned)it + 1u;
         unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpSums);
-        if (tid < 2 * kIcpSums) {
-            const int k = tid >> 1;
+        const __amdgpu_buffer_rsrc_t gran_rsrc = granule_rsrc(gran, (unsigned)(G * 2 * kIcpSums * sizeof(unsigned long long)));
+        if (tid < kIcpSums) {
+            const int k = tid;
             double v = 0.0;
 #pragma unroll
             for (int g = 0; g < kIcpGroupsPerBlock; ++g) {
@@ -441,8 +442,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
             }
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-            granule_store(gran + (size_t)blockIdx.x * (2 * kIcpSums) + tid, epoch, half);
+            granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + k) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
         }
         // ---- exchange: workgroup 0 gathers every partial, solves, and broadcasts the update --------------
         // (Every workgroup gathering every partial -- G x G x 304 bytes of agent-scope loads per iteration --
@@ -465,14 +465,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 bool fail = false;
                 for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
                     unsigned long long lo[kGatherChunk], hi[kGatherChunk];
-                    const unsigned long long *g0 = gran + ((size_t)b * kIcpSums + k) * 2;
+                    const unsigned g0 = (unsigned)(((size_t)b * kIcpSums + k) * 16);  // byte offset of {lo, hi} of scalar k of workgroup b
                     unsigned pending = 0;
     #pragma unroll
                     for (int u = 0; u < kGatherChunk; ++u) {
                         lo[u] = hi[u] = 0ull;
                         if (b + u < b1) {
-                            lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
-                            hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
+                            granule_load_pair(gran_rsrc, g0 + (unsigned)u * (16 * kIcpSums), lo[u], hi[u]);
                             pending |= 1u << u;
                         }
                     }
@@ -491,10 +490,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         __builtin_amdgcn_s_sleep(1);
     #pragma unroll
                         for (int u = 0; u < kGatherChunk; ++u)
-                            if ((pending >> u) & 1u) {
-                                lo[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums));
-                                hi[u] = granule_load(g0 + (size_t)u * (2 * kIcpSums) + 1);
-                            }
+                            if ((pending >> u) & 1u) granule_load_pair(gran_rsrc, g0 + (unsigned)u * (16 * kIcpSums), lo[u], hi[u]);
     #pragma unroll
                         for (int u = 0; u < kGatherChunk; ++u)
                             if (((pending >> u) & 1u) && (unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch)

@@ -21,6 +21,30 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Two adjacent granules (the two halves of one double) moved by ONE 16-byte access: half as many entries in the
+// memory queue of the gathering CU (where the price of a hand-off sits) and half as many fabric writes on the
+// publishing side.  Each 8-byte half still validates itself by its own tag, so nothing depends on the 16 bytes
+// travelling together.  Buffer instructions because the builtin takes the cache policy (16 = sc1) and the compiler
+// keeps track of the outstanding loads, which it cannot do for inline assembly.
+typedef int kicp_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(const unsigned long long *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void granule_load_pair(__amdgpu_buffer_rsrc_t r, unsigned byte_offset, unsigned long long &a,
+                                                  unsigned long long &b) {
+    const kicp_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 16);
+    a = (unsigned long long)(unsigned)v.x | ((unsigned long long)(unsigned)v.y << 32);
+    b = (unsigned long long)(unsigned)v.z | ((unsigned long long)(unsigned)v.w << 32);
+}
+__device__ __forceinline__ void granule_store_pair(__amdgpu_buffer_rsrc_t r, unsigned byte_offset, unsigned tag, unsigned lo, unsigned hi) {
+    kicp_v4i v;
+    v.x = (int)lo;
+    v.y = (int)tag;
+    v.z = (int)hi;
+    v.w = (int)tag;
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_offset, 0, 16);
+}
+
 __device__ __forceinline__ int count_of(const int *n_ptr, int n_imm) { return n_ptr ? *n_ptr : n_imm; }
 
 // ------------------------------------------------------------------------------------------
