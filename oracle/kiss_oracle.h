@@ -17,7 +17,10 @@
  *    zero-pivot rule, Sophus' SE3 exp / log / product branches): those libraries are absent, the
  *    stand-in headers forward these operations to the restatement in this file, which is
  *    written from the published algorithms of the pinned versions and checked against
- *    scipy/numpy in tests/test_oracle.py.
+ *    scipy/numpy in tests/test_oracle.py.  Likewise unpinned: tsl::robin_map's iteration order
+ *    (bucket order upstream, insertion order here and in the stand-in), which orders
+ *    VoxelDownsample's output and so decides which points AddPoints' order-dependent rule keeps
+ *    in a contested voxel.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library.  The product (kiss-icp_amd/) never links, imports or calls it.

@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include "kicp.h"
 #include "kiss_icp/pipeline/KissICP.hpp"
 #include "kiss_oracle.h"
 
@@ -189,6 +190,55 @@ int main() {
         const size_t n =
             ko_preprocess(reinterpret_cast<const double *>(f.data()), f.size(), nullptr, 0, I, 20.0, 1.0, 0, 1, ref.data());
         CHECK(pre.Preprocess(f, {}, Sophus::SE3d()).size() == n);
+    }
+    // ---- multi-stream batch entry of the C-ABI from C++ (no Python, no torch): one stream on GPU 0, poses exchanged by
+    // RCCL called directly by the library; frames queued four deep, poses against the oracle's --------------------------
+    {
+        kicp_config kc;
+        kicp_config_default(&kc);
+        kc.deskew = 0;
+        const int devices[1] = {0};
+        kicp_batch *b = nullptr;
+        const int rc = kicp_batch_create(&kc, devices, 1, 0, 1, nullptr, nullptr, 4, &b);
+        if (rc != KICP_OK) std::printf("kicp_batch_create: %s\n", kicp_last_error());
+        CHECK(rc == KICP_OK);
+        if (rc == KICP_OK) {
+            ko_config oc;
+            ko_config_default(&oc);
+            oc.deskew = 0;
+            ko_pipeline *op = ko_pipeline_create(&oc);
+            std::vector<double> want;
+            double worst = 0;
+            size_t got = 0;
+            for (int k = 0; k < 10; ++k) {
+                const Sophus::SE3d inv = pose_of(0.8 * k, 0.05 * k, 0.01 * k).inverse();
+                Points frame;
+                Points sample = scene(6000);
+                for (auto &p : sample) frame.push_back(inv * p);
+                const double *xyz[1] = {reinterpret_cast<const double *>(frame.data())};
+                const size_t n[1] = {frame.size()};
+                CHECK(kicp_batch_register_frames(b, xyz, n, nullptr, nullptr) == KICP_OK);  // frame may be freed now
+                ko_pipeline_register_frame(op, xyz[0], n[0], nullptr, 0);
+                double To[16];
+                ko_pipeline_pose(op, To);
+                want.insert(want.end(), To, To + 16);
+                if (k % 5 == 4) {  // five frames per sync: two blocks of four
+                    CHECK(kicp_batch_sync(b) == KICP_OK);
+                    std::vector<double> T(16 * 5);
+                    size_t nf = 0;
+                    CHECK(kicp_batch_poses(b, 0, T.data(), 5, &nf) == KICP_OK && nf == 5);
+                    for (size_t i = 0; i < nf; ++i) worst = std::fmax(worst, pose_diff(T.data() + 16 * i, want.data() + 16 * (got + i)));
+                    got += nf;
+                }
+            }
+            double sec = 0;
+            CHECK(kicp_batch_gather_seconds(b, &sec) == KICP_OK && sec > 0.0);
+            std::printf("batch entry: worst |T_gpu - T_oracle| over %zu frames = %.3e, last pose exchange %.1f us\n", got, worst, 1e6 * sec);
+            CHECK(got == 10 && worst < 1e-7);
+            kicp_pipeline *pp = nullptr;
+            CHECK(kicp_batch_pipeline(b, 0, &pp) == KICP_OK && pp != nullptr);
+            CHECK(kicp_batch_destroy(b) == KICP_OK);
+        }
     }
     ko_map_destroy(omap);
     std::printf(g_fail ? "test_cpp_api: %d FAILED\n" : "test_cpp_api: all checks passed\n", g_fail);
