@@ -794,7 +794,8 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
             return KICP_ERR_HIP;
         }
         KICP_TRY(r->run_prefix.reserve(n * sizeof(int)));
-        const int we = launch_tile_weights(r->sort_out.as<unsigned long long>(), r->frame.as<double>(), nullptr, (int)n, n, map->view(), st, 0, (int)options().icp_weight_base,
+        const int we = launch_tile_weights(r->sort_out.as<unsigned long long>(), r->frame.as<double>(), nullptr, (int)n, n, map->view(), st, 0, (int)options().icp_weight_base, (int)options().icp_weight_quad,
+                                           kIcpListRunMax * icp_max_blocks(r->device, (int)kIcpLdsBytesMax),
                                            r->run_prefix.as<int>(), r->stream);
         if (we != 0) {
             set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
@@ -1340,7 +1341,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     if (sorted && n) {
         // weights of the sorted points under this frame's initial guess (which the previous frame's registration
         // has just left in the device state), and their prefix: runs of equal weight
-        const int we = launch_tile_weights(I.order, p->src[par].as<double>(), &prep->n_src, 0, n, m->view(), st, 1, (int)options().icp_weight_base, p->run_prefix.as<int>(), s);
+        const int we = launch_tile_weights(I.order, p->src[par].as<double>(), &prep->n_src, 0, n, m->view(), st, 1, (int)options().icp_weight_base, (int)options().icp_weight_quad, kIcpListRunMax * G, p->run_prefix.as<int>(), s);
         if (we != 0) {
             set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
             return KICP_ERR_HIP;
@@ -2057,6 +2058,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (the prefix sums are 32-bit)
         options().icp_weight_base = value;
+    } else if (!strcmp(name, "icp_weight_quad")) {
+        if (value < -1 || value > 4096) return KICP_ERR_INVALID_ARG;
+        options().icp_weight_quad = value;
     } else if (!strcmp(name, "icp_inject_timeout")) {
         if (value < 0) return KICP_ERR_INVALID_ARG;
         options().icp_inject_timeout = value;

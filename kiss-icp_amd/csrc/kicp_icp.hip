@@ -58,7 +58,8 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     unsigned long long ncorr_last, ncorr_total, examined_total;
     double pad2;
     int fail;
-    int tile_points;  // points handed out from the tile's store
+    int tile_points;  // points asked of the tile's store (the demand; what does not fit stays in the map)
+    int tile_stored;  // end of the points kept in the store
     int next_point;   // phase B: next unserved point of the chunk
     int origin[3];    // voxel with relative tile coordinates (0, 0, 0)
     int any_fill;     // phase A: some query of the chunk is outside its known window
@@ -69,7 +70,8 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
-static_assert(sizeof(IcpShared) % 16 == 0, "the query records behind it must stay 16-byte aligned");
+static_assert(sizeof(IcpShared) % 16 == 0 && offsetof(IcpShared, pts) % 16 == 0 && sizeof(IcpPoint) % 16 == 0,
+              "the query records behind the point slots must stay 16-byte aligned");
 
 // low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
 __device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
@@ -80,7 +82,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
     // shift its base off 8/16-byte alignment)
     IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
-    IcpQueryMeta *metas = reinterpret_cast<IcpQueryMeta *>(smem + sizeof(IcpShared));
 
     const int tid = threadIdx.x;
     const int lane = tid & (kIcpGroup - 1);
@@ -145,20 +146,29 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     }
     const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, kIcpMaxMeta) : 0;
     const bool use_lists = n_meta > 0 && n_local <= kIcpListRunMax;
+    // LDS behind the fixed part: only as many point slots of a chunk as the run can fill (a run of 16 points leaves
+    // 9 KiB of the 128 to the tile), then the query records, the table, and the region of points and lists
+    const size_t head_bytes = offsetof(IcpShared, pts) + (size_t)min(kIcpChunk, max(n_local, 1)) * sizeof(IcpPoint);
+    IcpQueryMeta *metas = reinterpret_cast<IcpQueryMeta *>(smem + head_bytes);
     Tile tile;
     {
-        char *q = smem + sizeof(IcpShared) + (size_t)n_meta * sizeof(IcpQueryMeta);
+        char *q = smem + head_bytes + (size_t)n_meta * sizeof(IcpQueryMeta);
+        const int slots = n_local <= kIcpListRunMax ? kIcpTileSlots / 2 : kIcpTileSlots;
+        tile.slots_mask = slots - 1;
+        tile.hash_shift = slots == kIcpTileSlots ? 20 : 21;
+        tile.load_limit = (slots * 3) / 4;
         tile.keys = reinterpret_cast<unsigned *>(q);
-        tile.vals = tile.keys + kIcpTileSlots;
-        q += (size_t)2 * kIcpTileSlots * sizeof(unsigned);
-        tile.lists = use_lists ? reinterpret_cast<unsigned short *>(q) : nullptr;
-        tile.list_cap = use_lists ? kIcpListPool : 0;
-        tile.list_count = &sh.list_entries;
-        if (use_lists) q += (size_t)kIcpListPool * sizeof(unsigned short);
+        tile.vals = tile.keys + slots;
+        q += (size_t)2 * slots * sizeof(unsigned);
         tile.points = reinterpret_cast<double *>(q);
         const long room = (long)P.lds_bytes - (long)(q - smem);
-        tile.cap_points = n_meta > 0 && room > 0 ? (int)min((long)0xFFFF, room / (long)(3 * sizeof(double))) : 0;
+        tile.region_bytes = n_meta > 0 && room > 0 ? (unsigned)min(room, (long)0xFFFF * 24) & ~15u : 0u;
+        tile.cap_points = (int)(tile.region_bytes / 24u);
+        tile.lists = use_lists ? reinterpret_cast<unsigned short *>(q) : nullptr;
+        tile.list_top = use_lists ? (int)(tile.region_bytes / 2u) : 0;
+        tile.list_count = &sh.list_entries;
         tile.count = &sh.tile_points;
+        tile.stored = &sh.tile_stored;
         tile.entries = &sh.tile_entries;
         tile.ox = tile.oy = tile.oz = 0;  // set once the first point's voxel is known
     }
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     if (tid == 0) {
         sh.fail = 0;
         sh.tile_points = 0;
+        sh.tile_stored = 0;
         sh.tile_entries = 0;
         sh.list_entries = 0;
         sh.any_fill = 0;
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         metas[i].list_n = metas[i].list_cap = 0;
     }
     if (n_meta > 0)
-        for (int i = tid; i < kIcpTileSlots; i += kIcpThreads) {
+        for (int i = tid; i <= tile.slots_mask; i += kIcpThreads) {
             tile.keys[i] = kTileEmpty;
             tile.vals[i] = 0u;
         }

@@ -243,6 +243,7 @@ struct Options {
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long icp_weight_base = 16;   // run boundaries: a source point weighs this + the population of its voxel
+    long icp_weight_quad = -1;   // the weight also carries population^2 / this; 0: never; -1: when runs are short (kicp_sort.hip)
     long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once
 };
 Options &options();

@@ -351,16 +351,25 @@ constexpr unsigned kTileOverflow = 0xFFFFFFFEu;  // block id beyond 24 bits: que
 constexpr int kTileSpan = 1024;                  // relative voxel coordinates 0 .. 1023 per axis
 
 struct Tile {
-    unsigned *keys;  // [kIcpTileSlots] relative voxel key (10 bits per axis) or kTileEmpty
-    unsigned *vals;  // [kIcpTileSlots]
-    double *points;  // xyz triples in LDS
-    int cap_points;
-    int *count;      // LDS points handed out so far
-    int *entries;    // occupied table slots
-    unsigned short *lists;  // pool of scan lists (small runs only), or nullptr
-    int list_cap;
-    int *list_count;
-    int ox, oy, oz;  // voxel with relative coordinates (0, 0, 0)
+    unsigned *keys;  // [slots] relative voxel key (10 bits per axis) or kTileEmpty
+    unsigned *vals;  // [slots]
+    int slots_mask;  // slots - 1 (2048 slots for runs of at most 64 points, else 4096)
+    int hash_shift;  // 32 - log2(slots)
+    int load_limit;  // entries beyond which the table counts as full (3/4)
+    // One LDS region holds the points (24 bytes each, handed out from the bottom) AND the scan lists (16-bit
+    // entries, handed out from the top): a workgroup whose neighbourhood is large uses all of it for points and
+    // searches lane-per-voxel, one whose neighbourhood is small has room for the lists that make its searches
+    // short.  Points are handed out in the fill phases, lists in the search phases, never at the same time.
+    double *points;          // start of the region
+    unsigned region_bytes;
+    int cap_points;          // region_bytes / 24 (what fits when no list is kept)
+    int *count;              // points asked for so far (the demand: keeps counting past what fits)
+    int *stored;             // end of the points actually kept
+    int *entries;            // occupied table slots
+    unsigned short *lists;   // == (unsigned short *)points, indexed from the top; nullptr: this workgroup keeps no lists
+    int list_top;            // region_bytes / 2
+    int *list_count;         // list entries handed out so far
+    int ox, oy, oz;          // voxel with relative coordinates (0, 0, 0)
 };
 __device__ __forceinline__ int tile_ref(unsigned val) { return (int)(val & 0xFFFFFFu); }
 __device__ __forceinline__ int tile_cnt(unsigned val) { return (int)((val >> 24) & 63u); }
@@ -369,18 +378,18 @@ __device__ __forceinline__ bool tile_rel(const Tile &t, int qx, int qy, int qz, 
     key = (rx << 20) | (ry << 10) | rz;
     return rx < (unsigned)kTileSpan && ry < (unsigned)kTileSpan && rz < (unsigned)kTileSpan;
 }
-__device__ __forceinline__ unsigned tile_hash(unsigned key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
-static_assert(kIcpTileSlots == 4096, "tile_hash returns 12 bits");
+__device__ __forceinline__ unsigned tile_hash(const Tile &t, unsigned key) { return (key * 0x9E3779B1u) >> t.hash_shift; }
+static_assert(kIcpTileSlots == 4096, "hash_shift is derived from 4096 / 2048 slots");
 // slot of a key or -1 (LDS loads; other waves may be inserting: relaxed workgroup-scope atomics keep the
 // compiler from caching them)
 constexpr int kTileMaxProbes = 32;  // the table is kept at most 3/4 full; a chain this long means "not here"
 __device__ __forceinline__ int tile_find(const Tile &t, unsigned key) {
-    unsigned s = tile_hash(key);
+    unsigned s = tile_hash(t, key);
     for (int probes = 0; probes < kTileMaxProbes; ++probes) {
         const unsigned k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k == key) return (int)s;
         if (k == kTileEmpty) return -1;
-        s = (s + 1) & (kIcpTileSlots - 1);
+        s = (s + 1) & (unsigned)t.slots_mask;
     }
     return -1;
 }
@@ -507,10 +516,10 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
         slot[h] = -1;
         off[h] = 0;
         if (need[h] && blk[h] >= 0 && cnt[h] > 0) {
-            unsigned sidx = tile_hash(rkey[h]);
+            unsigned sidx = tile_hash(tile, rkey[h]);
             bool placed = false;
             // (a chain longer than tile_find follows, or a table more than 3/4 full, counts as "table full")
-            const bool room = __hip_atomic_load(tile.entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (kIcpTileSlots * 3) / 4;
+            const bool room = __hip_atomic_load(tile.entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tile.load_limit;
             for (int probes = 0; room && probes < kTileMaxProbes; ++probes) {
                 const unsigned old = atomicCAS(&tile.keys[sidx], kTileEmpty, rkey[h]);
                 if (old == kTileEmpty) {
@@ -524,12 +533,16 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
                     placed = true;  // somebody else is bringing it in
                     break;
                 }
-                sidx = (sidx + 1) & (kIcpTileSlots - 1);
+                sidx = (sidx + 1) & (unsigned)tile.slots_mask;
             }
             if (!placed) fail = true;  // table full
             if (won[h]) {
                 off[h] = atomicAdd(tile.count, cnt[h]);
-                if (off[h] + cnt[h] > tile.cap_points) {
+                // (no list is handed out during a fill phase: the list counter stands still)
+                const unsigned lists_bytes = tile.lists ? 2u * (unsigned)__hip_atomic_load(tile.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                const bool fits = (unsigned)(off[h] + cnt[h]) * 24u + min(lists_bytes, tile.region_bytes) <= tile.region_bytes && off[h] + cnt[h] <= 0xFFFF;
+                if (fits) atomicMax(tile.stored, off[h] + cnt[h]);
+                if (!fits) {
                     // LDS store full: the table remembers where the voxel is in the map instead (the lookup is
                     // saved, the points are read from HBM / L2 at every search)
                     const unsigned val = (unsigned)blk[h] < 0x1000000u ? ((unsigned)blk[h] | ((unsigned)cnt[h] << 24) | kTileGlobal | kTileReady)
@@ -768,8 +781,12 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
         int nb = -1;
         const int want = total + 16;
         if (lane == 0) {
-            nb = atomicAdd(tile.list_count, want);
-            if (nb + want > tile.list_cap) nb = -1;
+            // from the top of the region down, as long as the list stays clear of the points kept below (no point
+            // is handed out during a search phase)
+            const int used = atomicAdd(tile.list_count, want);
+            const int start = tile.list_top - used - want;
+            const int stored = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nb = (start >= 0 && (long)start * 2 >= (long)stored * 24) ? start : -1;
         }
         nb = __shfl(nb, 0, 32);
         if (nb < 0) {

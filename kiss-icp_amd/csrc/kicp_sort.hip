@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_tile_keys(const double *xyz, const int 
 // thousand points, at most ~10^5: a multi-kernel device scan would cost more in launches -- on the serial chain
 // of the frame, right in front of the registration -- than the work itself)
 __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
-                                                            MapView m, const PipeState *state, int pipeline_mode, int weight_base, int *prefix) {
+                                                            MapView m, const PipeState *state, int pipeline_mode, int weight_base, int weight_quad_in, int small_limit,
+                                                            int *prefix) {
     __shared__ int wave_sum[16];
     constexpr int kLdsWeights = 24576;
     __shared__ unsigned short lds_w[kLdsWeights];  // (a weight is at most base + 255)
@@ -66,6 +67,12 @@ __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long 
     const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
     const int t = threadIdx.x;
     const bool in_lds = n <= kLdsWeights && weight_base <= 1024;
+    // The quadratic term (weight_quad_in < 0: automatic) is for clouds of at most small_limit points, i.e. runs of
+    // a few dozen points with full-size voxels: there a workgroup's time is its tile's overflow and the number of
+    // 16-point rounds, and dense runs must be SHORT (measured: 17.3 vs 19.8 us per iteration on the KITTI-like
+    // scene with c^2 / 10); with hundreds of points per run the per-point work dominates and the term only
+    // starves the sparse runs (1M-point configuration: 136 -> 153 us with c^2 / 16).  profiles/r02_ak, r02_al.
+    const int weight_quad = weight_quad_in >= 0 ? weight_quad_in : (n <= small_limit ? 10 : 0);
     // pass 1 (coalesced): the weights themselves.  This launch sits on the serial chain of a frame, right in front
     // of the registration, and a thread's lookups are chains of dependent loads (sort key -> point -> map slot):
     // kBatch of them are kept in flight per thread, stage by stage, instead of one after the other.  (What is left
@@ -130,8 +137,11 @@ __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long 
             }
             const int q = q0 + 1024 * u;
             if (q < n) {
-                if (in_lds) lds_w[q] = (unsigned short)(weight_base + cnt[u]);
-                else prefix[q] = weight_base + cnt[u];
+                // base + c + c^2 / quad: the points a run's tile must hold grow faster than linearly with the
+                // population c of the voxels around it (full voxels have full neighbours)
+                const int w = weight_base + cnt[u] + (weight_quad > 0 ? (cnt[u] * cnt[u]) / weight_quad : 0);
+                if (in_lds) lds_w[q] = (unsigned short)min(w, 0xFFFF);
+                else prefix[q] = w;
             }
         }
     }
@@ -174,9 +184,10 @@ __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long 
 }
 
 int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
-                        const PipeState *state, int pipeline_mode, int weight_base, int *prefix, hipStream_t s) {
+                        const PipeState *state, int pipeline_mode, int weight_base, int weight_quad, int small_limit, int *prefix,
+                        hipStream_t s) {
     if (n_max == 0) return 0;
-    hipLaunchKernelGGL(k_tile_weights_scan, dim3(1), dim3(1024), 0, s, order, frame, n_ptr, n_imm, m, state, pipeline_mode, weight_base, prefix);
+    hipLaunchKernelGGL(k_tile_weights_scan, dim3(1), dim3(1024), 0, s, order, frame, n_ptr, n_imm, m, state, pipeline_mode, weight_base, weight_quad, small_limit, prefix);
     return (int)hipGetLastError();
 }
 

@@ -9,10 +9,11 @@ from kiss_icp_amd.kiss_icp import KissICP
 opts = dict(a.split('=') for a in sys.argv[1:])
 street = opts.pop('street', '0') == '1'  # street=1: round 1's bare street scene
 livox = opts.pop('livox', '0') == '1'    # livox=1: the 1M-point / 0.1 m configuration
+frames = int(opts.pop('frames', '0'))    # frames=N: drive N frames first (default 30 / 20 / 14)
 opts.setdefault('icp_profile', '1')
 for k, v in opts.items():
     _cabi.set_option(k, int(v))
-nf = 14 if street else (20 if livox else 30)
+nf = frames or (14 if street else (20 if livox else 30))
 scans = generate_scans(livox_like if livox else (kitti_like if street else kitti_like_vegetated), dict(seed=2 if livox else 0, n_frames=nf), range(nf))
 k = KissICP(load_config(deskew=False, voxel_size=0.1) if livox else load_config(deskew=False))
 for i in range(nf):
