@@ -68,7 +68,7 @@ def workload(name):
 def pmc_traffic(name):
     """HBM bytes per k_icp launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
     passes over this same command, corrected as calibrated on a known-size copy; scripts/pmc_to_json.py
-    writes the file, scripts/gpu_final.sh collects the counters).  Counters cannot be collected inside the
+    writes the file, scripts/gpu_call.sh (WHAT=pmc) collects the counters).  Counters cannot be collected inside the
     timed run, so this is the committed measurement of a SEPARATE profiled run -- or None."""
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

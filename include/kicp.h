@@ -329,6 +329,10 @@ int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t 
  *                     WEIGHT, a point weighing this + the population of its voxel (default 16: on the 1M-point /
  *                     0.1 m configuration 135 us per iteration against 175 at 4 and 146 at 64, flat on the
  *                     KITTI-like one: profiles/r02_w_sweep.txt, r02_ab_sweep_weights.txt)
+ *   "icp_weight_quad" the weight also carries population^2 / this.  0: never; -1 (default): / 10 when the source
+ *                     cloud has at most 64 points per workgroup -- short runs, where a workgroup's time is
+ *                     whether its tile fits in LDS (17.3 vs 19.8 us per iteration on the KITTI-like scene) --
+ *                     and never with longer runs (1M-point configuration: worse with it)
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
