@@ -64,6 +64,7 @@ __global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long 
     constexpr int kLdsWeights = 24576;
     __shared__ unsigned short lds_w[kLdsWeights];  // (a weight is at most base + 255)
     const int n = n_ptr ? *n_ptr : n_imm;
+    if (n < kIcpWeightedMin) return;  // k_icp cuts runs of equal LENGTH below this and never reads the prefix
     const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
     const int t = threadIdx.x;
     const bool in_lds = n <= kLdsWeights && weight_base <= 1024;
