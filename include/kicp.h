@@ -319,6 +319,11 @@ int kicp_device_synchronize(int device_id);
  * compared with the oracle's on the same inputs -- pivot order, zero-pivot rule and all -- without a registration
  * around it (tests/test_gpu_paths.py). */
 int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t n, double *x);
+/* Host self-test (no device needed): the float64 -> float32 narrowing the host-input entries apply to a scan before
+ * its upload (option "staging_f32").  dst receives the narrowed values; *exact = 1 iff every value survives the
+ * round trip, which is the only case in which a scan travels as float32 (one NaN, one value with more than 24
+ * significant bits, one value outside float32's range: the scan goes up as float64). */
+int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact);
 
 /* ------------------------------------------------------------------------------------------
  * tuning knobs (process-wide; read when a handle is created).  Unknown names are an error.

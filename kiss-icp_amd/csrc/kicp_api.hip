@@ -2011,6 +2011,15 @@ int kicp_device_synchronize(int device_id) {
     KICP_HIP(hipDeviceSynchronize());
     return KICP_OK;
 }
+// Host self-test: the staging path's float64 -> float32 narrowing (AVX2 or scalar, as the staging threads run it).
+// *exact = 1 iff every value survives the round trip -- the only case in which a scan is uploaded as float32.
+int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact) {
+    if ((!src || !dst) && count) return KICP_ERR_INVALID_ARG;
+    if (!exact) return KICP_ERR_INVALID_ARG;
+    *exact = narrow_exact(src, dst, count) ? 1 : 0;
+    return KICP_OK;
+}
+
 int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t n, double *x) {
     if ((!A || !b || !x) && n) return KICP_ERR_INVALID_ARG;
     KICP_TRY(check_device(device_id));

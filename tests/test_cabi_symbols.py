@@ -125,3 +125,39 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"kiss_oracle|from oracle|import oracle|ko_[a-z]+_", text):
                     offenders.append(os.path.join(d, f))
     assert not offenders, offenders
+
+
+def test_staging_narrowing_is_lossless_or_refused():
+    """kicp_selftest_narrow = the float64 -> float32 narrowing of the host-input staging path (AVX2 main loop of 8 +
+    scalar tail): float32-born values come back bit for bit and are declared exact; a single value that float32
+    cannot hold -- at any position of the vector loop or the tail -- makes the whole block inexact (the scan is
+    then uploaded as float64); -0.0 and infinities are exact, NaN is not (NaN != NaN: never narrowed)."""
+    import ctypes as C
+
+    from kiss_icp_amd import _cabi
+
+    L = _cabi.lib()
+    rng = np.random.default_rng(5)
+
+    def narrow(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty(len(a), dtype=np.float32)
+        exact = C.c_int(-1)
+        assert L.kicp_selftest_narrow(a.ctypes.data_as(C.c_void_p), len(a), out.ctypes.data_as(C.c_void_p), C.byref(exact)) == 0
+        return out, exact.value
+
+    for n in (0, 1, 7, 8, 9, 64, 1003):
+        born32 = (rng.normal(0, 50, n).astype(np.float32)).astype(np.float64)
+        out, exact = narrow(born32)
+        assert exact == 1 and np.array_equal(out.astype(np.float64), born32) and np.array_equal(out, born32.astype(np.float32))
+        for pos in range(n):
+            if n > 64 and pos % 97:
+                continue
+            bad = born32.copy()
+            bad[pos] = bad[pos] + 1e-9 if bad[pos] != 0 else 1e-50  # more than 24 significant bits / below float32's range
+            assert narrow(bad)[1] == 0, (n, pos)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 1.0, 3.4028234663852886e38, 1.401298464324817e-45, 2.0 ** -126])
+    out, exact = narrow(special)
+    assert exact == 1 and np.array_equal(np.signbit(out), np.signbit(special)) and np.array_equal(out.astype(np.float64), special)
+    for v in (np.nan, 1e39, -1e39, 1e-46, 0.1, 16777217.0):
+        assert narrow(np.array([1.0, v, 2.0]))[1] == 0, v
