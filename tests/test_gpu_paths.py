@@ -518,3 +518,29 @@ def test_batch_entry_two_streams_host_communicator(gpu, O):
     assert np.array_equal(traj[0][-1], want[0])
     assert sorted(calls) == [0, 0, 1, 1]
     b.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(voxel_size=0.5, max_points_per_voxel=40, max_range=60.0, min_range=5.0),
+    dict(voxel_size=2.0, max_points_per_voxel=5, max_range=40.0, min_range=0.0),
+    dict(voxel_size=1.0, max_points_per_voxel=20, max_range=100.0, min_range=0.0, max_num_iterations=3, convergence_criterion=1e-12),
+    dict(voxel_size=1.0, max_points_per_voxel=20, max_range=100.0, min_range=0.0, initial_threshold=0.5, min_motion_th=0.01),
+])
+def test_pipeline_away_from_the_default_configuration(gpu, O, cfg):
+    """the configurations tests/test_ref_pins_oracle.py holds the oracle to the reference's own sources on: wide and
+    narrow voxels, range crops that bite, an iteration cap that bites, a tight adaptive threshold -- HIP pipeline
+    against the oracle, frame by frame"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=13, n_frames=10, beams=32, azimuth_steps=400)
+    k = _pipe(deskew=False, **cfg)
+    ko = O.KissICP(deskew=0, **cfg)
+    for i in range(10):
+        pts, ts = ds[i]
+        fg, sg = k.register_frame(pts, ts)
+        fo, so = ko.register_frame(pts, ts)
+        assert np.array_equal(fg, fo) and np.array_equal(sg, so), i
+        dt, dr = pose_error(ko.last_pose, k.last_pose)
+        assert dt < TIGHT and dr < TIGHT, (cfg, i, dt, dr)
+        assert k.last_stats()["icp"]["iterations"] == ko.last_stats()["iterations"], (cfg, i)
+    assert np.allclose(sort_rows(k.local_map.point_cloud()), sort_rows(ko.local_map.point_cloud()), rtol=0, atol=1e-9)
