@@ -65,6 +65,46 @@ def workload(name):
     return livox_like, {}, dict(deskew=False, voxel_size=0.1), "1M-pt 128x8192 rays, voxel 0.1 m"
 
 
+def launch_plan(gpus, world_env, device, n_devices):
+    """what `--gpus N` means for this process.  Returns (mode, devices, exchange):
+      ("rank", None, None)         started by torch.distributed.run (WORLD_SIZE in the environment, what the driver does
+                                   for N > 1): this process is ONE of N ranks, one stream on its own GPU;
+      ("single", [d], None)        N = 1;
+      ("in-process", devices, x)   N > 1 without a launcher: N streams driven from this process through the C-ABI's batch
+                                   entry (kicp_batch_*: one worker thread per stream inside libkicp.so), poses all-gathered by
+                                   RCCL called directly (x = "rccl") -- or, with --device d (every stream on the one GPU of a
+                                   1-GPU box: plumbing), through a host communicator (x = "host"), because RCCL refuses two
+                                   ranks on one device.
+    Fewer visible devices than streams without --device is an error, never a silent single-stream run."""
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world_env is not None:
+        if int(world_env) != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world_env}: the launcher and the flag disagree")
+        return "rank", None, None
+    if gpus == 1:
+        return "single", [device if device >= 0 else 0], None
+    if device >= 0:
+        return "in-process", [device] * gpus, "host"
+    if n_devices < gpus:
+        raise SystemExit(f"--gpus {gpus} needs {gpus} GPUs, {n_devices} visible (use --device D to stack the streams on one GPU "
+                         "for a plumbing run)")
+    return "in-process", list(range(gpus)), "rccl"
+
+
+def visible_devices():
+    """GPUs this box offers, asked in a child process: this one must not touch a HIP runtime before the scans exist
+    (the generator pool forks) nor before torch has loaded its own (libkicp binds to the one already in the process)"""
+    import subprocess
+
+    code = "import sys; sys.path.insert(0, %r); from kiss_icp_amd import _cabi; print(_cabi.device_count())" % os.path.join(ROOT, "kiss-icp_amd", "python")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
 def pmc_traffic(name):
     """HBM bytes per k_icp launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
     passes over this same command, corrected as calibrated on a known-size copy; scripts/pmc_to_json.py
@@ -103,9 +143,114 @@ def cpu_baseline(scans, warmup, steps, cfg):
     return best, detail
 
 
+def host_communicator(n_ranks, device):
+    """a kicp_batch_comm that moves the blocks through host memory with the C-ABI's own device copies: for N streams
+    stacked on ONE device (a plumbing run on a 1-GPU box), where RCCL cannot be used"""
+    import ctypes as C
+    import threading
+
+    from kiss_icp_amd import _cabi
+
+    L = _cabi.lib()
+    barrier = threading.Barrier(n_ranks)
+    blocks = [None] * n_ranks
+
+    def all_gather(ctx, rank, d_send, d_recv, nbytes, stream):
+        try:
+            if L.kicp_device_synchronize(device):
+                return 2
+            mine = (C.c_ubyte * nbytes)()
+            if L.kicp_device_download(device, mine, d_send, nbytes):
+                return 2
+            blocks[rank] = bytes(mine)
+            barrier.wait(timeout=120)
+            joined = b"".join(blocks)
+            if L.kicp_device_upload(device, d_recv, joined, len(joined)):
+                return 2
+            barrier.wait(timeout=120)
+            return 0
+        except Exception:  # noqa: BLE001 -- nothing may propagate into the C caller
+            return 2
+
+    return _cabi.BatchComm(None, _cabi.BatchComm.INIT(0), _cabi.BatchComm.ALL_GATHER(all_gather), _cabi.BatchComm.FINALIZE(0))
+
+
+def main_in_process(args, devices, exchange):
+    """N > 1 streams from ONE process: the C-ABI's batch entry (worker thread per stream inside the library, each bound to
+    its GPU), poses all-gathered once per batch by RCCL called directly.  No Python and no torch in the per-frame path
+    beyond handing the N host arrays of a round to kicp_batch_register_frames."""
+    import numpy as np
+
+    from kiss_icp_amd import multistream
+    from kiss_icp_amd.datasets import generate_scans
+
+    W, K, S = args.warmup, args.steps, len(devices)
+    factory, ds_kw, cfg_over, workload_name = workload(args.workload)
+    t_gen = time.perf_counter()
+    streams = []
+    for r in range(S):
+        sc = generate_scans(factory, dict(ds_kw, seed=multistream.stream_seed(args.seed, r), n_frames=W + K), range(W + K),
+                            processes=args.gen_procs or None)
+        streams.append([(np.ascontiguousarray(p, dtype=np.float64), np.ascontiguousarray(t, dtype=np.float64)) for p, t in sc])
+    t_gen = time.perf_counter() - t_gen
+
+    import torch  # first: libkicp must bind to the HIP runtime torch has already loaded
+
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.config import load_config
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    for kv in args.opt:
+        name, value = kv.split("=")
+        _cabi.set_option(name, int(value))
+    comm = host_communicator(S, devices[0]) if exchange == "host" else None
+    batch = multistream.StreamBatch(load_config(**cfg_over), devices, comm=comm)
+
+    def drive(lo, hi):
+        for f in range(lo, hi):
+            batch.register_frames([streams[r][f][0] for r in range(S)], [streams[r][f][1] for r in range(S)])
+        batch.sync()
+
+    def sync_devices():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    drive(0, W)  # untimed warm-up
+    sync_devices()
+    t0 = time.perf_counter()
+    drive(W, W + K)
+    sync_devices()
+    elapsed = time.perf_counter() - t0
+    poses = [batch.poses(r) for r in range(S)]
+    assert all(len(p) == K for p in poses), [len(p) for p in poses]
+    out = {
+        "metric": "RegisterFrame scans/s", "value": S * K / elapsed, "unit": "scans/s", "n_gpus": S, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": workload_name, "input": "host float64 arrays (pageable) -> kicp_batch_register_frames",
+            "streams": S, "parallelism": f"streams{S}", "devices": devices,
+            "launcher": "in-process: kicp_batch_* (one worker thread per stream inside libkicp.so)",
+            "exchange": "ncclAllGather called directly, once per batch" if exchange == "rccl"
+                        else "host communicator (streams stacked on one device: plumbing, not a scaling measurement)",
+            "frames_driven": W + K,
+        },
+        "rccl_ranks": S if exchange == "rccl" else 0,
+        "pose_gather_s": batch.gather_seconds(),
+        "scan_generation_s": t_gen,
+    }
+    batch.close()
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
     W, K = args.warmup, args.steps
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        mode, devices, exchange = launch_plan(args.gpus, None, args.device, visible_devices())
+        return main_in_process(args, devices, exchange)
+    launch_plan(args.gpus, os.environ.get("WORLD_SIZE"), args.device, 1 << 30)  # the launcher and the flag must agree
     rank = int(os.environ.get("RANK", "0"))
     factory, ds_kw, cfg_over, workload_name = workload(args.workload)
     # the synthetic scans first, by a pool of processes, before this process touches the GPU runtime
@@ -143,6 +288,7 @@ def main():
     pipe = KissICP(load_config(**cfg_over), device_id=local_rank)
     multistream.run_batch_host(pipe, host[:W], dist, comm_device)  # W untimed warm-up frames
     pipe.icp_timing(reset=True)
+    pipe.host_stats(reset=True)
 
     # ---- timed region: exactly K frames, barrier + synchronize on both sides -------------------
     multistream.barrier(dist)
@@ -155,6 +301,7 @@ def main():
     elapsed = multistream.max_over_ranks(elapsed, dist, comm_device)
     icp = pipe.icp_timing()
     stats = pipe.last_stats()
+    host_side = pipe.host_stats()
 
     if dist is not None:  # every rank leaves the process group together, before rank 0 goes on to report
         try:
@@ -191,6 +338,8 @@ def main():
             "icp_workgroups": pipe.icp_profile()["workgroups"],
         },
         "ms_per_icp_iter": icp["total_ms"] / max(1, icp["iterations"]),
+        # what the host side of the K timed calls did (kicp_pipeline_host_stats): waits must be zero in steady state
+        "host_side": host_side,
         "scan_generation_s": t_gen,
     }
     cyc, tk = pipe.icp_clock()

@@ -180,6 +180,21 @@ int kicp_pipeline_destroy(kicp_pipeline *p);
  * kicp_pipeline_sync(). */
 int kicp_pipeline_register_frame(kicp_pipeline *p, const double *xyz, size_t n,
                                  const double *timestamps, size_t n_timestamps);
+/* RegisterFrame exactly as the reference declares it: blocks AND returns both clouds (KissICP.cpp:67: the
+ * preprocessed frame and the source).  pre_out / src_out hold pre_cap / src_cap points (n points each is always
+ * enough); *n_pre / *n_src = points the clouds have.  The preprocessed frame is downloaded while the
+ * registration is still running, so this costs about what kicp_pipeline_register_frame costs. */
+int kicp_pipeline_register_frame_outputs(kicp_pipeline *p, const double *xyz, size_t n,
+                                         const double *timestamps, size_t n_timestamps,
+                                         double *pre_out, size_t pre_cap, size_t *n_pre,
+                                         double *src_out, size_t src_cap, size_t *n_src);
+/* ... for hosts that build their own containers from the result (std::vector's range constructor, a JNI array
+ * copy): the two clouds stay in pinned host memory OWNED BY THE PIPELINE and *pre_view / *src_view point into it,
+ * valid until the next call on this pipeline.  One copy fewer than the entry above. */
+int kicp_pipeline_register_frame_views(kicp_pipeline *p, const double *xyz, size_t n,
+                                       const double *timestamps, size_t n_timestamps,
+                                       const double **pre_view, size_t *n_pre,
+                                       const double **src_view, size_t *n_src);
 /* The same without waiting: the scan is copied into pinned staging memory (a few helper threads,
  * option "staging_threads"), so the caller's buffers are free again when the call returns; its upload and
  * the stages in front of the registration then run on a second stream UNDER the previous frame's
@@ -248,6 +263,32 @@ int kicp_pipeline_icp_iteration_profile(kicp_pipeline *p, uint32_t *out, int cap
  * out must hold n_iters * n_groups * 4 words (cap_words) */
 int kicp_pipeline_icp_group_profile(kicp_pipeline *p, uint32_t *out, size_t cap_words, int *n_iters,
                                     int *n_groups);
+/* Where the HOST side of the queued frames spent its time (since the last reset): the asynchronous entries are
+ * meant to return without ever waiting for the device; every wait they did take is counted here, so that a test
+ * (tests/test_gpu_paths.py) and bench.py can hold them to it.  KICP_HOST_TRACE=1 in the environment additionally
+ * prints one line per queued frame on stderr. */
+typedef struct kicp_host_stats {
+    uint64_t frames;            /* frames queued */
+    uint64_t backpressure_waits;/* waits because "queue_depth" frames were already queued on the device (the caller
+                                   is ahead of the device: benign, the device has work) */
+    uint64_t capacity_waits;    /* waits for a queued frame to finish so that the map's growth could be bounded */
+    uint64_t staging_waits;     /* waits for a pinned staging slot whose upload had not finished */
+    uint64_t ring_syncs;        /* full drains because the frame-record ring (256 frames in flight) was full */
+    uint64_t counter_refreshes; /* blocking read-backs of the map counters (a stream synchronisation each) */
+    uint64_t map_grows;         /* reallocations of the map's slot array or block pool */
+    uint64_t map_rehashes;      /* rebuilds of the slot array (growth or tombstone clean-up) */
+    uint64_t buffer_grows;      /* reallocations of the frame buffers (a scan larger than any before) */
+    double stage_ms;            /* host time copying scans into pinned memory */
+    double enqueue_ms;          /* host time queueing copies and kernels */
+    double backpressure_ms;     /* host time in back-pressure waits */
+    double wait_ms;             /* host time blocked in every OTHER wait counted above (these starve the device) */
+    double device_gap_ms;       /* device time between the end of a registration and the start of the next, summed over
+                                   the frames collected by kicp_pipeline_sync since the last reset (map update + front
+                                   of the next registration; a starved device shows up here) */
+    double max_device_gap_ms;   /* ... the largest single one */
+    double max_call_ms;         /* the longest single call of an asynchronous entry */
+} kicp_host_stats;
+int kicp_pipeline_host_stats(kicp_pipeline *p, kicp_host_stats *stats, int reset);
 /* the HIP stream (hipStream_t) the pipeline launches on, as an opaque pointer */
 int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
 
@@ -265,9 +306,12 @@ int kicp_pipeline_stream(kicp_pipeline *p, void **stream);
  * kicp_batch_unique_id() on one rank and distributed by the launcher's own means.
  *
  * The exchange: comm == NULL uses RCCL called directly (ncclCommInitRank / ncclAllGather from librccl,
- * resolved with dlopen) on a stream of its own; one fixed-size block of 16 + 128 * frames_per_gather bytes per
- * rank and gather (several gathers when a sync completed more frames; ranks in OTHER processes must then have
- * queued the same number of frames).  A host may supply its own communicator (MPI, a test stub) instead.
+ * resolved with dlopen) on a stream of its own; one fixed-size block of 32 + 128 * frames_per_gather bytes per
+ * rank and gather.  A block carries its rank's frame count and pipeline status, so several gathers follow when
+ * ANY rank completed more frames than a block holds (ranks need not queue the same number of frames), and a
+ * rank whose pipeline failed still takes part -- every process then returns that rank's status from
+ * kicp_batch_sync instead of waiting in the collective for ever.  A host may supply its own communicator (MPI,
+ * a test stub) instead.
  * ---------------------------------------------------------------------------------------- */
 #define KICP_BATCH_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
 typedef struct kicp_batch kicp_batch;
@@ -349,8 +393,14 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     co-resident maximum minus this)
  *   "staging_threads" helper threads (besides the caller) that copy a host scan into pinned memory (default 3)
  *   "staging_f32"     1 = narrow float64 host scans to float32 for the upload when lossless (default 1)
+ *   "staging_zero_copy"  1 (default) = no upload call: the two kernels that read the raw scan fetch it over PCIe from
+ *                     the pinned, device-mapped staging slot themselves; 0 = hipMemcpyAsync into HBM first
+ *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
+ *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
  *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if
  *                     their workgroups never became co-resident (exercises the replay path)
+ *   "icp_inject_timeout_skip"  ... after leaving its first M registrations alone
+ *   "map_rehash_every"  test hook: pipelines rebuild their map's slot array (in stream order, no host wait) every N frames
  *   "map_apply_threads"  workgroup size of the AddPoints apply kernel: 256, 512 (default) or 1024
  *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
  *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)

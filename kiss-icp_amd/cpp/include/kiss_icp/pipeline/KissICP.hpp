@@ -85,6 +85,7 @@ public:
 
 private:
     void PushPoseEdits();
+    void CollectState();
     Vector3dVectorTuple CollectFrame();
     Sophus::SE3d last_pose_;
     Sophus::SE3d last_delta_;
@@ -97,6 +98,7 @@ private:
     VoxelHashMap local_map_;  // view of the pipeline's device map
     int last_iterations_ = 0;
     double last_sigma_ = 0.0;
+    std::size_t last_n_pre_ = 0, last_n_src_ = 0;
 };
 
 }  // namespace kiss_icp::pipeline

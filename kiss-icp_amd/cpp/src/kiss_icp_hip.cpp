@@ -271,7 +271,7 @@ void KissICP::PushPoseEdits() {
     if (std::memcmp(T, dev_delta_, sizeof T) != 0) check(kicp_pipeline_set_delta(handle_, T), "KissICP::delta");
 }
 
-KissICP::Vector3dVectorTuple KissICP::CollectFrame() {
+void KissICP::CollectState() {
     check(kicp_pipeline_pose(handle_, dev_pose_), "KissICP::pose");
     check(kicp_pipeline_delta(handle_, dev_delta_), "KissICP::delta");
     last_pose_ = detail::se3_from_rowmajor(dev_pose_);
@@ -284,8 +284,13 @@ KissICP::Vector3dVectorTuple KissICP::CollectFrame() {
     check(kicp_pipeline_last_stats(handle_, &fs), "KissICP::RegisterFrame");
     last_iterations_ = fs.icp.iterations;
     last_sigma_ = fs.sigma;
+    last_n_pre_ = fs.n_preprocessed;
+    last_n_src_ = fs.n_source;
+}
 
-    Vector3dVector pre(fs.n_preprocessed), source(fs.n_source);
+KissICP::Vector3dVectorTuple KissICP::CollectFrame() {
+    CollectState();
+    Vector3dVector pre(last_n_pre_), source(last_n_src_);
     size_t n = 0;
     check(kicp_pipeline_output(handle_, KICP_OUT_PREPROCESSED, xyz(pre), pre.size(), &n), "KissICP::RegisterFrame");
     check(kicp_pipeline_output(handle_, KICP_OUT_SOURCE, xyz(source), source.size(), &n), "KissICP::RegisterFrame");
@@ -299,9 +304,17 @@ KissICP::Vector3dVectorTuple KissICP::RegisterFrame(const std::vector<Eigen::Vec
 
 KissICP::Vector3dVectorTuple KissICP::RegisterFrame(PointSpan frame, const double *timestamps, std::size_t n_timestamps) {
     PushPoseEdits();
-    check(kicp_pipeline_register_frame(handle_, frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps),
+    // both clouds arrive in pinned memory of the pipeline -- the preprocessed frame while the registration is still
+    // running -- and the two vectors the reference's signature returns are built from there in one pass each
+    const double *pre = nullptr, *src = nullptr;
+    size_t n_pre = 0, n_src = 0;
+    check(kicp_pipeline_register_frame_views(handle_, frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps, &pre,
+                                             &n_pre, &src, &n_src),
           "KissICP::RegisterFrame");
-    return CollectFrame();
+    CollectState();
+    const auto *p3 = reinterpret_cast<const Eigen::Vector3d *>(pre);
+    const auto *s3 = reinterpret_cast<const Eigen::Vector3d *>(src);
+    return {Vector3dVector(p3, p3 + n_pre), Vector3dVector(s3, s3 + n_src)};  // KissICP.cpp:67
 }
 
 KissICP::Vector3dVectorTuple KissICP::RegisterFrameDevice(const double *d_xyz, std::size_t n, const double *d_timestamps,

@@ -7,6 +7,7 @@
 #include <immintrin.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -31,6 +32,19 @@ const char *get_error() { return g_err; }
 Options &options() {
     static Options o;
     return o;
+}
+
+static inline double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+// KICP_HOST_TRACE=1: one line per queued frame on stderr (where the host side of a frame spent its time)
+static bool host_trace_on() {
+    static const bool on = [] {
+        const char *e = getenv("KICP_HOST_TRACE");
+        return e && *e && *e != '0';
+    }();
+    return on;
 }
 
 int DevBuf::reserve(size_t need, bool keep, hipStream_t s) {
@@ -232,9 +246,11 @@ private:
         unsigned long seen = 0;  // generation of the last job this helper worked on
         for (;;) {
             Job *j;
-            // at thousands of scans per second the next job is a fraction of a millisecond away: look for it for
-            // a while before going to sleep (waking a sleeping thread costs more than the copy it is woken for)
-            for (int spin = 0; spin < 20000 && gen_hint_.load(std::memory_order_acquire) == seen; ++spin) _mm_pause();
+            // a copy is often two jobs back to back (the narrowing attempt, then the timestamps): look for the next one
+            // briefly (~30 us) before going to sleep.  Not longer: the helpers of an idle pipeline must not burn cores
+            // (GPU boxes are shared, containers carry CPU quotas), and with "queue_depth" frames queued on the device
+            // the caller has a whole frame time for a copy that one core finishes in a third of it.
+            for (int spin = 0; spin < 1000 && gen_hint_.load(std::memory_order_acquire) == seen; ++spin) _mm_pause();
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return quit_ || (cur_ && gen_ != seen); });
@@ -312,9 +328,13 @@ MapView kicp_map::view() const {
 }
 
 int kicp_map::refresh_counters() {
+    const double t0 = now_ms();
     KICP_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
     KICP_HIP(hipStreamSynchronize(stream));
+    n_refresh++;
+    wait_ms += now_ms() - t0;
     used_ub = h_ctr[C_USED];
+    live_ub = h_ctr[C_LIVE];
     bump_ub = h_ctr[C_BUMP] < blocks_cap ? h_ctr[C_BUMP] : blocks_cap;
     return KICP_OK;
 }
@@ -358,6 +378,8 @@ int kicp_map::check_errors() {
 
 static int map_rehash(kicp_map *m, uint32_t new_cap) {
     // (re)build the slot array from the live blocks; drops tombstones
+    m->n_rehash++;
+    if (new_cap != m->slot_cap) m->n_grow++;
     if (new_cap != m->slot_cap) {
         DevBuf ns;
         KICP_TRY(ns.reserve((size_t)new_cap * sizeof(Slot)));
@@ -386,10 +408,10 @@ int kicp_map::ensure_capacity(size_t incoming) {
     if (capacity_ok(incoming)) return KICP_OK;
     KICP_TRY(refresh_counters());
     const size_t live = (size_t)h_ctr[C_LIVE], tomb = (size_t)h_ctr[C_TOMB];
-    // Growth targets leave room for kQueueSlack frames of upper-bound accounting: with frames queued
-    // back-to-back the host only learns the true counters a frame or two late, and every refresh
-    // above is a stream synchronisation.
-    constexpr size_t kQueueSlack = 4;
+    // Growth targets leave room for the frames that may be queued behind the newest one whose exact counters the
+    // host has seen ("queue_depth", plus the incoming one and one to spare): each of them is accounted with one
+    // new voxel per raw point until its record arrives, and growing is a stream synchronisation.
+    const size_t kQueueSlack = (size_t)(options().queue_depth > 0 ? options().queue_depth : 8) + 2;
     if (2 * ((size_t)used_ub + incoming) > slot_cap) {
         const size_t want = 2 * (live + kQueueSlack * incoming);
         uint32_t cap = slot_cap;
@@ -408,6 +430,7 @@ int kicp_map::ensure_capacity(size_t incoming) {
             return KICP_ERR_CAPACITY;
         }
         const size_t old_bytes = (size_t)blocks_cap * stride;
+        n_grow++;
         KICP_TRY(blocks.reserve(want * stride + 64, true, stream));
         KICP_HIP(hipMemsetAsync(blocks.as<char>() + old_bytes, 0, want * stride + 64 - old_bytes, stream));
         // the free-block ring is indexed modulo its capacity: re-linearise the live entries
@@ -447,7 +470,7 @@ static int map_alloc(kicp_map *m) {
     KICP_HIP(hipMemsetAsync(m->blocks.p, 0, m->blocks.bytes, m->stream));
     KICP_HIP(hipMemsetAsync(m->ctr.p, 0, m->ctr.bytes, m->stream));
     KICP_HIP(hipStreamSynchronize(m->stream));
-    m->used_ub = m->bump_ub = 0;
+    m->used_ub = m->bump_ub = m->live_ub = 0;
     return KICP_OK;
 }
 
@@ -528,7 +551,7 @@ int kicp_map_clear(kicp_map *m) {
     KICP_HIP(hipMemsetAsync(m->blocks.p, 0, (size_t)m->bump_ub * m->stride, m->stream));
     KICP_HIP(hipMemsetAsync(m->ctr.p, 0, sizeof(int) * C_COUNT, m->stream));
     KICP_HIP(hipStreamSynchronize(m->stream));
-    m->used_ub = m->bump_ub = 0;
+    m->used_ub = m->bump_ub = m->live_ub = 0;
     return KICP_OK;
 }
 
@@ -569,6 +592,7 @@ static int map_insert_device(kicp_map *m, const double *d_in, const int *n_ptr, 
     launch_map_apply(v, sc, (int)n_max, m->stream);
     KICP_HIP(hipGetLastError());
     m->used_ub += (long)n_max;
+    m->live_ub += (long)n_max;
     m->bump_ub += (long)n_max;
     if (m->bump_ub > m->blocks_cap) m->bump_ub = m->blocks_cap;
     return KICP_OK;
@@ -1070,6 +1094,7 @@ struct kicp_pipeline {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t prep_stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // early download of the preprocessed frame (kicp_pipeline_register_frame_outputs), created on first use
     hipEvent_t icp_done_event = nullptr;   // the event recorded behind the most recent ICP launch (or none)
     hipEvent_t ev_prep_done[2] = {nullptr, nullptr};  // recorded on `prep_stream`, by frame parity
     uint64_t frames_enqueued = 0;
@@ -1089,6 +1114,7 @@ struct kicp_pipeline {
     hipEvent_t ev[kRing][2];
     bool ev_ok = false;
     int in_flight = 0;
+    int done_upto = 0;    // frames [0, done_upto) of the ring are known to be complete (their successor's launch event fired)
     uint64_t frames_done = 0;
     FrameRecord last;  // most recent completed frame
     bool have_last = false;
@@ -1106,10 +1132,14 @@ struct kicp_pipeline {
     // registration replay (timeout): co-residency cap for the ICP grid, the last frame's inputs
     int icp_cap = 0;
     int inject_timeouts = 0;  // test hook ("icp_inject_timeout" option, read at create)
+    int inject_skip = 0;      // ... after this many untouched registrations ("icp_inject_timeout_skip")
     FrameInput last_in;
     // ICP timing accumulators
     double icp_ms = 0.0;
     uint64_t icp_launches = 0, icp_iters = 0, icp_bytes = 0;
+    kicp_host_stats hs = {};            // where the host side of the queued frames went (kicp_pipeline_host_stats)
+    uint64_t map_refresh0 = 0, map_grow0 = 0, map_rehash0 = 0;  // the map's counters at the last reset
+    double map_wait0 = 0.0;
     std::vector<double> pending_poses;  // row-major 4x4 per frame completed since the caller's last sync
     bool poses_stale = false;           // the caller has seen them: the next queued frame starts a new list
 };
@@ -1122,6 +1152,7 @@ static PipeState *pipe_state(kicp_pipeline *p) { return map_mini_state(p->map); 
 
 static int pipe_reserve(kicp_pipeline *p, size_t n) {
     if (p->cap_points && n <= p->cap_points) return KICP_OK;
+    if (p->cap_points) p->hs.buffer_grows++;
     if (p->in_flight) KICP_TRY(pipe_sync(p, false));
     KICP_HIP(hipStreamSynchronize(p->prep_stream));
     // never less than a minimum: an EMPTY first scan must still find its buffers (the front-stage
@@ -1194,16 +1225,55 @@ static void pipe_refresh_bounds(kicp_pipeline *p) {
     // ev[i + 1][0] sits in front of frame i+1's registration launch, i.e. behind frame i's last kernel
     long pending = p->in_flight > 0 ? (long)p->ring[p->in_flight - 1].n_raw : 0;
     for (int i = p->in_flight - 2; i >= 0; --i) {
-        if (hipEventQuery(p->ev[i + 1][0]) == hipSuccess) {
+        if (i + 1 <= p->done_upto || hipEventQuery(p->ev[i + 1][0]) == hipSuccess) {
+            if (i + 1 > p->done_upto) p->done_upto = i + 1;
             const FrameRecord &r = p->ring[i];
-            const long used = (long)r.map_ctr[C_USED] + pending, bump = (long)r.map_ctr[C_BUMP] + pending;
+            const long used = (long)r.map_ctr[C_USED] + pending, bump = (long)r.map_ctr[C_BUMP] + pending,
+                       live = (long)r.map_ctr[C_LIVE] + pending;
             if (used < m->used_ub) m->used_ub = used;
             if (bump < m->bump_ub) m->bump_ub = bump;
+            if (live < m->live_ub) m->live_ub = live;
             return;
         }
         pending += (long)p->ring[i].n_raw;
     }
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+}
+
+// Back-pressure of the asynchronous entries: at most "queue_depth" frames are kept queued on the device.  A host
+// that produces scans faster than the device registers them would otherwise run arbitrarily far ahead (the HIP
+// runtime then blocks inside some later call for milliseconds at a time -- measured, profiles/r03_b -- and the
+// map's capacity bounds, one voxel per raw point and queued frame, grow without need); with a few frames
+// queued the device never idles, and the wait, when it comes, is for work that is ahead of the caller anyway.
+static int pipe_backpressure(kicp_pipeline *p) {
+    const int depth = (int)options().queue_depth;
+    if (depth < 2 || p->in_flight < depth) return KICP_OK;
+    const int k = p->in_flight - depth + 1;  // frame k - 1 must be done = the event in front of frame k's registration
+    if (k <= p->done_upto) return KICP_OK;
+    if (hipEventQuery(p->ev[k][0]) != hipSuccess) {
+        (void)hipGetLastError();
+        const double t0 = now_ms();
+        KICP_HIP(hipEventSynchronize(p->ev[k][0]));
+        p->hs.backpressure_waits++;
+        p->hs.backpressure_ms += now_ms() - t0;
+    }
+    p->done_upto = k;
+    return KICP_OK;
+}
+
+// Drop the tombstones of the map's slot array IN STREAM ORDER, without the host waiting for anything: used when the
+// slots ever claimed (live + tombstones) approach the load limit while the live voxels alone are far from it --
+// the steady state of a moving sensor, whose old voxels die as fast as new ones appear.
+static int pipe_rehash_in_stream(kicp_pipeline *p) {
+    kicp_map *m = p->map;
+    KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
+    KICP_HIP(hipMemsetAsync(m->heads.p, 0xFF, (size_t)m->slot_cap * sizeof(int), m->stream));
+    launch_map_rehash(m->view(), m->bump_ub, m->stream);
+    KICP_HIP(hipGetLastError());
+    m->n_rehash++;
+    m->used_ub = m->live_ub;  // the rebuilt array holds exactly the live voxels (records of earlier frames stay valid,
+                              // if loose, upper bounds)
+    return KICP_OK;
 }
 
 // queue one frame whose scan is (or will be, in prep_stream order) in HBM at d_xyz: float64 xyz
@@ -1220,16 +1290,32 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         p->pending_poses.clear();
         p->poses_stale = false;
     }
-    if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(pipe_sync(p, false));
+    if (p->in_flight >= kicp_pipeline::kRing) {
+        const double t0 = now_ms();
+        KICP_TRY(pipe_sync(p, false));
+        p->hs.ring_syncs++;
+        p->hs.wait_ms += now_ms() - t0;
+    }
     KICP_TRY(pipe_reserve(p, n));
     kicp_map *m = p->map;
+    KICP_TRY(pipe_backpressure(p));
+    if (options().map_rehash_every > 0 && p->frames_enqueued > 0 && p->frames_enqueued % (uint64_t)options().map_rehash_every == 0)
+        KICP_TRY(pipe_rehash_in_stream(p));  // test hook: rebuild the slot array every N frames, frames in flight or not
     if (!m->capacity_ok(n)) {
         pipe_refresh_bounds(p);
+        // live voxels far from the limit, tombstones in the way: rebuild the slot array in stream order
+        const size_t slack = (size_t)(options().queue_depth > 0 ? options().queue_depth : 8) + 2;
+        if (!m->capacity_ok(n) && (size_t)m->bump_ub + n <= (size_t)m->blocks_cap &&
+            2 * ((size_t)m->live_ub + slack * n) <= m->slot_cap)
+            KICP_TRY(pipe_rehash_in_stream(p));
         if (!m->capacity_ok(n) && p->in_flight > 2) {
-            // throttle instead of draining: wait until frame in_flight-3 is done (the launch-start
-            // event of the frame behind it), i.e. at most two frames are still queued; then the bound
+            // (only with "queue_depth" 0) throttle instead of draining: wait until frame in_flight-3 is done (the
+            // launch-start event of the frame behind it), i.e. at most two frames are still queued; then the bound
             // (exact counters of the newest finished frame + two frames of slack) fits
+            const double t0 = now_ms();
             KICP_HIP(hipEventSynchronize(p->ev[p->in_flight - 2][0]));
+            p->hs.capacity_waits++;
+            p->hs.wait_ms += now_ms() - t0;
             pipe_refresh_bounds(p);
         }
     }
@@ -1359,7 +1445,9 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     I.conv = c.convergence_criterion;
     I.granules = p->granules.as<unsigned long long>();
     I.spin_limit = kSpinLimit;
-    if (p->inject_timeouts > 0) {
+    if (p->inject_skip > 0) {
+        p->inject_skip--;
+    } else if (p->inject_timeouts > 0) {
         I.inject_timeout = 1;
         p->inject_timeouts--;
     }
@@ -1387,6 +1475,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     launch_map_link(v, sc, fd, &prep->n_fd, 0, n_i, st, 1, s);
     launch_map_apply(v, sc, n_i, s);
     m->used_ub += (long)n;
+    m->live_ub += (long)n;
     m->bump_ub += (long)n;
     if (m->bump_ub > m->blocks_cap) m->bump_ub = m->blocks_cap;
     // --- ... and the frame record, written by the kernel itself into the pinned host ring ---------
@@ -1396,6 +1485,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     KICP_HIP(hipGetLastError());
     p->in_flight++;
     p->frames_enqueued++;
+    p->hs.frames++;
     p->last_in.valid = true;
     p->last_in.d_xyz = d_xyz;
     p->last_in.xyz_f32 = xyz_f32;
@@ -1419,14 +1509,28 @@ static int pipe_stage_and_enqueue(kicp_pipeline *p, const double *xyz64, const f
         return KICP_ERR_TIMESTAMPS;
     }
     if (n > (size_t)0x7FFFFFF0 / 3 || n_ts > (size_t)0x7FFFFFF0) return KICP_ERR_INVALID_ARG;
-    if (p->in_flight >= kicp_pipeline::kRing) KICP_TRY(pipe_sync(p, false));
+    const double t_call = now_ms();
+    if (p->in_flight >= kicp_pipeline::kRing) {
+        KICP_TRY(pipe_sync(p, false));
+        p->hs.ring_syncs++;
+        p->hs.wait_ms += now_ms() - t_call;
+    }
+    KICP_TRY(pipe_backpressure(p));
     KICP_TRY(pipe_reserve(p, n > n_ts ? n : n_ts));
     KICP_TRY(pipe_reserve_staging(p));
     const int slot = (int)(p->staged % kicp_pipeline::kStage);
     if (p->stage_busy[slot]) {  // its previous upload (four frames ago) must have left the slot
-        KICP_HIP(hipEventSynchronize(p->ev_h2d[slot]));
+        if (hipEventQuery(p->ev_h2d[slot]) != hipSuccess) {
+            (void)hipGetLastError();
+            const double t0 = now_ms();
+            KICP_HIP(hipEventSynchronize(p->ev_h2d[slot]));
+            p->hs.staging_waits++;
+            p->hs.wait_ms += now_ms() - t0;
+        }
         p->stage_busy[slot] = false;
     }
+    const double t_stage = now_ms();
+    const double wait_before = p->hs.wait_ms + p->map->wait_ms;
     char *h = p->stage[slot];
     double *h_ts = reinterpret_cast<double *>(h + p->stage_points * 3 * sizeof(double));
     constexpr size_t kChunk = 16384;  // values per task
@@ -1482,16 +1586,46 @@ static int pipe_stage_and_enqueue(kicp_pipeline *p, const double *xyz64, const f
             });
         }
     }
-    // upload on the stream that consumes it.  raw[par] / ts[par] were last read by the front stages of
-    // frame k-2, which precede this copy in stream order.
     const int par = (int)(p->frames_enqueued & 1u);
     hipStream_t sp = p->prep_stream;
-    if (n) KICP_HIP(hipMemcpyAsync(p->raw[par].p, h, n_val * (as_f32 ? sizeof(float) : sizeof(double)), hipMemcpyHostToDevice, sp));
-    if (n_ts) KICP_HIP(hipMemcpyAsync(p->ts[par].p, h_ts, n_ts * sizeof(double), hipMemcpyHostToDevice, sp));
-    KICP_HIP(hipEventRecord(p->ev_h2d[slot], sp));
+    const double t_copied = now_ms();
+    const int in_flight_before = p->in_flight;
+    int st;
+    double t_enq;
+    if (options().staging_zero_copy != 0) {
+        // No upload at all: the staging slot is pinned, device-mapped host memory, and the only kernels that read the
+        // raw scan (k_ts_minmax, k_pre_flags) read it once, front to back -- they fetch it over PCIe themselves.  One
+        // DMA hand-off less per frame, and the copy engines stay out of the frame path (their queues are created
+        // lazily, ~5-8 ms each, the first time the runtime finds the ones it has busy: measured as a one-off stall of
+        // the 10th frame of a process, profiles/r03_c).
+        void *d_h = nullptr;
+        KICP_HIP(hipHostGetDevicePointer(&d_h, h, 0));
+        const double *d_hts = reinterpret_cast<const double *>(static_cast<char *>(d_h) + p->stage_points * 3 * sizeof(double));
+        t_enq = now_ms();
+        st = pipe_enqueue(p, d_h, as_f32 ? 1 : 0, n, n_ts ? d_hts : nullptr, n_ts);
+        KICP_HIP(hipEventRecord(p->ev_h2d[slot], sp));  // behind the front stages of this frame: the slot is free again
+    } else {
+        // upload on the stream that consumes it.  raw[par] / ts[par] were last read by the front stages of
+        // frame k-2, which precede this copy in stream order.
+        if (n) KICP_HIP(hipMemcpyAsync(p->raw[par].p, h, n_val * (as_f32 ? sizeof(float) : sizeof(double)), hipMemcpyHostToDevice, sp));
+        if (n_ts) KICP_HIP(hipMemcpyAsync(p->ts[par].p, h_ts, n_ts * sizeof(double), hipMemcpyHostToDevice, sp));
+        KICP_HIP(hipEventRecord(p->ev_h2d[slot], sp));
+        t_enq = now_ms();
+        st = pipe_enqueue(p, p->raw[par].p, as_f32 ? 1 : 0, n, n_ts ? p->ts[par].as<double>() : nullptr, n_ts);
+    }
     p->stage_busy[slot] = true;
     p->staged++;
-    return pipe_enqueue(p, p->raw[par].p, as_f32 ? 1 : 0, n, n_ts ? p->ts[par].as<double>() : nullptr, n_ts);
+    const double t_end = now_ms();
+    const double waited = (p->hs.wait_ms + p->map->wait_ms) - wait_before;  // inside pipe_enqueue
+    p->hs.stage_ms += t_copied - t_stage;
+    p->hs.enqueue_ms += (t_end - t_copied) - waited;
+    if (t_end - t_call > p->hs.max_call_ms) p->hs.max_call_ms = t_end - t_call;
+    if (host_trace_on())
+        fprintf(stderr, "[kicp host] frame %llu in_flight %d: call %.3f ms = pre %.3f + copy %.3f (%s) + h2d calls %.3f + enqueue %.3f (waited %.3f); waits backpressure %llu cap %llu stage %llu refresh %llu grow %llu rehash %llu\n",
+                (unsigned long long)p->frames_enqueued - 1, in_flight_before, t_end - t_call, t_stage - t_call, t_copied - t_stage, as_f32 ? "f32" : "f64",
+                t_enq - t_copied, t_end - t_enq, waited, (unsigned long long)p->hs.backpressure_waits, (unsigned long long)p->hs.capacity_waits, (unsigned long long)p->hs.staging_waits,
+                (unsigned long long)p->map->n_refresh, (unsigned long long)p->map->n_grow, (unsigned long long)p->map->n_rehash);
+    return st;
 }
 
 extern "C" {
@@ -1524,6 +1658,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     p->device = device_id;
     p->cfg = *cfg;
     p->inject_timeouts = (int)options().icp_inject_timeout;
+    p->inject_skip = (int)options().icp_inject_timeout_skip;
     int s = KICP_OK;
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1588,6 +1723,10 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
         if (p->stage[i]) (void)hipHostFree(p->stage[i]);
     }
     if (p->out_stage) (void)hipHostFree(p->out_stage);
+    if (p->copy_stream) {
+        (void)hipStreamSynchronize(p->copy_stream);
+        (void)hipStreamDestroy(p->copy_stream);
+    }
     if (p->prep_stream) (void)hipStreamDestroy(p->prep_stream);
     if (p->ev_ok)
         for (int i = 0; i < kicp_pipeline::kRing; ++i) {
@@ -1611,6 +1750,22 @@ static void pipe_collect(kicp_pipeline *p, int count, int &err_bits) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, p->ev[i][0], p->ev[i][1]) == hipSuccess) p->icp_ms += ms;
             else (void)hipGetLastError();  // e.g. the option was switched on while frames were queued
+            if (i > 0) {  // device time between two registrations: the previous frame's map update + the front of this one
+                float gap = 0.f;
+                if (hipEventElapsedTime(&gap, p->ev[i - 1][1], p->ev[i][0]) == hipSuccess) {
+                    p->hs.device_gap_ms += gap;
+                    if (gap > p->hs.max_device_gap_ms) p->hs.max_device_gap_ms = gap;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (host_trace_on() && p->ev_ok) {
+            float t_start = 0.f, t_icp = 0.f;  // device-side timeline of the batch: registration start relative to the first frame's
+            if (hipEventElapsedTime(&t_start, p->ev[0][0], p->ev[i][0]) != hipSuccess) (void)hipGetLastError();
+            if (hipEventElapsedTime(&t_icp, p->ev[i][0], p->ev[i][1]) != hipSuccess) (void)hipGetLastError();
+            fprintf(stderr, "[kicp device] batch frame %d: registration starts at %.3f ms, runs %.3f ms (%d iterations, n_src %d, map %d voxels)\n", i,
+                    t_start, t_icp, r.st.icp_iterations, r.st.n_src, r.map_ctr[C_LIVE]);
         }
         p->icp_launches++;
         p->icp_iters += (uint64_t)r.st.icp_iterations;
@@ -1629,6 +1784,7 @@ static void pipe_collect(kicp_pipeline *p, int count, int &err_bits) {
         kicp_map *m = p->map;
         memcpy(m->h_ctr, p->last.map_ctr, sizeof m->h_ctr);
         m->used_ub = m->h_ctr[C_USED];
+        m->live_ub = m->h_ctr[C_LIVE];
         m->bump_ub = m->h_ctr[C_BUMP] < m->blocks_cap ? m->h_ctr[C_BUMP] : m->blocks_cap;
     }
 }
@@ -1642,13 +1798,21 @@ int kicp_pipeline_sync(kicp_pipeline *p) {
 
 // user_call = false: a wait the library inserted on its own (ring full, buffers growing); the poses it
 // completes stay on the caller's list
+static int pipe_sync_impl(kicp_pipeline *p);
 static int pipe_sync(kicp_pipeline *p, bool user_call) {
     KICP_HIP(hipSetDevice(p->device));
     if (p->poses_stale) {
         p->pending_poses.clear();
         p->poses_stale = false;
     }
+    // The list is marked "seen by the caller" only when the caller's sync RETURNS: a frame replayed inside it (after a
+    // registration that gave up) goes through pipe_enqueue, which must neither drop the poses collected a moment ago nor
+    // leave the flag cleared behind it.
+    const int st = pipe_sync_impl(p);
     if (user_call) p->poses_stale = true;
+    return st;
+}
+static int pipe_sync_impl(kicp_pipeline *p) {
     for (int attempt = 0;; ++attempt) {
         KICP_HIP(hipStreamSynchronize(p->stream));
         // a registration whose workgroups were not all resident gives up (bounded spin), commits nothing
@@ -1663,6 +1827,7 @@ static int pipe_sync(kicp_pipeline *p, bool user_call) {
         const int queued = p->in_flight;
         pipe_collect(p, good, err_bits);
         p->in_flight = 0;
+        p->done_upto = 0;
         if (good < queued) {
             PipeState *st = pipe_state(p);
             const int zero = 0;
@@ -1787,6 +1952,32 @@ int kicp_pipeline_output_size(kicp_pipeline *p, int which, size_t *n) {
     return KICP_OK;
 }
 
+// pinned bounce buffer of the output downloads
+static int pipe_out_stage(kicp_pipeline *p, size_t bytes) {
+    if (p->out_stage_bytes >= bytes) return KICP_OK;
+    if (p->out_stage) KICP_HIP(hipHostFree(p->out_stage));
+    p->out_stage = nullptr;
+    p->out_stage_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc((void **)&p->out_stage, want) != hipSuccess) {
+        set_error("pinned output buffer of %zu bytes failed", want);
+        return KICP_ERR_OOM;
+    }
+    p->out_stage_bytes = want;
+    return KICP_OK;
+}
+// pinned -> the caller's pageable memory, spread over the helper threads
+static void pipe_spread_copy(kicp_pipeline *p, void *dst_, const void *src_, size_t bytes) {
+    constexpr size_t kPiece = 256 * 1024;
+    const int pieces = (int)((bytes + kPiece - 1) / kPiece);
+    char *dst = static_cast<char *>(dst_);
+    const char *src = static_cast<const char *>(src_);
+    p->pool->run(pieces, [&](int k) {
+        const size_t a = (size_t)k * kPiece, e = a + kPiece < bytes ? a + kPiece : bytes;
+        memcpy(dst + a, src + a, e - a);
+    });
+}
+
 int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, size_t *n) {
     if (!p || !n || (!out && cap)) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(p->device));
@@ -1805,30 +1996,72 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
         }
         // large clouds (the preprocessed frame is ~3 MB): DMA into a pinned bounce buffer, then the helper
         // threads spread it into the caller's pageable memory
-        if (p->out_stage_bytes < bytes) {
-            if (p->out_stage) KICP_HIP(hipHostFree(p->out_stage));
-            p->out_stage = nullptr;
-            p->out_stage_bytes = 0;
-            const size_t want = bytes + bytes / 4;
-            if (hipHostMalloc((void **)&p->out_stage, want) != hipSuccess) {
-                set_error("pinned output buffer of %zu bytes failed", want);
-                return KICP_ERR_OOM;
-            }
-            p->out_stage_bytes = want;
-        }
+        KICP_TRY(pipe_out_stage(p, bytes));
         KICP_TRY(pipe_reserve_staging(p));  // (creates the helper threads)
-        constexpr size_t kPiece = 256 * 1024;
-        const int pieces = (int)((bytes + kPiece - 1) / kPiece);
         KICP_HIP(hipMemcpyAsync(p->out_stage, b.p, bytes, hipMemcpyDeviceToHost, p->stream));
         KICP_HIP(hipStreamSynchronize(p->stream));
-        char *dst = reinterpret_cast<char *>(out);
-        const char *src = p->out_stage;
-        p->pool->run(pieces, [&](int k) {
-            const size_t a = (size_t)k * kPiece, e = a + kPiece < bytes ? a + kPiece : bytes;
-            memcpy(dst + a, src + a, e - a);
-        });
+        pipe_spread_copy(p, out, p->out_stage, bytes);
     }
     return KICP_OK;
+}
+
+// RegisterFrame as the reference declares it (KissICP.cpp:35-68): blocks, and hands back BOTH clouds.  The
+// preprocessed frame -- the big one, as large as the scan -- is final long before the pose is: it leaves the device
+// (DMA into pinned memory on a third stream) and reaches the caller's buffer while the registration is still
+// running, so the call costs what the registration costs, not that plus a 3 MB download.
+// views: the clouds stay in the pipeline's pinned buffer and the caller gets pointers into it.
+static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps, size_t n_ts, bool views,
+                                 double *pre_out, size_t pre_cap, const double **pre_view, size_t *n_pre, double *src_out,
+                                 size_t src_cap, const double **src_view, size_t *n_src) {
+    KICP_HIP(hipSetDevice(p->device));
+    static const double kNone[3] = {0.0, 0.0, 0.0};
+    if (p->in_flight) KICP_TRY(pipe_sync(p, false));  // `pre` exists once: no frame may be queued behind this one
+    KICP_TRY(pipe_stage_and_enqueue(p, xyz ? xyz : kNone, nullptr, n, timestamps, n_ts));
+    const int par = (int)((p->frames_enqueued - 1) & 1u);
+    if (!p->copy_stream) KICP_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    // everything the front stages may have produced (at most n points) plus their counts, in one go: the counts are
+    // only known on the device, and a second round trip to size the copy would cost more than the few bytes saved
+    const size_t want = views ? n : (n < pre_cap ? n : pre_cap);
+    const size_t bytes = want * 3 * sizeof(double);
+    const size_t off_prep = (bytes + 63) & ~(size_t)63, off_src = off_prep + 256;
+    KICP_TRY(pipe_out_stage(p, off_src + (views ? n * 3 * sizeof(double) : 0)));
+    PrepState *h_prep = reinterpret_cast<PrepState *>(p->out_stage + off_prep);
+    KICP_HIP(hipStreamWaitEvent(p->copy_stream, p->ev_prep_done[par], 0));
+    KICP_HIP(hipMemcpyAsync(h_prep, p->prep.as<PrepState>() + par, sizeof(PrepState), hipMemcpyDeviceToHost, p->copy_stream));
+    if (bytes) KICP_HIP(hipMemcpyAsync(p->out_stage, p->pre.p, bytes, hipMemcpyDeviceToHost, p->copy_stream));
+    KICP_HIP(hipStreamSynchronize(p->copy_stream));
+    const size_t got_pre = (size_t)h_prep->n_pre;
+    const size_t c = got_pre < want ? got_pre : want;
+    if (!views && c) pipe_spread_copy(p, pre_out, p->out_stage, c * 3 * sizeof(double));
+    // ... and now the pose
+    KICP_TRY(pipe_sync(p, true));
+    *n_pre = (size_t)p->last.st.n_pre;
+    if (*n_pre != got_pre) {  // (a replayed registration re-runs the front stages on the same scan: same counts)
+        set_error("preprocessed count changed under the download (%zu vs %zu)", got_pre, *n_pre);
+        return KICP_ERR_HIP;
+    }
+    if (!views) return kicp_pipeline_output(p, KICP_OUT_SOURCE, src_out, src_cap, n_src);
+    *pre_view = reinterpret_cast<const double *>(p->out_stage);
+    *n_src = (size_t)p->last.st.n_src;
+    *src_view = reinterpret_cast<const double *>(p->out_stage + off_src);
+    if (*n_src) {
+        KICP_HIP(hipMemcpyAsync(p->out_stage + off_src, p->src[par].p, *n_src * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        KICP_HIP(hipStreamSynchronize(p->stream));
+    }
+    return KICP_OK;
+}
+
+int kicp_pipeline_register_frame_outputs(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps, size_t n_ts,
+                                         double *pre_out, size_t pre_cap, size_t *n_pre, double *src_out, size_t src_cap,
+                                         size_t *n_src) {
+    if (!p || (!xyz && n) || !n_pre || !n_src || (!pre_out && pre_cap) || (!src_out && src_cap)) return KICP_ERR_INVALID_ARG;
+    return pipe_register_outputs(p, xyz, n, timestamps, n_ts, false, pre_out, pre_cap, nullptr, n_pre, src_out, src_cap, nullptr, n_src);
+}
+
+int kicp_pipeline_register_frame_views(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps, size_t n_ts,
+                                       const double **pre_view, size_t *n_pre, const double **src_view, size_t *n_src) {
+    if (!p || (!xyz && n) || !n_pre || !n_src || !pre_view || !src_view) return KICP_ERR_INVALID_ARG;
+    return pipe_register_outputs(p, xyz, n, timestamps, n_ts, true, nullptr, 0, pre_view, n_pre, nullptr, 0, src_view, n_src);
 }
 
 int kicp_pipeline_voxelize(kicp_pipeline *p, const double *xyz, size_t n, double *source_xyz, size_t *n_source,
@@ -1929,6 +2162,26 @@ int kicp_pipeline_icp_group_profile(kicp_pipeline *p, uint32_t *out, size_t cap_
                            (size_t)groups * 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
     *n_iters = iters;
     *n_groups = groups;
+    return KICP_OK;
+}
+
+int kicp_pipeline_host_stats(kicp_pipeline *p, kicp_host_stats *out, int reset) {
+    if (!p) return KICP_ERR_INVALID_ARG;
+    const kicp_map *m = p->map;
+    if (out) {
+        *out = p->hs;
+        out->counter_refreshes = m->n_refresh - p->map_refresh0;
+        out->map_grows = m->n_grow - p->map_grow0;
+        out->map_rehashes = m->n_rehash - p->map_rehash0;
+        out->wait_ms += m->wait_ms - p->map_wait0;
+    }
+    if (reset) {
+        memset(&p->hs, 0, sizeof p->hs);
+        p->map_refresh0 = m->n_refresh;
+        p->map_grow0 = m->n_grow;
+        p->map_rehash0 = m->n_rehash;
+        p->map_wait0 = m->wait_ms;
+    }
     return KICP_OK;
 }
 
@@ -2064,6 +2317,8 @@ int kicp_set_option(const char *name, long value) {
         options().staging_threads = value;
     } else if (!strcmp(name, "staging_f32")) {
         options().staging_f32 = value;
+    } else if (!strcmp(name, "staging_zero_copy")) {
+        options().staging_zero_copy = value;
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (the prefix sums are 32-bit)
         options().icp_weight_base = value;
@@ -2073,6 +2328,15 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_inject_timeout")) {
         if (value < 0) return KICP_ERR_INVALID_ARG;
         options().icp_inject_timeout = value;
+    } else if (!strcmp(name, "icp_inject_timeout_skip")) {
+        if (value < 0) return KICP_ERR_INVALID_ARG;
+        options().icp_inject_timeout_skip = value;
+    } else if (!strcmp(name, "map_rehash_every")) {
+        if (value < 0) return KICP_ERR_INVALID_ARG;
+        options().map_rehash_every = value;
+    } else if (!strcmp(name, "queue_depth")) {
+        if (value != 0 && (value < 2 || value > kicp_pipeline::kRing - 1)) return KICP_ERR_INVALID_ARG;
+        options().queue_depth = value;
     } else if (!strcmp(name, "map_apply_threads")) {
         if (value != 256 && value != 512 && value != 1024) return KICP_ERR_INVALID_ARG;
         options().map_apply_threads = value;

@@ -48,9 +48,13 @@ struct Frame {
 //                                                   communicator running on this thread reported)
 // Status codes are kicp_status; the text of a failure is fetched with last_error().
 
-// One block per rank and gather: a count and `cap` poses.  Fixed size, so that ranks in different processes
-// need not agree on anything but the number of sync calls.
-inline size_t block_doubles(size_t cap) { return 2 + 16 * cap; }
+// One block per rank and gather: a four-word header -- poses in this block, the rank, poses the rank completed in this
+// sync altogether, the status of the rank's own pipeline sync -- and `cap` poses.  Fixed size, and everything a rank
+// needs to know about the others travels IN the blocks: ranks in different processes need not agree on anything but
+// the number of sync calls (the number of gather rounds is the maximum over all ranks, a rank whose pipeline failed
+// still takes part -- with an empty block and its status -- instead of leaving the others inside the collective).
+constexpr size_t kBlockHeader = 4;
+inline size_t block_doubles(size_t cap) { return kBlockHeader + 16 * cap; }
 
 template <class Pipe>
 class Driver {
@@ -96,32 +100,45 @@ public:
     // poses(rank) holds what global rank `rank` completed since the previous sync.
     int sync() {
         if (!started_) return fail(KICP_ERR_INVALID_ARG, "batch not started");
-        int rc = post_all(Cmd::Sync);
-        if (rc != KICP_OK) return rc;
-        // more frames than one block carries: several gathers.  Ranks of other processes must have queued the
-        // same number of frames per sync (documented in kicp.h); the local ones are known here.
-        size_t most = 0;
-        for (auto &w : workers_) most = std::max(most, w.fresh.size() / 16);
-        size_t rounds = std::max<size_t>(1, (most + cap_ - 1) / cap_);
+        // a stream whose pipeline fails here still goes through the exchange (an empty block carrying its status): its
+        // peers -- possibly in other processes -- are already on their way into the collective
+        const int rc_sync = post_all(Cmd::Sync);
+        const std::string err_sync = error_;
         all_poses_.assign(n_total_, {});
         gather_seconds_ = 0.0;
+        size_t rounds = 1;  // known after the first gather: the most frames any rank of any process completed
+        int rc_remote = KICP_OK, bad_rank = -1;
         for (size_t r = 0; r < rounds; ++r) {
             for (auto &w : workers_) w.round = r;
             const auto t0 = std::chrono::steady_clock::now();
-            rc = post_all(Cmd::Gather);
+            const int rc = post_all(Cmd::Gather);
             gather_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (rc != KICP_OK) return rc;
-            // every local rank received the same blocks; rank 0 of this process is the one read out, the others
-            // are compared against it in debug builds of the test
+            if (rc != KICP_OK) return rc;  // the exchange itself failed: nothing more can be agreed on
+            // every local rank received the same blocks; rank 0 of this process is the one read out
             const Worker &w0 = workers_[0];
             for (int g = 0; g < n_total_; ++g) {
                 const double *blk = w0.gathered.data() + size_t(g) * block_doubles(cap_);
-                size_t cnt = size_t(blk[0]);
+                const size_t cnt = size_t(blk[0]), total = size_t(blk[2]);
                 if (cnt > cap_) return fail(KICP_ERR_INVALID_ARG, "gathered block carries an impossible count");
-                all_poses_[g].insert(all_poses_[g].end(), blk + 2, blk + 2 + 16 * cnt);
+                all_poses_[g].insert(all_poses_[g].end(), blk + kBlockHeader, blk + kBlockHeader + 16 * cnt);
+                if (r == 0) {
+                    rounds = std::max(rounds, (total + cap_ - 1) / cap_);
+                    if (blk[3] != 0.0 && rc_remote == KICP_OK) {
+                        rc_remote = int(blk[3]);
+                        bad_rank = g;
+                    }
+                }
             }
         }
         ++syncs_;
+        if (rc_sync != KICP_OK) {
+            error_ = err_sync;
+            return rc_sync;
+        }
+        if (rc_remote != KICP_OK) {
+            error_ = "stream " + std::to_string(bad_rank) + " (another process): its pipeline failed in this sync";
+            return rc_remote;
+        }
         return KICP_OK;
     }
 
@@ -169,6 +186,7 @@ private:
         std::vector<double> block;     // what this rank contributes to one gather
         std::vector<double> gathered;  // n_total blocks
         size_t round = 0;
+        int sync_rc = KICP_OK;         // status of this stream's own pipeline in the running sync
         bool open = false, comm_open = false;
     };
 
@@ -223,13 +241,18 @@ private:
         case Cmd::Enqueue:
             return w.frame.skip ? KICP_OK : p.enqueue(w.frame);
         case Cmd::Sync: {
-            int rc = p.sync();
-            if (rc != KICP_OK) return rc;
+            w.fresh.clear();
+            w.sync_rc = p.sync();
+            if (w.sync_rc != KICP_OK) return w.sync_rc;
             size_t n = 0;
-            rc = p.new_poses(nullptr, 0, &n);
-            if (rc != KICP_OK) return rc;
-            w.fresh.assign(16 * n, 0.0);
-            return n ? p.new_poses(w.fresh.data(), n, &n) : KICP_OK;
+            int rc = p.new_poses(nullptr, 0, &n);
+            if (rc == KICP_OK && n) {
+                w.fresh.assign(16 * n, 0.0);
+                rc = p.new_poses(w.fresh.data(), n, &n);
+            }
+            if (rc != KICP_OK) w.fresh.clear();
+            w.sync_rc = rc;
+            return rc;
         }
         case Cmd::Gather: {
             const size_t have = w.fresh.size() / 16;
@@ -237,7 +260,9 @@ private:
             std::fill(w.block.begin(), w.block.end(), std::numeric_limits<double>::quiet_NaN());
             w.block[0] = double(hi - lo);
             w.block[1] = double(rank);
-            if (hi > lo) std::memcpy(w.block.data() + 2, w.fresh.data() + 16 * lo, (hi - lo) * 16 * sizeof(double));
+            w.block[2] = double(have);
+            w.block[3] = double(w.sync_rc);
+            if (hi > lo) std::memcpy(w.block.data() + kBlockHeader, w.fresh.data() + 16 * lo, (hi - lo) * 16 * sizeof(double));
             const size_t bytes = w.block.size() * sizeof(double);
             int rc = p.put(w.block.data(), bytes);
             if (rc != KICP_OK) return rc;

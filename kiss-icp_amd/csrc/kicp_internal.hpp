@@ -242,9 +242,13 @@ struct Options {
     long icp_reserve_cus = 32;   // CUs left out of the ICP grid (one per shader engine) for the front stages of the next frame
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
+    long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
     long icp_weight_base = 16;   // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_quad = -1;   // the weight also carries population^2 / this; 0: never; -1: when runs are short (kicp_sort.hip)
     long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once
+    long icp_inject_timeout_skip = 0;  // ... after this many registrations that are left alone
+    long map_rehash_every = 0;   // test hook: a pipeline rebuilds its map's slot array in stream order every N frames
+    long queue_depth = 4;        // frames a pipeline keeps queued on the device before an asynchronous entry waits (>= 2; 0: no limit)
 };
 Options &options();
 
@@ -276,8 +280,11 @@ struct kicp_map {
     uint32_t slot_cap = 0;
     int blocks_cap = 0;
     // host-side upper bounds of the device counters (exact after refresh_counters)
-    long used_ub = 0, bump_ub = 0;
+    long used_ub = 0, bump_ub = 0, live_ub = 0;
     int h_ctr[kicp::C_COUNT] = {0};
+    // host-side event counters (kicp_pipeline_host_stats)
+    uint64_t n_refresh = 0, n_grow = 0, n_rehash = 0;
+    double wait_ms = 0.0;  // host time blocked in refreshes / growth
     // scratch of add_points
     kicp::DevBuf pts_in, world, next, rec_slot, rec_count, rec_head, rec_list;
     unsigned insert_seq = 0;

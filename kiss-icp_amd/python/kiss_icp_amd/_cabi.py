@@ -57,6 +57,18 @@ class FrameStats(C.Structure):
         return d
 
 
+class HostStats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64), ("backpressure_waits", C.c_uint64), ("capacity_waits", C.c_uint64), ("staging_waits", C.c_uint64),
+        ("ring_syncs", C.c_uint64), ("counter_refreshes", C.c_uint64), ("map_grows", C.c_uint64), ("map_rehashes", C.c_uint64),
+        ("buffer_grows", C.c_uint64), ("stage_ms", C.c_double), ("enqueue_ms", C.c_double), ("backpressure_ms", C.c_double),
+        ("wait_ms", C.c_double), ("device_gap_ms", C.c_double), ("max_device_gap_ms", C.c_double), ("max_call_ms", C.c_double),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 _dp = C.POINTER(C.c_double)
 _vp, _sz, _d, _i, _u64p, _szp = C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)
 
@@ -88,6 +100,8 @@ SIGNATURES = {
     "kicp_pipeline_create": [C.POINTER(Config), _i, C.POINTER(_vp)],
     "kicp_pipeline_destroy": [_vp],
     "kicp_pipeline_register_frame": [_vp, _vp, _sz, _vp, _sz],
+    "kicp_pipeline_register_frame_outputs": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _szp, _vp, _sz, _szp],
+    "kicp_pipeline_register_frame_views": [_vp, _vp, _sz, _vp, _sz, C.POINTER(_vp), _szp, C.POINTER(_vp), _szp],
     "kicp_pipeline_register_frame_async": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_register_frame_async_f32": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_register_frame_device": [_vp, _vp, _sz, _vp, _sz],
@@ -108,6 +122,7 @@ SIGNATURES = {
     "kicp_pipeline_icp_clock": [_vp, _u64p, _u64p],
     "kicp_pipeline_icp_first_iteration": [_vp, _u64p, _u64p, C.POINTER(_i)],
     "kicp_pipeline_icp_group_profile": [_vp, _vp, _sz, C.POINTER(_i), C.POINTER(_i)],
+    "kicp_pipeline_host_stats": [_vp, C.POINTER(HostStats), _i],
     "kicp_pipeline_stream": [_vp, C.POINTER(_vp)],
     "kicp_device_alloc": [_i, _sz, C.POINTER(_vp)],
     "kicp_device_free": [_i, _vp],

@@ -58,11 +58,15 @@ class KissICP:
     def register_frame(self, frame, timestamps=()):
         pts = _cabi.points(frame)
         ts = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64).ravel())
-        st = _cabi.lib().kicp_pipeline_register_frame(self._h, _cabi.ptr(pts), len(pts), _cabi.ptr(ts) if len(ts) else None, len(ts))
+        n = len(pts)
+        pre, src = np.empty((n, 3)), np.empty((n, 3))
+        n_pre, n_src = C.c_size_t(0), C.c_size_t(0)
+        st = _cabi.lib().kicp_pipeline_register_frame_outputs(self._h, _cabi.ptr(pts), n, _cabi.ptr(ts) if len(ts) else None, len(ts),
+                                                              _cabi.ptr(pre), n, C.byref(n_pre), _cabi.ptr(src), n, C.byref(n_src))
         if st == 8:
             raise IndexError(_cabi.lib().kicp_last_error().decode())
         _cabi.check(st)
-        return self.output(0), self.output(1)
+        return pre[: n_pre.value], src[: n_src.value].copy()
 
     def voxelize(self, iframe):
         frame_downsample = voxel_down_sample(iframe, self.config.mapping.voxel_size * 0.5, self.device_id)
@@ -194,6 +198,12 @@ class KissICP:
         out[..., 6] = raw[..., 3] & 15
         out[..., 7], out[..., 8] = (raw[..., 3] >> 4) & 4095, raw[..., 3] >> 16
         return out
+
+    def host_stats(self, reset=False):
+        """kicp_pipeline_host_stats: waits the asynchronous entries took on the host, and where their time went"""
+        s = _cabi.HostStats()
+        _cabi.check(_cabi.lib().kicp_pipeline_host_stats(self._h, C.byref(s), int(reset)))
+        return s.asdict()
 
     def stream(self):
         s = C.c_void_p()

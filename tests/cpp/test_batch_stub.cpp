@@ -33,7 +33,7 @@ struct StubPipe {
     std::vector<double> queued_payload;  // first coordinate of each queued scan, to see the right scan reached the right stream
     size_t done = 0, queued = 0, reported = 0;
     std::thread::id thread;
-    int fail_enqueue_at = -1, fail_open = 0;
+    int fail_enqueue_at = -1, fail_open = 0, fail_sync_at = -1, syncs = 0;
     std::string err;
 
     int open(int r, int dev, size_t bytes, int total) {
@@ -61,6 +61,12 @@ struct StubPipe {
         return KICP_OK;
     }
     int sync() {
+        if (syncs++ == fail_sync_at) {
+            err = "registration gave up";
+            queued = done;  // the frames of this batch are lost
+            reported = done;
+            return KICP_ERR_TIMEOUT;
+        }
         reported = done;
         done = queued;
         return KICP_OK;
@@ -184,7 +190,7 @@ static void test_one_process_four_streams() {
         CHECK(std::memcmp(d.received(i).data(), d.received(0).data(), d.received(0).size() * sizeof(double)) == 0);
     // padding of a short block is NaN, never stale poses
     const double *blk2 = d.received(0).data() + 2 * block_doubles(8);
-    CHECK(blk2[0] == 2.0 && blk2[1] == 2.0 && std::isnan(blk2[2 + 16 * 2]));
+    CHECK(blk2[0] == 2.0 && blk2[1] == 2.0 && blk2[2] == 2.0 && blk2[3] == 0.0 && std::isnan(blk2[kBlockHeader + 16 * 2]));
 
     // an empty sync: one gather, nothing new anywhere
     size_t before = comm.gathers;
@@ -300,7 +306,61 @@ static void test_failures_surface() {
     }
 }
 
+static void test_a_failing_pipeline_does_not_strand_its_peers() {
+    // two "processes" {0,1} and {2}; the pipeline of rank 1 fails its first sync.  Both processes return from sync()
+    // (nobody is left inside the collective), both report the failure, the healthy ranks' poses are delivered, and the
+    // next sync works.  The processes queue DIFFERENT numbers of frames: the round count travels in the blocks.
+    StubComm comm;
+    const int dev_a[2] = {0, 1}, dev_b[1] = {0};
+    Driver<StubPipe> a(2, 0, 3, 4, comm.table()), b(1, 2, 3, 4, comm.table());
+    int rc_a = -1, rc_b = -1;
+    std::thread ta([&] {
+        rc_a = a.start(dev_a, [](int i) {
+            auto p = std::make_unique<StubPipe>();
+            if (i == 1) p->fail_sync_at = 0;
+            return p;
+        });
+    });
+    std::thread tb([&] { rc_b = b.start(dev_b, plain); });
+    ta.join();
+    tb.join();
+    CHECK(rc_a == KICP_OK && rc_b == KICP_OK);
+    double scan[3] = {1, 2, 3};
+    auto drive = [&](Driver<StubPipe> &d, int frames, int *rc) {
+        std::vector<Frame> f(d.n_local());
+        for (auto &x : f) {
+            x.xyz = scan;
+            x.n = 1;
+        }
+        *rc = KICP_OK;
+        for (int k = 0; k < frames && *rc == KICP_OK; ++k) *rc = d.register_frames(f.data());
+        if (*rc == KICP_OK) *rc = d.sync();
+    };
+    std::thread t1([&] { drive(a, 3, &rc_a); }), t2([&] { drive(b, 9, &rc_b); });  // 9 frames: three rounds of 4
+    t1.join();
+    t2.join();
+    CHECK(rc_a == KICP_ERR_TIMEOUT && rc_b == KICP_ERR_TIMEOUT);
+    CHECK(a.last_error().find("stream 1") != std::string::npos && a.last_error().find("gave up") != std::string::npos);
+    CHECK(b.last_error().find("stream 1") != std::string::npos);
+    check_poses(a, 0, 0, 3);
+    check_poses(b, 0, 0, 3);
+    CHECK(a.poses(1).empty() && b.poses(1).empty());
+    check_poses(a, 2, 0, 9);
+    check_poses(b, 2, 0, 9);
+    std::thread t3([&] { drive(a, 2, &rc_a); }), t4([&] { drive(b, 2, &rc_b); });
+    t3.join();
+    t4.join();
+    CHECK(rc_a == KICP_OK && rc_b == KICP_OK);
+    check_poses(a, 0, 3, 2);
+    check_poses(a, 1, 0, 2);
+    check_poses(b, 2, 9, 2);
+    std::thread s1([&] { a.stop(); }), s2([&] { b.stop(); });
+    s1.join();
+    s2.join();
+}
+
 int main() {
+    test_a_failing_pipeline_does_not_strand_its_peers();
     test_one_process_four_streams();
     test_two_processes();
     test_failures_surface();

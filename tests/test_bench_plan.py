@@ -1,0 +1,53 @@
+"""CPU tests of bench.py's launch logic: `--gpus N` must mean N streams -- as one rank of N under torch.distributed.run
+(what the driver launches for N > 1), or, started plainly, N streams driven in-process through the C-ABI's batch entry --
+and must fail loudly, never fall back to a single stream, when the box cannot provide them."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_one_gpu_is_a_single_stream():
+    assert bench.launch_plan(1, None, -1, 1) == ("single", [0], None)
+    assert bench.launch_plan(1, None, 3, 8) == ("single", [3], None)
+
+
+def test_under_a_launcher_this_process_is_one_rank():
+    assert bench.launch_plan(8, "8", -1, 8)[0] == "rank"
+    assert bench.launch_plan(1, "1", -1, 1)[0] == "rank"
+    with pytest.raises(SystemExit, match="disagree"):
+        bench.launch_plan(2, "4", -1, 8)
+
+
+def test_without_a_launcher_n_streams_run_in_process():
+    assert bench.launch_plan(8, None, -1, 8) == ("in-process", list(range(8)), "rccl")
+    assert bench.launch_plan(2, None, -1, 8) == ("in-process", [0, 1], "rccl")
+    # streams stacked on one device (1-GPU box): RCCL refuses two ranks per device, so the exchange is the host communicator
+    assert bench.launch_plan(2, None, 0, 1) == ("in-process", [0, 0], "host")
+
+
+def test_too_few_devices_is_an_error_not_a_single_stream_run():
+    with pytest.raises(SystemExit, match="needs 4 GPUs, 1 visible"):
+        bench.launch_plan(4, None, -1, 1)
+    with pytest.raises(SystemExit):
+        bench.launch_plan(0, None, -1, 1)
+
+
+def test_bench_refuses_n_gpus_on_a_box_without_them():
+    """the real command on this (GPU-less) box: it stops before generating a single scan"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    from kiss_icp_amd import _cabi
+
+    if _cabi.device_count() >= 8:
+        pytest.skip("this box has 8 GPUs")
+    assert r.returncode != 0
+    assert "needs 8 GPUs" in r.stderr
+    assert '"n_gpus"' not in r.stdout

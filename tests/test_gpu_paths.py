@@ -60,13 +60,16 @@ def test_async_host_input_is_bitwise_the_sync_path(gpu, O, deskew):
             return k, k.synced_poses()
         finally:
             for k_ in opts:
-                _cabi.set_option(k_, 1 if k_ == "staging_f32" else 3)
+                _cabi.set_option(k_, {"staging_threads": 3, "queue_depth": 4}.get(k_, 1))
 
     variants = {
         "f64 narrowed": run(scans),
         "f32 native": run([(p.astype(np.float32), t) for p, t in scans]),
         "f64 as is": run(scans, staging_f32=0),
         "no helper threads": run(scans, staging_threads=0),
+        "uploaded first (no zero-copy reads of the staging slot)": run(scans, staging_zero_copy=0),
+        "no queue depth limit": run(scans, queue_depth=0),
+        "two frames queued at most": run(scans, queue_depth=2),
     }
     for name, (k, poses) in variants.items():
         assert len(poses) == n_frames, name
@@ -388,6 +391,111 @@ def test_a_registration_that_gives_up_is_replayed(gpu, O):
         ko2.register_frame(ds[i][0], np.array([]))
     dt, dr = pose_error(ko2.last_pose, kq.last_pose)
     assert dt < TIGHT and dr < TIGHT
+
+
+def test_replay_keeps_the_callers_pose_list_intact(gpu):
+    """a registration that gives up in the MIDDLE of a sync is replayed inside that sync: the poses the sync hands to
+    the caller are those of every queued frame, in order, once -- and the next sync starts a new list (the replay goes
+    through the normal queueing path, which must not mistake itself for the caller's next batch)"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=9, n_frames=7, beams=32, azimuth_steps=512)
+    clean = _pipe(deskew=False)
+    want = []
+    for i in range(7):
+        clean.register_frame(ds[i][0])
+        want.append(clean.last_pose)
+    for skip, queued in ((0, 1), (2, 3), (3, 4)):  # the failing registration is the LAST of `queued` frames
+        _cabi.set_option("icp_inject_timeout", 1)
+        _cabi.set_option("icp_inject_timeout_skip", skip)
+        try:
+            k = _pipe(deskew=False)
+        finally:
+            _cabi.set_option("icp_inject_timeout", 0)
+            _cabi.set_option("icp_inject_timeout_skip", 0)
+        for i in range(queued):
+            k.register_frame_async(ds[i][0])
+        k.sync()
+        got = k.synced_poses()
+        assert len(got) == queued, (skip, len(got))
+        for i in range(queued):
+            assert np.array_equal(got[i], want[i]), (skip, i)
+        for i in range(queued, queued + 2):
+            k.register_frame_async(ds[i][0])
+        k.sync()
+        got = k.synced_poses()
+        assert len(got) == 2, (skip, len(got))  # a NEW list: nothing of the previous sync in front of it
+        for j in range(2):
+            assert np.array_equal(got[j], want[queued + j]), (skip, j)
+        assert np.array_equal(k.last_pose, want[queued + 1])
+
+
+def test_async_entry_never_starves_the_device(gpu):
+    """the driver's bench shape: a fresh pipeline, a young map, 5 + 20 full-size scans handed to the asynchronous host
+    entry back to back.  After the first two frames (buffers and map sized from the first scan) the host side takes
+    no wait that leaves the device without work -- no capacity wait, no counter read-back, no reallocation, no
+    staging-slot wait -- only back-pressure (the caller is ahead of the device), and on the device consecutive
+    registrations follow each other without a gap beyond the map update between them"""
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=3, n_frames=25)  # (generated in this process: a pool would fork a process that holds a HIP runtime)
+    scans = [(np.ascontiguousarray(ds[i][0], dtype=np.float64), ds[i][1]) for i in range(25)]
+    k = _pipe(deskew=False)
+    for p, t in scans[:2]:
+        k.register_frame_async(p, t)
+    k.sync()
+    k.host_stats(reset=True)
+    for p, t in scans[2:5]:
+        k.register_frame_async(p, t)
+    k.sync()
+    for p, t in scans[5:]:
+        k.register_frame_async(p, t)
+    k.sync()
+    h = k.host_stats()
+    assert h["frames"] == 23
+    for key in ("capacity_waits", "staging_waits", "ring_syncs", "counter_refreshes", "map_grows", "buffer_grows"):
+        assert h[key] == 0, (key, h)
+    assert h["wait_ms"] == 0.0, h
+    assert h["max_call_ms"] < 2.0, h  # a call is a copy into pinned memory plus a dozen launches
+    # the serial chain between two registrations is ~0.1 ms (map update + run weights); a starved device shows ms
+    assert h["max_device_gap_ms"] < 0.5, h
+    assert len(k.synced_poses()) == 20
+
+
+def test_slot_array_rebuilt_in_stream_order(gpu, O):
+    """a moving sensor fills the map's slot array with tombstones; the pipeline drops them by rebuilding the array IN
+    STREAM ORDER, frames queued before and behind it, without the host waiting for anything.  Forced here every 7 frames
+    (test hook "map_rehash_every"; on its own it happens when live + tombstoned slots reach half the table) on a drive
+    that prunes, tombstones and recycles blocks: the trajectory and the map stay the oracle's"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+
+    n = 120
+    ds = kitti_like(seed=8, n_frames=n, beams=32, azimuth_steps=512, yaw_deg=0.8)
+    ko = O.KissICP(deskew=0, max_range=40.0, voxel_size=0.5)
+    _cabi.set_option("map_rehash_every", 7)
+    try:
+        k = _pipe(deskew=False, max_range=40.0, voxel_size=0.5)
+        k.register_frame(ds[0][0])
+        ko.register_frame_noout(ds[0][0], ds[0][1])
+        k.host_stats(reset=True)
+        for i in range(1, n):
+            k.register_frame_async(ds[i][0])
+            ko.register_frame_noout(ds[i][0], ds[i][1])
+            if i % 40 == 0:
+                k.sync()
+                assert k.local_map.num_voxels() == ko.local_map.num_voxels(), i
+        k.sync()
+    finally:
+        _cabi.set_option("map_rehash_every", 0)
+    dt, dr = pose_error(ko.last_pose, k.last_pose)
+    assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+    assert k.local_map.num_voxels() == ko.local_map.num_voxels()
+    np.testing.assert_allclose(sort_rows(k.local_map.point_cloud()), sort_rows(ko.local_map.point_cloud()), rtol=0, atol=1e-8)
+    h = k.host_stats()
+    assert h["map_rehashes"] >= 15, h
+    assert h["counter_refreshes"] == 0 and h["capacity_waits"] == 0 and h["map_grows"] == 0, h
 
 
 def test_device_solve_is_bitwise_the_oracles(gpu, O):
