@@ -922,9 +922,13 @@ struct ScopedBufs {
 
 static int downsample_device(const double *d_in, const int *n_ptr, int n_imm, int n_max, double voxel,
                              DevBuf &tab, uint32_t tab_cap, int *slot_of, int *blk_counts, double *d_out,
-                             int *d_nout, int *d_err, bool claim, hipStream_t s) {
+                             int *d_nout, int *d_err, bool claim, int order, int *rb_elem, int *rb_home, hipStream_t s) {
     DsParams P;
     memset(&P, 0, sizeof P);
+    P.order = order;
+    P.tab_cap = (int)tab_cap;
+    P.rb_elem = rb_elem;
+    P.rb_home = rb_home;
     P.in = d_in;
     P.n_ptr = n_ptr;
     P.n_imm = n_imm;
@@ -938,8 +942,13 @@ static int downsample_device(const double *d_in, const int *n_ptr, int n_imm, in
     P.n_out = d_nout;
     P.err = d_err;
     if (claim) launch_ds_claim(P, s);
-    launch_ds_flags(P, s);
-    launch_ds_scatter(P, s);
+    if (order) {
+        launch_ds_arrange(P, s);
+        launch_ds_scatter_rb(P, s);
+    } else {
+        launch_ds_flags(P, s);
+        launch_ds_scatter(P, s);
+    }
     KICP_HIP(hipGetLastError());
     return KICP_OK;
 }
@@ -969,20 +978,23 @@ int kicp_voxel_downsample(const double *xyz, size_t n, double voxel_size, int de
     if (n == 0) return KICP_OK;
     ScopedStream ss;
     KICP_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
-    DevBuf in, out, tab, slot_of, counts, misc;
+    DevBuf in, out, tab, slot_of, counts, misc, rb;
     ScopedBufs sb;
-    sb.v = {&in, &out, &tab, &slot_of, &counts, &misc};
+    sb.v = {&in, &out, &tab, &slot_of, &counts, &misc, &rb};
+    const int order = options().downsample_order != 0;
+    const uint32_t cap = next_pow2(2 * n);
     KICP_TRY(in.reserve(n * 3 * sizeof(double)));
     KICP_TRY(out.reserve(n * 3 * sizeof(double)));
     KICP_TRY(slot_of.reserve(n * sizeof(int)));
-    KICP_TRY(counts.reserve(((n + 1023) / 1024 + 1) * sizeof(int)));
+    KICP_TRY(counts.reserve(((size_t)cap / 1024 + (n + 1023) / 1024 + 2) * sizeof(int)));
     KICP_TRY(misc.reserve(2 * sizeof(int)));
-    const uint32_t cap = next_pow2(2 * n);
+    if (order) KICP_TRY(rb.reserve((size_t)cap * 2 * sizeof(int)));
     KICP_TRY(init_ds_table(tab, cap, ss.s));
     KICP_HIP(hipMemsetAsync(misc.p, 0, 2 * sizeof(int), ss.s));
     KICP_HIP(hipMemcpyAsync(in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ss.s));
     KICP_TRY(downsample_device(in.as<double>(), nullptr, (int)n, (int)n, voxel_size, tab, cap, slot_of.as<int>(),
-                               counts.as<int>(), out.as<double>(), misc.as<int>(), misc.as<int>() + 1, true, ss.s));
+                               counts.as<int>(), out.as<double>(), misc.as<int>(), misc.as<int>() + 1, true, order,
+                               order ? rb.as<int>() : nullptr, order ? rb.as<int>() + cap : nullptr, ss.s));
     int h[2];
     KICP_HIP(hipMemcpyAsync(h, misc.p, sizeof h, hipMemcpyDeviceToHost, ss.s));
     KICP_HIP(hipStreamSynchronize(ss.s));
@@ -1102,7 +1114,8 @@ struct kicp_pipeline {
     kicp_map *map = nullptr;
     // fd (the 0.5 v cloud, read by the map update) and src (the 1.5 v cloud, read by the registration)
     // exist twice, indexed by frame parity; so do the upload targets raw / ts of the host-input path
-    DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, counts, granules, prof_groups, prep;
+    DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, rb1, rb2, counts, granules, prof_groups, prep;
+    int ds_order = 1;  // VoxelDownsample output order ("downsample_order" option, read at create)
     DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
     DevBuf run_prefix;                      // inclusive prefix of the sorted points' weights
     size_t sort_tmp_bytes = 0;
@@ -1173,16 +1186,20 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->work.reserve(b3));
     KICP_TRY(p->slot1.reserve(cap * sizeof(int)));
     KICP_TRY(p->slot2.reserve(cap * sizeof(int)));
-    KICP_TRY(p->counts.reserve(3 * ((cap + 1023) / 1024 + 1) * sizeof(int)));
+    const uint32_t tcap = next_pow2(2 * cap);
+    KICP_TRY(p->counts.reserve(3 * ((cap + 1023) / 1024 + (size_t)tcap / 1024 + 2) * sizeof(int)));
     KICP_TRY(p->sort_in.reserve(cap * sizeof(unsigned long long)));
     KICP_TRY(p->sort_out[0].reserve(cap * sizeof(unsigned long long)));
     KICP_TRY(p->sort_out[1].reserve(cap * sizeof(unsigned long long)));
     p->sort_tmp_bytes = tile_sort_temp_bytes(cap);
     KICP_TRY(p->sort_tmp.reserve(p->sort_tmp_bytes));
     KICP_TRY(p->run_prefix.reserve(cap * sizeof(int)));
-    const uint32_t tcap = next_pow2(2 * cap);
     KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
+    if (p->ds_order) {
+        KICP_TRY(p->rb1.reserve((size_t)tcap * 2 * sizeof(int)));
+        KICP_TRY(p->rb2.reserve((size_t)tcap * 2 * sizeof(int)));
+    }
     p->tab_cap = tcap;
     p->cap_points = cap;
     p->last_in.valid = false;  // the upload targets moved
@@ -1325,7 +1342,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     const int par = (int)(p->frames_enqueued & 1u);
     PrepState *prep = p->prep.as<PrepState>() + par;
     double *fd = p->fd[par].as<double>();
-    const int nblk = (int)((p->cap_points + 1023) / 1024 + 1);
+    const int nblk = (int)((p->cap_points + 1023) / 1024 + p->tab_cap / 1024 + 2);
     int *cnt0 = p->counts.as<int>(), *cnt1 = cnt0 + nblk, *cnt2 = cnt1 + nblk;
     const int n_i = (int)n;
 
@@ -1358,6 +1375,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     P.out = p->pre.as<double>();
     P.n_out = &prep->n_pre;
     P.ds_tab = p->tab1.as<DsSlot>();
+    P.ds_order = p->ds_order;
     P.ds_mask = p->tab_cap - 1;
     P.ds_voxel = c.voxel_size * 0.5;  // KissICP.cpp:72
     P.ds_slot_of = p->slot1.as<int>();
@@ -1368,6 +1386,10 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // --- Voxelize (KissICP.cpp:70-75) ---------------------------------------------------------
     DsParams D1;
     memset(&D1, 0, sizeof D1);
+    D1.order = p->ds_order;
+    D1.tab_cap = (int)p->tab_cap;
+    D1.rb_elem = p->rb1.as<int>();
+    D1.rb_home = p->rb1.as<int>() + p->tab_cap;
     D1.in = p->pre.as<double>();
     D1.n_ptr = &prep->n_pre;
     D1.n_max = n_i;
@@ -1383,10 +1405,12 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     D1.next_voxel = c.voxel_size * 1.5;  // KissICP.cpp:73
     D1.next_slot_of = p->slot2.as<int>();
     D1.err = &st->err;
-    launch_ds_flags(D1, sp);
-    launch_ds_scatter(D1, sp);
     DsParams D2;
     memset(&D2, 0, sizeof D2);
+    D2.order = p->ds_order;
+    D2.tab_cap = (int)p->tab_cap;
+    D2.rb_elem = p->rb2.as<int>();
+    D2.rb_home = p->rb2.as<int>() + p->tab_cap;
     D2.in = fd;
     D2.n_ptr = &prep->n_fd;
     D2.n_max = n_i;
@@ -1398,8 +1422,17 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     D2.out = p->src[par].as<double>();
     D2.n_out = &prep->n_src;
     D2.err = &st->err;
-    launch_ds_flags(D2, sp);
-    launch_ds_scatter(D2, sp);
+    if (p->ds_order) {  // the reference's output order: arrange the grid's clusters, then compact bucket by bucket
+        launch_ds_arrange(D1, sp);
+        launch_ds_scatter_rb(D1, sp);
+        launch_ds_arrange(D2, sp);
+        launch_ds_scatter_rb(D2, sp);
+    } else {
+        launch_ds_flags(D1, sp);
+        launch_ds_scatter(D1, sp);
+        launch_ds_flags(D2, sp);
+        launch_ds_scatter(D2, sp);
+    }
     KICP_HIP(hipGetLastError());
     // --- spatial order of the source cloud: the ICP kernel hands every workgroup a compact patch of it ----
     const bool sorted = n <= ((size_t)1 << 24);
@@ -1659,6 +1692,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     p->cfg = *cfg;
     p->inject_timeouts = (int)options().icp_inject_timeout;
     p->inject_skip = (int)options().icp_inject_timeout_skip;
+    p->ds_order = options().downsample_order != 0 ? 1 : 0;
     int s = KICP_OK;
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1713,7 +1747,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     p->pool = nullptr;
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
-                      &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
+                      &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->rb1, &p->rb2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
                       &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_prefix})
         b->release();
     for (int i = 0; i < 2; ++i)
@@ -2317,6 +2351,9 @@ int kicp_set_option(const char *name, long value) {
         options().staging_threads = value;
     } else if (!strcmp(name, "staging_f32")) {
         options().staging_f32 = value;
+    } else if (!strcmp(name, "downsample_order")) {
+        if (value != 0 && value != 1) return KICP_ERR_INVALID_ARG;
+        options().downsample_order = value;
     } else if (!strcmp(name, "staging_zero_copy")) {
         options().staging_zero_copy = value;
     } else if (!strcmp(name, "icp_weight_base")) {

@@ -248,6 +248,7 @@ struct Options {
     long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once
     long icp_inject_timeout_skip = 0;  // ... after this many registrations that are left alone
     long map_rehash_every = 0;   // test hook: a pipeline rebuilds its map's slot array in stream order every N frames
+    long downsample_order = 1;   // VoxelDownsample output order: 1 the reference's (tsl::robin_map bucket order), 0 ascending index
     long queue_depth = 4;        // frames a pipeline keeps queued on the device before an asynchronous entry waits (>= 2; 0: no limit)
 };
 Options &options();

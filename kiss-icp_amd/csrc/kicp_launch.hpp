@@ -23,6 +23,7 @@ struct PreParams {
     int *n_out;         // device count of `out`
     // fused stage A of VoxelDownsample(out, ds_voxel); ds_tab == nullptr disables it
     DsSlot *ds_tab;
+    int ds_order;  // 1: the table is the reference's grid (its hash, its bucket count: DsParams::order)
     uint32_t ds_mask;
     double ds_voxel;
     int *ds_slot_of;
@@ -31,6 +32,16 @@ struct PreParams {
 
 // VoxelDownsample (core/VoxelUtils.cpp:7-21)
 struct DsParams {
+    // order == 1: the survivors leave in the order the reference emits them -- the iteration (bucket) order of the
+    // tsl::robin_map VoxelDownsample collects them in (VoxelUtils.cpp:9-19).  The scratch table then IS that grid:
+    // the reference's hash (VoxelUtils.hpp:46-50), its bucket count (reserve(frame.size()) -> the power of two >=
+    // 2 n, from the device-side count), linear probing -- which occupies exactly the buckets robin-hood probing
+    // occupies; k_ds_arrange then settles, cluster by cluster, WHICH survivor sits in which bucket.
+    // order == 0: ascending original index (the table is only a set; own hash, host-side mask).
+    int order;
+    int tab_cap;   // buckets allocated (>= any bucket count the mode needs); sizes the bucket-wise launches
+    int *rb_elem;  // [tab_cap] order == 1: index (into `in`) of the point the reference holds in each bucket
+    int *rb_home;  // [tab_cap] scratch of k_ds_arrange
     const double *in;
     const int *n_ptr;  // device count of `in`, or nullptr -> n_imm
     int n_imm;
@@ -72,6 +83,8 @@ void launch_pre_scatter(const PreParams &P, hipStream_t s);
 void launch_ds_claim(const DsParams &P, hipStream_t s);
 void launch_ds_flags(const DsParams &P, hipStream_t s);
 void launch_ds_scatter(const DsParams &P, hipStream_t s);
+void launch_ds_arrange(const DsParams &P, hipStream_t s);      // order == 1: instead of launch_ds_flags
+void launch_ds_scatter_rb(const DsParams &P, hipStream_t s);   // order == 1: instead of launch_ds_scatter
 void launch_map_link(const MapView &m, const InsertScratch &sc, const double *in, const int *n_ptr, int n_imm,
                      int n_max, const PipeState *state, int use_pose, hipStream_t s);
 void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipStream_t s);

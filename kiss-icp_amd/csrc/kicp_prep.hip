@@ -139,12 +139,28 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_flags(PreParams P) {
     if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = total;
 }
 
+// ---- the reference's grid (DsParams::order == 1) --------------------------------------------------------------
+// std::hash<Voxel> (core/VoxelUtils.hpp:46-50): u32 wrap-around products, xor-ed; bucket = hash & (bucket_count - 1)
+__device__ __forceinline__ uint32_t ref_home(unsigned long long key, uint32_t mask) {
+    int x, y, z;
+    unpack_voxel(key, x, y, z);
+    return (((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u)) & mask;
+}
+// grid.reserve(n) (VoxelUtils.cpp:10) = rehash(ceil(float(n) / max_load_factor 0.5f)) rounded up to a power of two
+__device__ __forceinline__ uint32_t ref_grid_mask(int n) {
+    if (n <= 0) return 0u;
+    const unsigned want = (unsigned)ceilf((float)n / 0.5f);
+    unsigned b = 1u;
+    while (b < want) b <<= 1;
+    return b - 1u;
+}
+
 // find-or-claim the slot of a voxel in the downsample scratch table
-__device__ __forceinline__ int ds_claim(DsSlot *tab, uint32_t mask, unsigned long long key) {
+__device__ __forceinline__ int ds_claim(DsSlot *tab, uint32_t mask, unsigned long long key, int ref = 0) {
     // Read before CAS: ~15 scan points share a voxel, so most arrivals find their key already
     // there and never touch the atomic unit.  Keys are stable for the lifetime of a claim phase,
     // so a (possibly L1-stale) plain read can only cost an extra CAS, never a wrong answer.
-    uint32_t s = hash_key(key, mask);
+    uint32_t s = ref ? ref_home(key, mask) : hash_key(key, mask);
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         unsigned long long cur = tab[s].key;
         if (cur == kKeyEmpty) cur = atomicCAS(&tab[s].key, kKeyEmpty, key);
@@ -172,7 +188,7 @@ struct ClaimAgg {
 
 // all kScanThreads threads call this; returns the table slot of this thread's voxel (-1: none)
 __device__ __forceinline__ int ds_claim_aggregated(ClaimAgg &agg, DsSlot *tab, uint32_t mask, bool valid,
-                                                   unsigned long long key, int idx, int *err) {
+                                                   unsigned long long key, int idx, int *err, int ref = 0) {
     for (int e = threadIdx.x; e < kAggSlots; e += kScanThreads) {
         agg.key[e] = kKeyEmpty;
         agg.minidx[e] = 0x7FFFFFFF;
@@ -196,7 +212,7 @@ __device__ __forceinline__ int ds_claim_aggregated(ClaimAgg &agg, DsSlot *tab, u
     for (int e = threadIdx.x; e < kAggSlots; e += kScanThreads) {
         const unsigned long long k = agg.key[e];
         if (k == kKeyEmpty) continue;
-        const int s = ds_claim(tab, mask, k);
+        const int s = ds_claim(tab, mask, k, ref);
         if (s >= 0) ds_min_index(tab, s, agg.minidx[e]);
         else atomicOr(err, E_TABLE_FULL);
         agg.slot[e] = s;
@@ -238,7 +254,8 @@ __global__ __launch_bounds__(kScanThreads) void k_pre_scatter(PreParams P) {
             if (valid) key = pack_voxel(vx, vy, vz);
             else atomicOr(P.err, E_RANGE);
         }
-        const int s = ds_claim_aggregated(agg, P.ds_tab, P.ds_mask, valid, key, j, P.err);
+        // (the reference's grid has 2^ceil(log2(2 n)) buckets, n = the points this stage hands on: `grand`)
+        const int s = ds_claim_aggregated(agg, P.ds_tab, P.ds_order ? ref_grid_mask(grand) : P.ds_mask, valid, key, j, P.err, P.ds_order);
         if (keep) P.ds_slot_of[j] = s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256) void k_ds_claim(DsParams P) {
                   vz = voxel_coord(P.in[3 * i + 2], P.voxel);
         int s = -1;
         if (voxel_in_range(vx, vy, vz)) {
-            s = ds_claim(P.tab, P.mask, pack_voxel(vx, vy, vz));
+            s = ds_claim(P.tab, P.order ? ref_grid_mask(n) : P.mask, pack_voxel(vx, vy, vz), P.order);
             if (s >= 0) ds_min_index(P.tab, s, i);
             else atomicOr(P.err, E_TABLE_FULL);
         } else {
@@ -321,6 +338,102 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.n_out = grand;
 }
 
+// ---- the reference's output order (DsParams::order == 1) --------------------------------------------------------
+// After the claims the table holds, for every distinct voxel, {key, index of its first point} somewhere in the run of
+// occupied buckets that starts at or before its home: the same buckets the reference's robin-hood table occupies
+// (linear probing fills the same set whatever the insertion order and whoever displaces whom).  What the reference
+// fixes beyond that is who sits where INSIDE a maximal run of occupied buckets (a cluster) -- and clusters never
+// interact.  tsl::robin_map 1.4.0 inserts like this (oracle/ref_build/shim/tsl/robin_map.h states the rules): the new
+// element walks from its home bucket; at each bucket it takes the place of an occupant that is STRICTLY closer to its
+// own home -- i.e. whose home lies further right -- and the occupant walks on by the same rule; at an empty bucket the
+// walker settles.  (Equal homes: the walker moves on, so a group of one home is rotated by an insertion in front of
+// it -- the result is NOT simply "sorted by home, then by arrival".)  One thread replays these insertions for its
+// cluster, in arrival order = ascending index of the voxel's first point; clusters hold a handful of elements (a
+// table at most half full: mean 1.1, max ~20 on a 130k-point scan), a long one is merely slow.
+__global__ __launch_bounds__(kScanThreads) void k_ds_arrange(DsParams P) {
+    const int n = count_of(P.n_ptr, P.n_imm);
+    const uint32_t mask = ref_grid_mask(n);
+    const int b = blockIdx.x * kScanThreads + threadIdx.x;
+    const bool occ = n > 0 && (uint32_t)b <= mask && P.tab[b].key != kKeyEmpty;
+    int total;
+    block_exclusive_scan(occ, total);
+    if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = total;
+    if (!occ || P.tab[((uint32_t)b - 1u) & mask].key != kKeyEmpty) return;  // not the first bucket of a cluster
+    int c = 0;
+    while (P.tab[((uint32_t)b + (uint32_t)c) & mask].key != kKeyEmpty) ++c;  // (a table at most half full has an empty bucket)
+    if (c == 1) {
+        P.rb_elem[b] = P.tab[b].minidx;
+        return;
+    }
+    for (int j = 0; j < c; ++j) P.rb_elem[((uint32_t)b + (uint32_t)j) & mask] = -1;
+    int last = -1;
+    for (int step = 0; step < c; ++step) {
+        // the next arrival: the smallest first-point index above the previous one
+        int best = 0x7FFFFFFF, bj = 0;
+        for (int j = 0; j < c; ++j) {
+            const int t = P.tab[((uint32_t)b + (uint32_t)j) & mask].minidx;
+            if (t > last && t < best) {
+                best = t;
+                bj = j;
+            }
+        }
+        last = best;
+        const unsigned long long key = P.tab[((uint32_t)b + (uint32_t)bj) & mask].key;
+        int cur_t = best;
+        int cur_h = (int)((ref_home(key, mask) - (uint32_t)b) & mask);  // home relative to the cluster's first bucket: 0 .. c-1
+        for (int pos = cur_h;; ++pos) {
+            const uint32_t slot = ((uint32_t)b + (uint32_t)pos) & mask;
+            const int et = P.rb_elem[slot];
+            if (et < 0) {
+                P.rb_elem[slot] = cur_t;
+                P.rb_home[slot] = cur_h;
+                break;
+            }
+            const int eh = P.rb_home[slot];
+            if (cur_h < eh) {  // the occupant is strictly closer to its home: it gives way and walks on
+                P.rb_elem[slot] = cur_t;
+                P.rb_home[slot] = cur_h;
+                cur_t = et;
+                cur_h = eh;
+            }
+        }
+    }
+}
+
+// bucket-order compaction: the survivor of bucket b goes to position (occupied buckets before b); wipes the table;
+// fused, stage A of the next downsample on the emitted point
+__global__ __launch_bounds__(kScanThreads) void k_ds_scatter_rb(DsParams P) {
+    const int n = count_of(P.n_ptr, P.n_imm);
+    const uint32_t mask = ref_grid_mask(n);
+    const int b = blockIdx.x * kScanThreads + threadIdx.x;
+    const bool occ = n > 0 && (uint32_t)b <= mask && P.tab[b].key != kKeyEmpty;
+    int total, grand;
+    const int base = block_base(P.blk_counts, &grand);
+    const int j = base + block_exclusive_scan(occ, total);
+    if (occ) {
+        const int i = P.rb_elem[b];
+        const double x = P.in[3 * i], y = P.in[3 * i + 1], z = P.in[3 * i + 2];
+        P.out[3 * j] = x;
+        P.out[3 * j + 1] = y;
+        P.out[3 * j + 2] = z;
+        P.tab[b].key = kKeyEmpty;
+        P.tab[b].minidx = 0x7FFFFFFF;
+        if (P.next_tab) {
+            const int vx = voxel_coord(x, P.next_voxel), vy = voxel_coord(y, P.next_voxel),
+                      vz = voxel_coord(z, P.next_voxel);
+            int s2 = -1;
+            if (voxel_in_range(vx, vy, vz)) {
+                s2 = ds_claim(P.next_tab, ref_grid_mask(grand), pack_voxel(vx, vy, vz), 1);
+                if (s2 >= 0) ds_min_index(P.next_tab, s2, j);
+                else atomicOr(P.err, E_TABLE_FULL);
+            } else {
+                atomicOr(P.err, E_RANGE);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.n_out = grand;
+}
+
 void launch_ts_minmax(const double *ts, int n_ts, PrepState *st, hipStream_t s) {
     hipLaunchKernelGGL(k_ts_minmax, dim3(grid_for(n_ts, 256, 512)), dim3(256), 0, s, ts, n_ts, st);
 }
@@ -335,6 +448,12 @@ void launch_ds_claim(const DsParams &P, hipStream_t s) {
 }
 void launch_ds_flags(const DsParams &P, hipStream_t s) {
     hipLaunchKernelGGL(k_ds_flags, dim3(grid_for(P.n_max, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
+}
+void launch_ds_arrange(const DsParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_ds_arrange, dim3(grid_for(P.tab_cap, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
+}
+void launch_ds_scatter_rb(const DsParams &P, hipStream_t s) {
+    hipLaunchKernelGGL(k_ds_scatter_rb, dim3(grid_for(P.tab_cap, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);
 }
 void launch_ds_scatter(const DsParams &P, hipStream_t s) {
     hipLaunchKernelGGL(k_ds_scatter, dim3(grid_for(P.n_max, kScanThreads, 1 << 20)), dim3(kScanThreads), 0, s, P);

@@ -25,6 +25,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -563,9 +564,107 @@ static void vt_erase(vtable *t, const int32_t v[3]) {
     t->size--;
 }
 
+/* Output order of VoxelDownsample.  The reference emits the survivors by iterating a tsl::robin_map
+ * (VoxelUtils.cpp:17-19), i.e. in BUCKET order of that container -- and the order matters downstream: it
+ * decides which points AddPoints' first-come cap / spacing rule accepts (VoxelHashMap.cpp:98-118) and which
+ * point of a 1.5 v voxel the second downsample keeps (KissICP.cpp:72-73).
+ *   1 (default)  the bucket order of tsl::robin_map 1.4.0 after grid.reserve(frame.size()) and one insert per
+ *                distinct voxel in frame order, restated from the container's published algorithm (see
+ *                oracle/ref_build/shim/tsl/robin_map.h for the rules; third-party: parity unpinned);
+ *   0            ascending original index (what rounds 1-2 of this repository defined). */
+static int g_downsample_order = 1;
+void ko_set_downsample_order(int order) { g_downsample_order = order ? 1 : 0; }
+int ko_get_downsample_order(void) { return g_downsample_order; }
+
+/* std::hash<Voxel> (VoxelUtils.hpp:46-50): u32 wrap-around products, xor-ed, widened */
+static inline uint32_t ref_voxel_hash(const int32_t v[3]) {
+    return ((uint32_t)v[0] * 73856093u) ^ ((uint32_t)v[1] * 19349669u) ^ ((uint32_t)v[2] * 83492791u);
+}
+
+static size_t downsample_tsl_order(const double *xyz, size_t n, double voxel_size, double *out) {
+    if (n == 0) return 0;
+    /* grid.reserve(n): rehash(ceil(float(n) / max_load_factor 0.5f)), rounded up to a power of two */
+    size_t want = (size_t)ceilf((float)n / 0.5f), B = 1;
+    while (B < want) B <<= 1;
+    const size_t mask = B - 1;
+    int32_t *dist = (int32_t *)malloc(B * sizeof(int32_t)); /* distance from the home bucket, -1 = empty */
+    uint32_t *who = (uint32_t *)malloc(B * sizeof(uint32_t)); /* index of the point stored in the bucket */
+    int32_t *keys = (int32_t *)malloc(B * 3 * sizeof(int32_t));
+    for (size_t b = 0; b < B; ++b) dist[b] = -1;
+    size_t count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int32_t v[3];
+        ko_point_to_voxel(xyz + 3 * i, voxel_size, v);
+        size_t ib = ref_voxel_hash(v) & mask;
+        int32_t d = 0;
+        int found = 0;
+        while (d <= dist[ib]) { /* contains() / the search loop of insert */
+            if (keys[3 * ib] == v[0] && keys[3 * ib + 1] == v[1] && keys[3 * ib + 2] == v[2]) {
+                found = 1;
+                break;
+            }
+            ib = (ib + 1) & mask;
+            ++d;
+        }
+        if (found) continue;
+        /* (size() < load_threshold = B / 2 >= n always holds here: the grid never grows.  A probe sequence longer
+         * than DIST_FROM_IDEAL_BUCKET_LIMIT would make the container grow; it cannot happen at load <= 1/2 with
+         * this hash short of an adversarial cloud, and is refused rather than mis-stated.) */
+        uint32_t cw = (uint32_t)i;
+        int32_t ck[3] = {v[0], v[1], v[2]};
+        for (;;) { /* robin-hood placement: take the bucket of an occupant that is STRICTLY closer to its home */
+            if (d > 8192) {
+                fprintf(stderr, "ko_voxel_downsample: probe sequence beyond tsl's limit (not restated)\n");
+                abort();
+            }
+            if (d > dist[ib]) {
+                if (dist[ib] < 0) {
+                    dist[ib] = d;
+                    who[ib] = cw;
+                    keys[3 * ib] = ck[0];
+                    keys[3 * ib + 1] = ck[1];
+                    keys[3 * ib + 2] = ck[2];
+                    break;
+                }
+                const int32_t td = dist[ib];
+                const uint32_t tw = who[ib];
+                const int32_t tk[3] = {keys[3 * ib], keys[3 * ib + 1], keys[3 * ib + 2]};
+                dist[ib] = d;
+                who[ib] = cw;
+                keys[3 * ib] = ck[0];
+                keys[3 * ib + 1] = ck[1];
+                keys[3 * ib + 2] = ck[2];
+                d = td;
+                cw = tw;
+                ck[0] = tk[0];
+                ck[1] = tk[1];
+                ck[2] = tk[2];
+            }
+            ++d;
+            ib = (ib + 1) & mask;
+        }
+        ++count;
+    }
+    size_t kept = 0;
+    for (size_t b = 0; b < B; ++b) /* iteration = bucket order */
+        if (dist[b] >= 0) {
+            const size_t i = who[b];
+            out[3 * kept] = xyz[3 * i];
+            out[3 * kept + 1] = xyz[3 * i + 1];
+            out[3 * kept + 2] = xyz[3 * i + 2];
+            ++kept;
+        }
+    free(dist);
+    free(who);
+    free(keys);
+    (void)count;
+    return kept;
+}
+
 size_t ko_voxel_downsample(const double *xyz, size_t n, double voxel_size, double *out) {
-    /* VoxelUtils.cpp:7-21: insert the first point seen per voxel; emit one point per voxel.
-     * Emission order here: ascending original index (see header).                        */
+    /* VoxelUtils.cpp:7-21: insert the first point seen per voxel; emit one point per voxel. */
+    if (g_downsample_order == 1) return downsample_tsl_order(xyz, n, voxel_size, out);
+    /* emission order: ascending original index */
     vtable t;
     vt_init(&t, 2 * n + 16);
     size_t kept = 0;

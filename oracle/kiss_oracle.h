@@ -65,6 +65,10 @@ void ko_point_to_voxel(const double p[3], double voxel_size, int32_t v[3]);
  * original index (the reference's is tsl::robin_map bucket order -- unspecified).
  * out must hold n points; returns the number kept. */
 size_t ko_voxel_downsample(const double *xyz, size_t n, double voxel_size, double *out);
+/* output order of ko_voxel_downsample (and of the pipeline's two downsamples): 1 = the reference's, i.e. bucket order
+ * of tsl::robin_map 1.4.0 (default); 0 = ascending original index.  Process-wide. */
+void ko_set_downsample_order(int order);
+int ko_get_downsample_order(void);
 
 /* ---- VoxelHashMap (core/VoxelHashMap.{hpp,cpp}) ---------------------------------------- */
 typedef struct ko_map ko_map;

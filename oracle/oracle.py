@@ -93,6 +93,8 @@ def lib():
         "ko_ldlt6_solve": (None, [_dp, _dp, _dp]),
         "ko_point_to_voxel": (None, [_dp, d, C.POINTER(C.c_int32)]),
         "ko_voxel_downsample": (sz, [_dp, sz, d, _dp]),
+        "ko_set_downsample_order": (None, [i]),
+        "ko_get_downsample_order": (i, []),
         "ko_map_create": (vp, [d, d, C.c_uint]),
         "ko_map_destroy": (None, [vp]),
         "ko_map_clear": (None, [vp]),
@@ -215,6 +217,17 @@ def point_to_voxel(p, voxel_size):
     v = (C.c_int32 * 3)()
     lib().ko_point_to_voxel(_p(p), voxel_size, v)
     return np.array(v[:], dtype=np.int32)
+
+
+REFERENCE_ORDER, INDEX_ORDER = 1, 0
+
+
+def set_downsample_order(order):
+    """output order of VoxelDownsample, process-wide: REFERENCE_ORDER (default) = bucket order of the tsl::robin_map the
+    reference iterates (core/VoxelUtils.cpp:17-19); INDEX_ORDER = ascending original index.  Returns the previous one."""
+    old = lib().ko_get_downsample_order()
+    lib().ko_set_downsample_order(int(order))
+    return old
 
 
 def voxel_down_sample(frame, voxel_size):

@@ -38,9 +38,18 @@ def downsample():
     pts = random_cloud(rng, 3000, extent=12.0, z_extent=2.0)
     out = {"points": pts}
     for v, key in ((0.5, "out_050"), (1.5, "out_150")):
+        # the reference's order: bucket order of the tsl::robin_map it iterates (VoxelUtils.cpp:17-19)
         o = R.voxel_down_sample(pts, v)
         assert np.array_equal(o, N.voxel_downsample(pts, v)) and np.array_equal(o, O.voxel_down_sample(pts, v))
         out[key] = o
+        # ... and ascending original index (option downsample_order = 0 of the HIP path; the reference cannot produce it)
+        old = O.set_downsample_order(O.INDEX_ORDER)
+        try:
+            oi = O.voxel_down_sample(pts, v)
+        finally:
+            O.set_downsample_order(old)
+        assert np.array_equal(oi, N.voxel_downsample(pts, v, order="index")) and np.array_equal(sort_rows(oi), sort_rows(o))
+        out[key + "_index"] = oi
     np.savez_compressed(os.path.join(HERE, "downsample.npz"), source=SOURCE, **out)
 
 
@@ -121,6 +130,23 @@ def sequence():
         iters.append(ko.last_stats()["iterations"])
     out["poses"] = np.array(poses)
     out["iterations"] = np.array(iters)
+    # the same drive with VoxelDownsample emitting by ascending index (oracle == naive; not a reference behaviour)
+    old = O.set_downsample_order(O.INDEX_ORDER)
+    try:
+        ko, kn = O.KissICP(deskew=0, max_num_threads=1), N.KissICP(deskew=False, downsample_order="index")
+        poses_i, iters_i = [], []
+        for i in range(n_frames):
+            pts, ts = ds[i]
+            ko.register_frame(pts, ts)
+            kn.register_frame(pts, ts)
+            dt, dr = pose_error(ko.last_pose, kn.last_pose)
+            assert dt < 1e-9 and dr < 1e-9, (i, dt, dr)
+            poses_i.append(ko.last_pose)
+            iters_i.append(ko.last_stats()["iterations"])
+    finally:
+        O.set_downsample_order(old)
+    out["poses_index_order"] = np.array(poses_i)
+    out["iterations_index_order"] = np.array(iters_i)
     np.savez_compressed(os.path.join(HERE, "sequence.npz"), **out)
 
 

@@ -50,17 +50,60 @@ def se3_log(T):
     return np.array([X[0, 3], X[1, 3], X[2, 3], X[2, 1], X[0, 2], X[1, 0]])
 
 
-def voxel_downsample(frame, voxel_size):
-    """VoxelUtils.cpp:7-21: keep the first point of every voxel.  Output order is defined (here and
-    in the oracle) as ascending original index; the reference's is robin_map bucket order."""
+def voxel_hash(v):
+    """std::hash<Voxel> (VoxelUtils.hpp:46-50): u32 wrap-around products, xor-ed"""
+    M = 0xFFFFFFFF
+    return (((v[0] & M) * 73856093) & M) ^ (((v[1] & M) * 19349669) & M) ^ (((v[2] & M) * 83492791) & M)
+
+
+def robin_bucket_order(hashes, n_reserved):
+    """Ids 0..len(hashes)-1, inserted in that order into a tsl::robin_map (v1.4.0, default parameters) on which
+    reserve(n_reserved) was called first, listed in ITERATION (= bucket) order.  A second, independent statement of the
+    container's published rules (the first is oracle/ref_build/shim/tsl/robin_map.h):
+      reserve(n): bucket_count = smallest power of two >= ceil(float32(n) / 0.5);
+      insert: walk from hash & (B - 1) while the walker's distance from its home is <= the occupant's (empty = -1);
+      there the walker takes the bucket if it is empty, else swaps with the occupant -- which walks on by the same rule
+      (so an occupant EQUALLY far from home stays: elements of one home bucket behind an insertion point rotate)."""
+    if n_reserved == 0:
+        return []
+    want = int(np.ceil(np.float32(n_reserved) / np.float32(0.5)))
+    B = 1
+    while B < want:
+        B *= 2
+    dist = [-1] * B
+    elem = [-1] * B
+    for e, h in enumerate(hashes):
+        ib, d = h & (B - 1), 0
+        while d <= dist[ib]:
+            ib, d = (ib + 1) & (B - 1), d + 1
+        ce, cd = e, d
+        while True:
+            if cd > dist[ib]:
+                if dist[ib] < 0:
+                    dist[ib], elem[ib] = cd, ce
+                    break
+                (dist[ib], elem[ib]), (cd, ce) = (cd, ce), (dist[ib], elem[ib])
+            ib, cd = (ib + 1) & (B - 1), cd + 1
+    return [e for e in elem if e >= 0]
+
+
+def voxel_downsample(frame, voxel_size, order="reference"):
+    """VoxelUtils.cpp:7-21: keep the first point of every voxel; the survivors come out in the iteration order of the
+    tsl::robin_map they were collected in (order="reference", what the reference does) or by ascending original index
+    (order="index", the definition of rounds 1-2 of this repository)."""
+    frame = np.asarray(frame, dtype=np.float64).reshape(-1, 3)
     seen = set()
     keep = []
+    voxels = []
     for i, p in enumerate(frame):
         v = point_to_voxel(p, voxel_size)
         if v not in seen:
             seen.add(v)
             keep.append(i)
-    return np.asarray(frame, dtype=np.float64).reshape(-1, 3)[keep]
+            voxels.append(v)
+    if order == "reference":
+        keep = [keep[e] for e in robin_bucket_order([voxel_hash(v) for v in voxels], len(frame))]
+    return frame[keep]
 
 
 class VoxelHashMap:
@@ -191,8 +234,9 @@ class KissICP:
     """pipeline/KissICP.cpp:35-75 with KISSConfig defaults (KissICP.hpp:36-54)"""
 
     def __init__(self, voxel_size=1.0, max_range=100.0, min_range=0.0, max_points_per_voxel=20, min_motion_th=0.1,
-                 initial_threshold=2.0, max_num_iterations=500, convergence_criterion=1e-4, deskew=True):
+                 initial_threshold=2.0, max_num_iterations=500, convergence_criterion=1e-4, deskew=True, downsample_order="reference"):
         self.voxel_size, self.max_range, self.min_range, self.deskew = voxel_size, max_range, min_range, deskew
+        self.order = downsample_order
         self.max_iters, self.conv = max_num_iterations, convergence_criterion
         self.map = VoxelHashMap(voxel_size, max_range, max_points_per_voxel)
         self.threshold = AdaptiveThreshold(initial_threshold, min_motion_th, max_range)
@@ -201,8 +245,8 @@ class KissICP:
 
     def register_frame(self, frame, timestamps=()):
         pre = preprocess(frame, timestamps, self.last_delta, self.max_range, self.min_range, self.deskew)
-        fd = voxel_downsample(pre, self.voxel_size * 0.5)
-        source = voxel_downsample(fd, self.voxel_size * 1.5)
+        fd = voxel_downsample(pre, self.voxel_size * 0.5, self.order)
+        source = voxel_downsample(fd, self.voxel_size * 1.5, self.order)
         sigma = self.threshold.compute()
         guess = self.last_pose @ self.last_delta
         new_pose, self.iterations = align_points_to_map(source, self.map, guess, 3.0 * sigma, sigma, self.max_iters, self.conv)

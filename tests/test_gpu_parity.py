@@ -37,7 +37,37 @@ def test_voxel_downsample_bit_exact(gpu, O, n, voxel):
     got = voxel_down_sample(pts, voxel)
     want = O.voxel_down_sample(pts, voxel)
     assert got.shape == want.shape
-    assert np.array_equal(got, want)  # same points, same (ascending index) order
+    assert np.array_equal(got, want)  # same points, in the reference's order (tsl::robin_map bucket order)
+
+
+def test_voxel_downsample_order_small_tables(gpu, O):
+    """the reference's output order on tables of 2..256 buckets -- collisions, clusters wrapping around the end of the
+    table, equal-home groups rotated by insertions in front of them -- and a dense cloud whose clusters run long:
+    k_ds_arrange against the oracle's statement of tsl::robin_map's rules; then the index-order option"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.voxelization import voxel_down_sample
+
+    rng = np.random.default_rng(23)
+    for trial in range(300):
+        n = int(rng.integers(1, 129))
+        pts = np.round(rng.normal(0.0, float(rng.choice([2.0, 8.0, 40.0])), (n, 3)), 2)
+        v = float(rng.choice([0.5, 1.0, 1.5]))
+        assert np.array_equal(voxel_down_sample(pts, v), O.voxel_down_sample(pts, v)), (trial, n, v)
+    # every voxel of a small block occupied: the reference's hash maps neighbours to neighbouring buckets -> long clusters
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(6), indexing="ij"), axis=-1).reshape(-1, 3) * 0.5 + 0.25
+    g = g[rng.permutation(len(g))]
+    assert np.array_equal(voxel_down_sample(g, 0.5), O.voxel_down_sample(g, 0.5))
+    gold = _golden("downsample.npz")
+    _cabi.set_option("downsample_order", 0)
+    old = O.set_downsample_order(O.INDEX_ORDER)
+    try:
+        for v, key in ((0.5, "out_050"), (1.5, "out_150")):
+            assert np.array_equal(voxel_down_sample(gold["points"], v), gold[key + "_index"])
+        pts = random_cloud(rng, 20000)
+        assert np.array_equal(voxel_down_sample(pts, 0.5), O.voxel_down_sample(pts, 0.5))
+    finally:
+        _cabi.set_option("downsample_order", 1)
+        O.set_downsample_order(old)
 
 
 def test_voxel_downsample_duplicates_and_boundaries(gpu, O):
@@ -489,7 +519,10 @@ def test_golden_sequence_gpu(gpu):
 
 # ---- full-size, size-independent properties (no oracle needed) --------------------------------------------
 def test_downsample_properties_at_full_size(gpu):
-    """1M points: idempotence, one survivor per voxel, survivors are a subsequence of the input"""
+    """1M points: one survivor per voxel, each the FIRST input point of its voxel, a fixed point as a set; the output
+    order is that of the reference's grid -- checked here through a property that needs no oracle (home buckets ascend
+    in iteration order) -- and with the index-order option they come out exactly as keep-first says"""
+    from kiss_icp_amd import _cabi
     from kiss_icp_amd.voxelization import voxel_down_sample
 
     rng = np.random.default_rng(77)
@@ -498,12 +531,21 @@ def test_downsample_properties_at_full_size(gpu):
         out = voxel_down_sample(pts, v)
         vox = np.floor(out / v).astype(np.int64)
         assert len(np.unique(vox, axis=0)) == len(out)  # one point per voxel
-        assert len(out) == len(np.unique(np.floor(pts / v).astype(np.int64), axis=0))  # every voxel kept
-        assert np.array_equal(voxel_down_sample(out, v), out)  # idempotent
-        # keep-first: each survivor is the first input point of its voxel
         keys = np.floor(pts / v).astype(np.int64)
         _, first = np.unique(keys, axis=0, return_index=True)
-        assert np.array_equal(out, pts[np.sort(first)])
+        assert len(out) == len(first)  # every voxel kept
+        assert np.array_equal(sort_rows(out), sort_rows(pts[first]))  # keep-first: the first input point of each voxel
+        assert np.array_equal(sort_rows(voxel_down_sample(out, v)), sort_rows(out))  # a fixed point, as a set
+        # bucket order: homes (reference hash & (2^21 - 1): 1M points reserve 2^21 buckets) ascend except at collisions
+        u = vox.astype(np.int64) & 0xFFFFFFFF
+        home = (((u[:, 0] * 73856093) & 0xFFFFFFFF) ^ ((u[:, 1] * 19349669) & 0xFFFFFFFF) ^ ((u[:, 2] * 83492791) & 0xFFFFFFFF)) & ((1 << 21) - 1)
+        # robin-hood invariant: in bucket order the home buckets never descend (but once, where a cluster wraps around)
+        assert (np.diff(home) < 0).sum() <= 1
+        _cabi.set_option("downsample_order", 0)
+        try:
+            assert np.array_equal(voxel_down_sample(pts, v), pts[np.sort(first)])  # index order: a subsequence of the input
+        finally:
+            _cabi.set_option("downsample_order", 1)
 
 
 def test_map_properties_at_full_size(gpu):

@@ -294,6 +294,43 @@ def test_voxel_downsample_vs_naive(O):
     assert O.voxel_down_sample(np.zeros((0, 3)), 0.5).shape == (0, 3)
 
 
+def test_voxel_downsample_order_small_tables_vs_naive(O):
+    """the reference emits VoxelDownsample's survivors in the BUCKET ORDER of the tsl::robin_map it collects them in
+    (VoxelUtils.cpp:17-19).  Thousands of tiny clouds -- tables of 2..128 buckets, so home-bucket collisions, clusters
+    that wrap around the end of the table and equal-home groups rotated by insertions in front of them are the rule --
+    through the C oracle and the independent Python statement of the container's rules; and the index order option"""
+    rng = np.random.default_rng(23)
+    for trial in range(1500):
+        n = int(rng.integers(1, 65))
+        pts = np.round(rng.normal(0.0, float(rng.choice([2.0, 8.0, 40.0])), (n, 3)), 2)
+        v = float(rng.choice([0.5, 1.0, 1.5]))
+        a = O.voxel_down_sample(pts, v)
+        assert np.array_equal(a, N.voxel_downsample(pts, v)), (trial, n, v)
+    pts = random_cloud(rng, 3000, extent=10.0, z_extent=2.0)
+    old = O.set_downsample_order(O.INDEX_ORDER)
+    try:
+        for v in (0.5, 1.5):
+            a = O.voxel_down_sample(pts, v)
+            assert np.array_equal(a, N.voxel_downsample(pts, v, order="index"))
+            O.set_downsample_order(O.REFERENCE_ORDER)
+            b = O.voxel_down_sample(pts, v)
+            O.set_downsample_order(O.INDEX_ORDER)
+            assert not np.array_equal(a, b) and np.array_equal(sort_rows(a), sort_rows(b))  # same survivors, other order
+    finally:
+        O.set_downsample_order(old)
+
+
+def test_golden_downsample_both_orders(O):
+    g = np.load(os.path.join(GOLDEN, "downsample.npz"))
+    for v, key in ((0.5, "out_050"), (1.5, "out_150")):
+        assert np.array_equal(O.voxel_down_sample(g["points"], v), g[key])
+        old = O.set_downsample_order(O.INDEX_ORDER)
+        try:
+            assert np.array_equal(O.voxel_down_sample(g["points"], v), g[key + "_index"])
+        finally:
+            O.set_downsample_order(old)
+
+
 def test_map_vs_naive(O):
     rng = np.random.default_rng(22)
     om, nm = O.VoxelHashMap(1.0, 20.0, 20), N.VoxelHashMap(1.0, 20.0, 20)

@@ -47,6 +47,18 @@ def test_voxel_downsample_same_points_same_order(R, O):
         assert np.array_equal(R.voxel_down_sample(pts, v), O.voxel_down_sample(pts, v))
 
 
+def test_voxel_downsample_bucket_order_on_small_tables(R, O):
+    """the reference's own VoxelDownsample over the restated tsl::robin_map (oracle/ref_build/shim/tsl/robin_map.h)
+    against the oracle's statement of the same bucket order, on thousands of tiny clouds: tables of 2..128 buckets,
+    where collisions, wrap-around clusters and rotated equal-home groups are the rule"""
+    rng = np.random.default_rng(7)
+    for trial in range(3000):
+        n = int(rng.integers(1, 65))
+        pts = np.round(rng.normal(0.0, float(rng.choice([2.0, 8.0, 40.0])), (n, 3)), 2)
+        v = float(rng.choice([0.5, 1.0, 1.5]))
+        assert np.array_equal(R.voxel_down_sample(pts, v), O.voxel_down_sample(pts, v)), (trial, n, v)
+
+
 def test_preprocess_crop_and_deskew(R, O):
     rng = np.random.default_rng(2)
     pts = random_cloud(rng, 20000, extent=130.0, z_extent=10.0)
