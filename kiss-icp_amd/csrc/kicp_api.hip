@@ -1325,8 +1325,8 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         if (!m->capacity_ok(n) && (size_t)m->bump_ub + n <= (size_t)m->blocks_cap &&
             2 * ((size_t)m->live_ub + slack * n) <= m->slot_cap)
             KICP_TRY(pipe_rehash_in_stream(p));
-        if (!m->capacity_ok(n) && p->in_flight > 2) {
-            // (only with "queue_depth" 0) throttle instead of draining: wait until frame in_flight-3 is done (the
+        if (!m->capacity_ok(n) && p->in_flight > 2 && options().queue_depth == 0) {
+            // (without a queue depth the bounds can be arbitrarily loose) throttle instead of draining: wait until frame in_flight-3 is done (the
             // launch-start event of the frame behind it), i.e. at most two frames are still queued; then the bound
             // (exact counters of the newest finished frame + two frames of slack) fits
             const double t0 = now_ms();
