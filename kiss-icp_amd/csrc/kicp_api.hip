@@ -741,7 +741,7 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
         return KICP_ERR_HIP;
     }
     int s = r->state.reserve(sizeof(PipeState));
-    if (s == KICP_OK && icp_prepare(device_id) != 0) {
+    if (s == KICP_OK && (icp_prepare(device_id) != 0 || tile_sort_prepare(device_id) != 0)) {
         set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
         s = KICP_ERR_HIP;
     }
@@ -1713,7 +1713,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     if (s == KICP_OK)
         s = map_create_on_stream(cfg->voxel_size, cfg->max_range, (unsigned)cfg->max_points_per_voxel, device_id,
                                  p->stream, &p->map);
-    if (s == KICP_OK && icp_prepare(device_id) != 0) {
+    if (s == KICP_OK && (icp_prepare(device_id) != 0 || tile_sort_prepare(device_id) != 0)) {
         set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
         s = KICP_ERR_HIP;
     }

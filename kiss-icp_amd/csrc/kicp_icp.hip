@@ -16,24 +16,26 @@ namespace kicp {
 // ------------------------------------------------------------------------------------------
 // k_icp: the whole ICP loop of AlignPointsToMap in one persistent launch
 //
-// grid = G workgroups (all co-resident, G <= 256 = one per CU, each owning its CU's 160 KiB of
-// LDS), 512 threads = 16 groups of 32 lanes.  Per iteration every group walks its points (fixed
-// assignment, so the running transformed source of a point is always re-read by the group that
-// wrote it):
-//   s = est * s            TransformPoints of the previous iteration's estimate (Registration.cpp:159;
-//                          est = initial_guess for the first iteration, :147)
-//   (nn, d) = closest neighbour among the 27 voxels, keep iff d < max_dist (strict, :72).  The
-//             first visit of a voxel neighbourhood copies its candidates into an LDS region
-//             (bump-allocated from the workgroup's pool, exactly E points); as long as the query
-//             stays in the same voxel later iterations scan LDS only.
-//   accumulate the 16 unique scalars of J^T w J and J^T w r with J = [I | -hat(s)], r = s - nn,
-//   w = sigma^2 / (sigma + |r|^2)^2 (:81-98).
-// Workgroup partials are reduced in LDS in a fixed order, published as tagged granules, gathered
-// by EVERY workgroup (one hop, no second broadcast; 26 threads per scalar, each summing a
-// contiguous range of workgroups, then the 26 range sums in order: deterministic), and every
-// workgroup solves the same 6x6 system redundantly on its first four waves:
-// dx = LDLT(JTJ).solve(-JTr), est = exp(dx), T_icp = est * T_icp, stop when |dx| <
-// convergence_criterion (:156-163).
+// grid = G workgroups (all co-resident, G <= 256 = one per CU, each owning its CU's 160 KiB of LDS), 512 threads =
+// 16 groups of 32 lanes.  A workgroup serves a contiguous RUN of the spatially sorted source cloud (kicp_sort.hip)
+// and keeps the map voxels that run can reach in an LDS tile (kicp_search.hpp).  Per iteration, in three phases per
+// chunk of 128 points:
+//   A  one thread per point: s = est * s (TransformPoints, Registration.cpp:159; est = initial_guess for the first
+//      iteration, :147), its voxel, is its known window still good;
+//   B  one 32-lane group per point (pulled dynamically): (nn, d) = closest neighbour among the 27 voxels, against the
+//      tile (VoxelHashMap.cpp:46-70), after the queries that left their window have re-established it (B0);
+//   C  one thread per point: keep iff d < max_dist (strict, :72), w = sigma^2 / (sigma + |r|^2)^2, the 16 unique
+//      scalars of J^T w J and J^T w r with J = [I | -hat(s)], r = s - nn (:81-98), added in point order.
+// The exchange, once per iteration (tagged 16-byte granule pairs, sc1 stores and loads: the data is its own flag):
+//   1. every workgroup publishes its 18 partial sums;
+//   2. workgroup g < 8 (a "leader") gathers the partials of the workgroups b = g, g + 8, g + 16, ... (at most 32),
+//      sums them in that order and publishes the group's sums;
+//   3. EVERY workgroup gathers the (at most) 8 group sums, adds them in order, and solves the same 6x6 system on its
+//      first four waves: dx = LDLT(JTJ).solve(-JTr), est = exp(dx), stop when |dx| < convergence_criterion
+//      (:156-163); workgroup 0 also keeps T_icp = est * T_icp and the statistics.
+// Two short hops (28 x 304 B into 8 CUs, then 8 x 304 B into every CU) instead of one long one (224 x 304 B into ONE
+// CU's memory queue) plus a broadcast hop for the result; the summation tree depends on G only, never on timing or
+// placement, so results are reproducible bit for bit.
 // ------------------------------------------------------------------------------------------
 // one source point of the chunk a workgroup is working on (phases A -> B -> C of an iteration)
 struct IcpPoint {
@@ -49,7 +51,7 @@ static_assert(sizeof(IcpPoint) == 80, "IcpPoint layout");
 
 struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records and the candidate pool follow
     double part[kIcpGroupsPerBlock][kIcpSums];
-    double range_sum[kIcpParts][kIcpSums];
+    double range_sum[kIcpMaxMembers][kIcpSums];  // leader: its members' partials; every workgroup: the group sums (rows 0..7)
     double tot[kIcpSums];
     double est[8];  // q[4], t[3], |dx|
     // kept by ONE thread (kIcpBookThread of workgroup 0), off the critical path and out of registers:
@@ -455,163 +457,135 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + k) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
         }
-        // ---- exchange: workgroup 0 gathers every partial, solves, and broadcasts the update --------------
-        // (Every workgroup gathering every partial -- G x G x 304 bytes of agent-scope loads per iteration --
-        // costs more than a second hop once G reaches a few dozen: at 240 workgroups the all-gather moved
-        // 17.5 MB per iteration and took ~5 us; this way 73 KB go to one workgroup and 128 bytes come back.)
+        // ---- exchange: leaders sum their groups, every workgroup sums the groups and solves ----------------------
+        // (One root gathering all G partials -- round 2 -- had 224 x 19 granule pairs queue up in ONE CU's memory
+        // path, ~4.3 us, and a second hop of ~1.5 us to hand the update back; every workgroup gathering every
+        // partial -- round 1 -- moved 17.5 MB per iteration.)
         const unsigned c2 = PROF ? ticks32() : 0u;
-        unsigned long long *est_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpSums) + (size_t)(it & 1) * 16;
-        unsigned c3 = c2;
-        double nrm2 = 0.0;
-        if (blockIdx.x == 0) {
+        const int ng = min(kIcpExchangeGroups, G);  // groups = leaders; group g holds the workgroups g, g + ng, g + 2 ng, ...
+        unsigned long long *grp = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpSums) + (size_t)(it & 1) * kIcpExchangeGroups * (2 * kIcpSums);
+        const __amdgpu_buffer_rsrc_t grp_rsrc = granule_rsrc(grp, (unsigned)(kIcpExchangeGroups * 2 * kIcpSums * sizeof(unsigned long long)));
+        // poll one granule pair until both halves carry this iteration's tag; false: gave up (bounded spin, or another
+        // workgroup has already raised the timeout)
+        auto poll_pair = [&](const __amdgpu_buffer_rsrc_t &r, unsigned off, double &out) -> bool {
+            unsigned long long lo, hi;
+            granule_load_pair(r, off, lo, hi);
+            unsigned spins = 0;
+            while ((unsigned)(lo >> 32) != epoch || (unsigned)(hi >> 32) != epoch) {
+                if (PROF) ++gather_passes;
+                if (++spins > P.spin_limit ||
+                    ((spins & 255u) == 0 && (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT)))
+                    return false;
+                __builtin_amdgcn_s_sleep(2);
+                granule_load_pair(r, off, lo, hi);
+            }
+            out = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+            return true;
+        };
+        if ((int)blockIdx.x < ng) {
+            // leader: thread (k, j) fetches scalar k of the group's j-th member; 26 members per pass, all of a pass in flight
+            const int members = (G - (int)blockIdx.x + ng - 1) / ng;  // <= kIcpMaxMembers
             if (tid < kIcpParts * kIcpSums) {
-                // thread (k, part) sums scalar k over a contiguous range of workgroups, in order.  All the
-                // granules of the range (up to kGatherChunk workgroups x 2) are in flight together; every
-                // further pass re-polls, again together, exactly the ones whose tag has not arrived yet:
-                // one memory round trip per pass, however many granules are late.
-                constexpr int kGatherChunk = 10;  // >= ceil(256 / kIcpParts): one chunk per thread for any grid
-                const int k = tid % kIcpSums, part = tid / kIcpSums;
-                const int b0 = (G * part) / kIcpParts, b1 = (G * (part + 1)) / kIcpParts;
-                double v = 0.0;
-                bool fail = false;
-                for (int b = b0; b < b1 && !fail; b += kGatherChunk) {
-                    unsigned long long lo[kGatherChunk], hi[kGatherChunk];
-                    const unsigned g0 = (unsigned)(((size_t)b * kIcpSums + k) * 16);  // byte offset of {lo, hi} of scalar k of workgroup b
-                    unsigned pending = 0;
-    #pragma unroll
-                    for (int u = 0; u < kGatherChunk; ++u) {
-                        lo[u] = hi[u] = 0ull;
-                        if (b + u < b1) {
-                            granule_load_pair(gran_rsrc, g0 + (unsigned)u * (16 * kIcpSums), lo[u], hi[u]);
-                            pending |= 1u << u;
-                        }
-                    }
-    #pragma unroll
-                    for (int u = 0; u < kGatherChunk; ++u)
-                        if ((unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch) pending &= ~(1u << u);
-                    unsigned spins = 0;
-                    while (pending) {
-                        if (PROF) ++gather_passes;
-                        if (++spins > P.spin_limit ||
-                            ((spins & 255u) == 0 &&
-                             (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
-                            fail = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-    #pragma unroll
-                        for (int u = 0; u < kGatherChunk; ++u)
-                            if ((pending >> u) & 1u) granule_load_pair(gran_rsrc, g0 + (unsigned)u * (16 * kIcpSums), lo[u], hi[u]);
-    #pragma unroll
-                        for (int u = 0; u < kGatherChunk; ++u)
-                            if (((pending >> u) & 1u) && (unsigned)(lo[u] >> 32) == epoch && (unsigned)(hi[u] >> 32) == epoch)
-                                pending &= ~(1u << u);
-                    }
-                    if (fail) break;
-    #pragma unroll
-                    for (int u = 0; u < kGatherChunk; ++u)
-                        if (b + u < b1) {
-                            const double pv = __longlong_as_double(
-                                (long long)(((unsigned long long)(unsigned)hi[u] << 32) | (unsigned)lo[u]));
-                            v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-                        }
+                const int k = tid % kIcpSums;
+                for (int j = tid / kIcpSums; j < members; j += kIcpParts) {
+                    const int b = (int)blockIdx.x + ng * j;
+                    double v = 0.0;
+                    if (!poll_pair(gran_rsrc, (unsigned)(((size_t)b * kIcpSums + k) * 16), v)) sh.fail = 1;
+                    sh.range_sum[j][k] = v;
                 }
-                sh.range_sum[part][k] = v;
-                if (fail) sh.fail = 1;
             }
             __syncthreads();
-            if (sh.fail) {
-                // tell the waiting workgroups at once (they check the error word while they spin)
-                if (tid == 0) atomicOr(&st->err, E_TIMEOUT);
-                failed = true;
-                break;
-            }
-            if (tid < kIcpSums) {
+            if (tid < kIcpSums && !sh.fail) {
                 double v = 0.0;
-    #pragma unroll
-                for (int part = 0; part < kIcpParts; ++part) {
-                    const double pv = sh.range_sum[part][tid];
+                for (int j = 0; j < members; ++j) {  // member order: fixed by G alone
+                    const double pv = sh.range_sum[j][tid];
                     v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
                 }
-                sh.tot[tid] = v;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
             }
-            __syncthreads();
-            __syncthreads();
-            // ---- waves 0..3 (one per SIMD) solve the same system; the result goes through LDS -----
-            c3 = PROF ? ticks32() : 0u;
-            if (tid < kIcpSolveThreads) {
-                double S[kIcpSums];
-    #pragma unroll
-                for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
-                double JTJ[36], nb[6], dx[6];
-    #pragma unroll
-                for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
-                JTJ[0] = JTJ[7] = JTJ[14] = S[0];
-                // top-right block sum w * (-hat(s)) and its transpose
-                JTJ[0 * 6 + 4] = S[3];
-                JTJ[0 * 6 + 5] = -S[2];
-                JTJ[1 * 6 + 3] = -S[3];
-                JTJ[1 * 6 + 5] = S[1];
-                JTJ[2 * 6 + 3] = S[2];
-                JTJ[2 * 6 + 4] = -S[1];
-                JTJ[4 * 6 + 0] = S[3];
-                JTJ[5 * 6 + 0] = -S[2];
-                JTJ[3 * 6 + 1] = -S[3];
-                JTJ[5 * 6 + 1] = S[1];
-                JTJ[3 * 6 + 2] = S[2];
-                JTJ[4 * 6 + 2] = -S[1];
-                JTJ[3 * 6 + 3] = S[4];
-                JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
-                JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
-                JTJ[4 * 6 + 4] = S[7];
-                JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
-                JTJ[5 * 6 + 5] = S[9];
-    #pragma unroll
-                for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
-                ldlt6_solve(JTJ, nb, dx);
-                est = se3_exp(dx);
-    #pragma unroll
-                for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
-                if (tid == 0) {
-                    sh.est[0] = est.q[0];
-                    sh.est[1] = est.q[1];
-                    sh.est[2] = est.q[2];
-                    sh.est[3] = est.q[3];
-                    sh.est[4] = est.t[0];
-                    sh.est[5] = est.t[1];
-                    sh.est[6] = est.t[2];
-                    sh.est[7] = nrm2;
-                }
-            }
-            if (tid < 64) {  // the update, as 16 tagged granules: thread 0 has just put it in LDS (same wave)
-                group_lds_sync();
-                if (tid < 16) granule_store(est_gran + tid, epoch, reinterpret_cast<const unsigned *>(sh.est)[tid]);
-            }
-        } else {
-            if (tid < 16) {
-                unsigned long long g = granule_load(est_gran + tid);
-                unsigned spins = 0;
-                bool fail = false;
-                while ((unsigned)(g >> 32) != epoch) {
-                    if (++spins > P.spin_limit ||
-                        ((spins & 255u) == 0 &&
-                         (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
-                        fail = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    g = granule_load(est_gran + tid);
-                }
-                reinterpret_cast<unsigned *>(sh.est)[tid] = (unsigned)g;  // little-endian halves of est[0..7]
-                if (fail) sh.fail = 1;
-            }
+            __syncthreads();  // range_sum is reused below
+        }
+        // Few pollers: 224 workgroups x 152 lanes re-reading the group sums while the slowest workgroups still search
+        // slowed exactly those (their overflow voxels are read from L2 / HBM): measured, profiles/r03_g.  ONE lane per
+        // group watches the group's first granule pair; its 19 pairs leave the leader in one store instruction, so
+        // when the first has arrived the sweep below finds the rest (and polls on for any that has not).
+        if (tid < ng && !sh.fail) {
+            double dummy;
+            if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpSums) * 16), dummy)) sh.fail = 1;
+        }
+        __syncthreads();
+        if (tid < ng * kIcpSums && !sh.fail) {
+            const int k = tid % kIcpSums, g = tid / kIcpSums;
+            double v = 0.0;
+            if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpSums + k) * 16), v)) sh.fail = 1;
+            sh.range_sum[g][k] = v;
         }
         __syncthreads();
         if (sh.fail) {
+            // tell the waiting workgroups at once (they check the error word while they spin)
+            if (tid == 0) atomicOr(&st->err, E_TIMEOUT);
             failed = true;
             break;
         }
-        if (blockIdx.x != 0 || tid >= kIcpSolveThreads) {
+        if (tid < kIcpSums) {
+            double v = 0.0;
+            for (int g = 0; g < ng; ++g) {
+                const double pv = sh.range_sum[g][tid];
+                v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
+            }
+            sh.tot[tid] = v;
+        }
+        __syncthreads();
+        // ---- waves 0..3 (one per SIMD) of EVERY workgroup solve the same system; the result goes through LDS -----
+        const unsigned c3 = PROF ? ticks32() : 0u;
+        double nrm2 = 0.0;
+        if (tid < kIcpSolveThreads) {
+            double S[kIcpSums];
+#pragma unroll
+            for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
+            double JTJ[36], nb[6], dx[6];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+            JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+            // top-right block sum w * (-hat(s)) and its transpose
+            JTJ[0 * 6 + 4] = S[3];
+            JTJ[0 * 6 + 5] = -S[2];
+            JTJ[1 * 6 + 3] = -S[3];
+            JTJ[1 * 6 + 5] = S[1];
+            JTJ[2 * 6 + 3] = S[2];
+            JTJ[2 * 6 + 4] = -S[1];
+            JTJ[4 * 6 + 0] = S[3];
+            JTJ[5 * 6 + 0] = -S[2];
+            JTJ[3 * 6 + 1] = -S[3];
+            JTJ[5 * 6 + 1] = S[1];
+            JTJ[3 * 6 + 2] = S[2];
+            JTJ[4 * 6 + 2] = -S[1];
+            JTJ[3 * 6 + 3] = S[4];
+            JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+            JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+            JTJ[4 * 6 + 4] = S[7];
+            JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+            JTJ[5 * 6 + 5] = S[9];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+            ldlt6_solve(JTJ, nb, dx);
+            est = se3_exp(dx);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
+            if (tid == 0) {
+                sh.est[0] = est.q[0];
+                sh.est[1] = est.q[1];
+                sh.est[2] = est.q[2];
+                sh.est[3] = est.q[3];
+                sh.est[4] = est.t[0];
+                sh.est[5] = est.t[1];
+                sh.est[6] = est.t[2];
+                sh.est[7] = nrm2;
+            }
+        }
+        __syncthreads();
+        if (tid >= kIcpSolveThreads) {
             est.q[0] = sh.est[0];
             est.q[1] = sh.est[1];
             est.q[2] = sh.est[2];
@@ -725,7 +699,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     }
 }
 
-size_t icp_granule_words(int G) { return (size_t)2 * G * 2 * kIcpSums + 32; }  // partials, then the update (2 x 16)
+size_t icp_granule_words(int G) {  // the workgroups' partials, then the leaders' group sums; both twice (iteration parity)
+    return (size_t)2 * G * 2 * kIcpSums + (size_t)2 * kIcpExchangeGroups * 2 * kIcpSums;
+}
 
 int icp_prepare(int device_id) {
     // opt in to the full 160 KiB of LDS (dynamic regions above 64 KiB need the attribute), once per

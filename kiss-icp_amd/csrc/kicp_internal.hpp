@@ -159,7 +159,9 @@ constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 prob
 constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;  // 16
 constexpr int kIcpSolveThreads = 256;  // waves 0..3 (one per SIMD) solve the 6x6 system, the rest wait
 constexpr int kIcpBookThread = kIcpThreads - 64;  // first lane of the last wave: pose / statistics bookkeeping
-constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 threads share the gather of one scalar
+constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 (scalar, member) pairs gathered per pass by a leader
+constexpr int kIcpExchangeGroups = 8;  // leaders of the two-level exchange (workgroups 0..7)
+constexpr int kIcpMaxMembers = 32;     // workgroups per leader at most (256 / 8)
 constexpr int kIcpMaxBlocks = 256;
 constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the whole LDS
 constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time

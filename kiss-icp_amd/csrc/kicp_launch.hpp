@@ -63,6 +63,7 @@ struct DsParams {
 
 // spatial order of the source cloud (kicp_sort.hip): keys = {Morton code of the 2-voxel cell, index}, radix-sorted
 size_t tile_sort_temp_bytes(size_t n_max);
+int tile_sort_prepare(int device_id);  // LDS opt-in of the block sort, once per device
 int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_max, double voxel_size, unsigned long long *keys_in,
                      unsigned long long *keys_out, void *temp, size_t temp_bytes, hipStream_t s);
 // weights of the sorted source points (map points in the voxel each falls in under the initial guess) and their

@@ -347,29 +347,59 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
 // element walks from its home bucket; at each bucket it takes the place of an occupant that is STRICTLY closer to its
 // own home -- i.e. whose home lies further right -- and the occupant walks on by the same rule; at an empty bucket the
 // walker settles.  (Equal homes: the walker moves on, so a group of one home is rotated by an insertion in front of
-// it -- the result is NOT simply "sorted by home, then by arrival".)  One thread replays these insertions for its
-// cluster, in arrival order = ascending index of the voxel's first point; clusters hold a handful of elements (a
-// table at most half full: mean 1.1, max ~20 on a 130k-point scan), a long one is merely slow.
-__global__ __launch_bounds__(kScanThreads) void k_ds_arrange(DsParams P) {
-    const int n = count_of(P.n_ptr, P.n_imm);
-    const uint32_t mask = ref_grid_mask(n);
-    const int b = blockIdx.x * kScanThreads + threadIdx.x;
-    const bool occ = n > 0 && (uint32_t)b <= mask && P.tab[b].key != kKeyEmpty;
-    int total;
-    block_exclusive_scan(occ, total);
-    if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = total;
-    if (!occ || P.tab[((uint32_t)b - 1u) & mask].key != kKeyEmpty) return;  // not the first bucket of a cluster
-    int c = 0;
-    while (P.tab[((uint32_t)b + (uint32_t)c) & mask].key != kKeyEmpty) ++c;  // (a table at most half full has an empty bucket)
-    if (c == 1) {
-        P.rb_elem[b] = P.tab[b].minidx;
-        return;
+// it -- the result is NOT simply "sorted by home, then by arrival".)  k_ds_arrange replays these insertions cluster
+// by cluster, in arrival order = ascending index of the voxel's first point: a lone element needs nothing; a cluster of
+// 2..64 is replayed by ONE WAVE with the table in its lanes -- an insertion is two ballots and a shuffle, because
+// only the head of each home group behind the insertion point moves (to where the next group's head was); anything
+// longer (the table is at most half full: mean cluster 1.1, longest ~20 on a 130k-point scan) by one lane in memory.
+// one cluster of at most 64 buckets, replayed by one wave: lane j holds what sits at the cluster's j-th bucket
+__device__ __forceinline__ void ds_arrange_wave(const DsParams &P, uint32_t mask, int b, int c, int t, int h) {
+    const int lane = threadIdx.x & 63;
+    // arrival order: rank of this lane's element among the first-point indices (all distinct)
+    int rank = 0;
+    for (int i = 0; i < c; ++i) rank += (__shfl(t, i, 64) < t) ? 1 : 0;
+    int Et = -1, Eh = 0;  // the table being rebuilt: element (first-point index, relative home) at relative position `lane`
+    for (int k = 0; k < c; ++k) {
+        const unsigned long long who = __ballot(lane < c && rank == k);
+        const int src = __ffsll((long long)who) - 1;
+        const int zt = __shfl(t, src, 64), zh = __shfl(h, src, 64);
+        // the walker stops at the first position >= its home that is empty or whose occupant's home lies further right
+        const unsigned long long stop = __ballot(Et < 0 || Eh > zh) & (~0ull << zh);
+        const int p = __ffsll((long long)stop) - 1;
+        const unsigned long long occ = __ballot(Et >= 0);
+        if ((occ >> p) & 1ull) {
+            // occupied: the occupant -- the FIRST of its home group -- walks on past its own group and takes the place
+            // of the next group's first element, and so on up to the first empty position g.  Only group heads move.
+            const unsigned long long gt_p = (p >= 63) ? 0ull : (~0ull << (p + 1));
+            const int g = __ffsll((long long)(~occ & gt_p)) - 1;
+            const int prev_h = __shfl_up(Eh, 1, 64);
+            const unsigned long long range = (~0ull << p) & ((1ull << g) - 1ull);
+            const unsigned long long heads = __ballot(lane == p || Eh != prev_h) & range;
+            const unsigned long long recv = (heads & gt_p) | (1ull << g);
+            const unsigned long long before = heads & ((1ull << lane) - 1ull);
+            const int from = before ? 63 - __clzll((long long)before) : 0;
+            const int nt = __shfl(Et, from, 64), nh = __shfl(Eh, from, 64);
+            if ((recv >> lane) & 1ull) {
+                Et = nt;
+                Eh = nh;
+            }
+        }
+        if (lane == p) {
+            Et = zt;
+            Eh = zh;
+        }
     }
+    if (lane < c) P.rb_elem[((uint32_t)b + (uint32_t)lane) & mask] = Et;
+}
+
+// a cluster longer than a wave (an adversarial cloud: the table is at most half full): one lane replays it in global memory
+__device__ void ds_arrange_serial(const DsParams &P, uint32_t mask, int b) {
+    int c = 0;
+    while (P.tab[((uint32_t)b + (uint32_t)c) & mask].key != kKeyEmpty) ++c;
     for (int j = 0; j < c; ++j) P.rb_elem[((uint32_t)b + (uint32_t)j) & mask] = -1;
     int last = -1;
     for (int step = 0; step < c; ++step) {
-        // the next arrival: the smallest first-point index above the previous one
-        int best = 0x7FFFFFFF, bj = 0;
+        int best = 0x7FFFFFFF, bj = 0;  // the next arrival: the smallest first-point index above the previous one
         for (int j = 0; j < c; ++j) {
             const int t = P.tab[((uint32_t)b + (uint32_t)j) & mask].minidx;
             if (t > last && t < best) {
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_arrange(DsParams P) {
         last = best;
         const unsigned long long key = P.tab[((uint32_t)b + (uint32_t)bj) & mask].key;
         int cur_t = best;
-        int cur_h = (int)((ref_home(key, mask) - (uint32_t)b) & mask);  // home relative to the cluster's first bucket: 0 .. c-1
+        int cur_h = (int)((ref_home(key, mask) - (uint32_t)b) & mask);
         for (int pos = cur_h;; ++pos) {
             const uint32_t slot = ((uint32_t)b + (uint32_t)pos) & mask;
             const int et = P.rb_elem[slot];
@@ -400,11 +430,52 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_arrange(DsParams P) {
     }
 }
 
+__global__ __launch_bounds__(kScanThreads) void k_ds_arrange(DsParams P) {
+    __shared__ int wl_b[kScanThreads / 2];  // first buckets of this workgroup's clusters of two or more
+    __shared__ int wl_n;
+    const int n = count_of(P.n_ptr, P.n_imm);
+    const uint32_t mask = ref_grid_mask(n);
+    if (n <= 0 || (uint32_t)blockIdx.x * kScanThreads > mask) {  // beyond the grid: nothing here
+        if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) wl_n = 0;
+    const int b = blockIdx.x * kScanThreads + threadIdx.x;
+    const bool occ = (uint32_t)b <= mask && P.tab[b].key != kKeyEmpty;
+    int total;
+    block_exclusive_scan(occ, total);  // (contains the barrier that publishes wl_n)
+    if (threadIdx.x == 0) P.blk_counts[blockIdx.x] = total;
+    if (occ && P.tab[((uint32_t)b - 1u) & mask].key == kKeyEmpty) {  // first bucket of a cluster
+        if (P.tab[((uint32_t)b + 1u) & mask].key == kKeyEmpty) P.rb_elem[b] = P.tab[b].minidx;  // alone: nothing to settle
+        else wl_b[atomicAdd(&wl_n, 1)] = b;  // (two consecutive buckets cannot both be first buckets: at most 512)
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = wave; w < wl_n; w += kScanThreads / 64) {
+        const int cb = wl_b[w];
+        const uint32_t slot = ((uint32_t)cb + (uint32_t)lane) & mask;
+        const unsigned long long key = P.tab[slot].key;
+        const unsigned long long empties = __ballot(key == kKeyEmpty);
+        if (empties == 0ull) {  // longer than a wave
+            if (lane == 0) ds_arrange_serial(P, mask, cb);
+            continue;
+        }
+        const int c = __ffsll((long long)empties) - 1;
+        int t = 0x7FFFFFFF, h = 0;
+        if (lane < c) {
+            t = P.tab[slot].minidx;
+            h = (int)((ref_home(key, mask) - (uint32_t)cb) & mask);  // home relative to the cluster's first bucket: 0 .. c-1
+        }
+        ds_arrange_wave(P, mask, cb, c, t, h);
+    }
+}
+
 // bucket-order compaction: the survivor of bucket b goes to position (occupied buckets before b); wipes the table;
 // fused, stage A of the next downsample on the emitted point
 __global__ __launch_bounds__(kScanThreads) void k_ds_scatter_rb(DsParams P) {
     const int n = count_of(P.n_ptr, P.n_imm);
     const uint32_t mask = ref_grid_mask(n);
+    if (blockIdx.x != 0 && (n <= 0 || (uint32_t)blockIdx.x * kScanThreads > mask)) return;  // beyond the grid (its count is 0)
     const int b = blockIdx.x * kScanThreads + threadIdx.x;
     const bool occ = n > 0 && (uint32_t)b <= mask && P.tab[b].key != kKeyEmpty;
     int total, grand;
