@@ -448,7 +448,8 @@ int kicp_map::ensure_capacity(size_t incoming) {
             if (count) KICP_HIP(hipMemcpyAsync(free_ids.p, lin.data(), count * sizeof(int), hipMemcpyHostToDevice, stream));
             const int cur[3] = {0, (int)count, (int)count};
             KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FHEAD, &cur[0], sizeof(int), hipMemcpyHostToDevice, stream));
-            KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FTAIL, &cur[1], 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+            KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FTAIL, &cur[1], sizeof(int), hipMemcpyHostToDevice, stream));
+            KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FPEND, &cur[2], sizeof(int), hipMemcpyHostToDevice, stream));
             KICP_HIP(hipStreamSynchronize(stream));
         }
         blocks_cap = (int)want;
@@ -768,7 +769,7 @@ int kicp_registration_destroy(kicp_registration *r) {
     r->sort_in.release();
     r->sort_out.release();
     r->sort_tmp.release();
-    r->run_prefix.release();
+    r->run_wts.release();
     r->granules.release();
     r->state.release();
     if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -817,13 +818,9 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
             set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
             return KICP_ERR_HIP;
         }
-        KICP_TRY(r->run_prefix.reserve(n * sizeof(int)));
-        const int we = launch_tile_weights(r->sort_out.as<unsigned long long>(), r->frame.as<double>(), nullptr, (int)n, n, map->view(), st, 0, (int)options().icp_weight_base, (int)options().icp_weight_quad,
-                                           kIcpListRunMax * icp_max_blocks(r->device, (int)kIcpLdsBytesMax),
-                                           r->run_prefix.as<int>(), r->stream);
-        if (we != 0) {
-            set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
-            return KICP_ERR_HIP;
+        if (r->run_wts.bytes < n * sizeof(unsigned long long)) {  // tagged granules: a new buffer starts with tags no launch uses
+            KICP_TRY(r->run_wts.reserve(n * sizeof(unsigned long long)));
+            KICP_HIP(hipMemsetAsync(r->run_wts.p, 0, r->run_wts.bytes, r->stream));
         }
     }
     PipeState h;
@@ -833,7 +830,9 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         const int G = icp_fill_policy(r->device, P, n, cap);
         P.frame = r->frame.as<double>();
         P.order = sorted ? r->sort_out.as<unsigned long long>() : nullptr;
-        P.wprefix = sorted ? r->run_prefix.as<int>() : nullptr;
+        P.wts = sorted ? r->run_wts.as<unsigned long long>() : nullptr;
+        P.weight_base = (int)options().icp_weight_base;
+        P.weight_quad = (int)options().icp_weight_quad;
         P.work = r->work.as<double>();
         P.n_ptr = nullptr;
         P.n_imm = (int)n;
@@ -1117,7 +1116,7 @@ struct kicp_pipeline {
     DevBuf raw[2], ts[2], tmp, pre, fd[2], src[2], work, slot1, slot2, tab1, tab2, rb1, rb2, counts, granules, prof_groups, prep;
     int ds_order = 1;  // VoxelDownsample output order ("downsample_order" option, read at create)
     DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
-    DevBuf run_prefix;                      // inclusive prefix of the sorted points' weights
+    DevBuf run_wts;                         // run weights of the sorted points, one tagged granule each (written by k_icp's prologue)
     size_t sort_tmp_bytes = 0;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
@@ -1193,7 +1192,10 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(p->sort_out[1].reserve(cap * sizeof(unsigned long long)));
     p->sort_tmp_bytes = tile_sort_temp_bytes(cap);
     KICP_TRY(p->sort_tmp.reserve(p->sort_tmp_bytes));
-    KICP_TRY(p->run_prefix.reserve(cap * sizeof(int)));
+    if (p->run_wts.bytes < cap * sizeof(unsigned long long)) {  // tagged granules: a new buffer starts with tags no launch uses
+        KICP_TRY(p->run_wts.reserve(cap * sizeof(unsigned long long)));
+        KICP_HIP(hipMemsetAsync(p->run_wts.p, 0, p->run_wts.bytes, p->stream));
+    }
     KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
     if (p->ds_order) {
@@ -1457,15 +1459,10 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap);
     I.frame = p->src[par].as<double>();
     I.order = sorted ? p->sort_out[par].as<unsigned long long>() : nullptr;
-    if (sorted && n) {
-        // weights of the sorted points under this frame's initial guess (which the previous frame's registration
-        // has just left in the device state), and their prefix: runs of equal weight
-        const int we = launch_tile_weights(I.order, p->src[par].as<double>(), &prep->n_src, 0, n, m->view(), st, 1, (int)options().icp_weight_base, (int)options().icp_weight_quad, kIcpListRunMax * G, p->run_prefix.as<int>(), s);
-        if (we != 0) {
-            set_error("device scan of the run weights failed (%s)", hipGetErrorString((hipError_t)we));
-            return KICP_ERR_HIP;
-        }
-        I.wprefix = p->run_prefix.as<int>();
+    if (sorted && n) {  // runs of equal weight, settled by the kernel's own prologue
+        I.wts = p->run_wts.as<unsigned long long>();
+        I.weight_base = (int)options().icp_weight_base;
+        I.weight_quad = (int)options().icp_weight_quad;
     }
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
@@ -1748,7 +1745,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->map) kicp_map_destroy(p->map);
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
                       &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->rb1, &p->rb2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
-                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_prefix})
+                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_wts})
         b->release();
     for (int i = 0; i < 2; ++i)
         if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);

@@ -75,6 +75,158 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
 static_assert(sizeof(IcpShared) % 16 == 0 && offsetof(IcpShared, pts) % 16 == 0 && sizeof(IcpPoint) % 16 == 0,
               "the query records behind the point slots must stay 16-byte aligned");
 
+// ------------------------------------------------------------------------------------------
+// ---- runs of equal WEIGHT, settled here, inside the launch ---------------------------------------------------
+// A workgroup's tile must hold the map voxels its run can reach, and the map is far from uniform: next to the
+// sensor voxels are full, far away they hold a point or two.  Runs of equal LENGTH would need tiles of very
+// different sizes, and an iteration is as slow as its slowest workgroup; so runs are cut to equal weight, a
+// point weighing  base + c (+ c^2 / quad),  c = the population of the map voxel it falls in under the initial
+// guess.  (Until round 3 a single-workgroup kernel in front of this one computed the weights and their prefix:
+// 19 us + a dispatch gap on the frame's serial chain.)  Here: workgroup b weighs the b-th slice of L points of
+// the sorted cloud (one map lookup per point, all in flight together), publishes the weights and their sum as
+// tagged granules; every workgroup gathers the G sums -- one hop -- and reads the two slices its own run
+// boundaries fall into.  The point at sorted position q goes to workgroup floor(E[q] G / W), E the exclusive
+// prefix of the weights, W their total: integer arithmetic on data, so the partition never depends on timing.
+// Leaves the two ends of this workgroup's run in sh.run; false: a bounded wait gave up (the workgroups are not all
+// resident).  Not inlined: the kernel around it is at the limit of what the register allocator handles gracefully.
+// ------------------------------------------------------------------------------------------
+struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter block and the guess in scratch memory)
+    const double *frame;
+    const unsigned long long *order;
+    unsigned long long *wts, *granules;
+    const Slot *slots;
+    uint32_t mask;
+    double voxel_size;
+    PipeState *state;
+    int weight_base, weight_quad;
+    unsigned spin_limit;
+};
+__device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
+    IcpShared &sh = *shp;
+    const int tid = threadIdx.x;
+    MapView m;  // (only what a lookup reads)
+    m.slots = const_cast<Slot *>(P.slots);
+    m.mask = P.mask;
+    m.voxel_size = P.voxel_size;
+    PipeState *st = P.state;
+    const int L = (n + G - 1) / G;
+    const int s0 = min(n, (int)blockIdx.x * L), s1 = min(n, s0 + L);
+    if (tid == 0) sh.run[0] = sh.run[1] = 0;  // (a barrier follows before anybody reads or sets them)
+    const int quad = P.weight_quad >= 0 ? P.weight_quad : (n <= kIcpListRunMax * G ? 10 : 0);
+    long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
+    long long my_sum = 0;
+    for (int q = s0 + tid; q < s1; q += kIcpThreads) {
+        // (clamped: positions at and beyond n hold stale keys, and a load the compiler lets run ahead of the loop
+        // condition must stay inside the cloud -- without the clamp this loop faulted on the device)
+        const int p = min((int)(P.order[q] & 0xFFFFFFull), n - 1);
+        const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
+        double sp[3];
+        se3_act(guess, pin, sp);
+        const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
+        int cnt = 0;
+        if (voxel_in_range(vx, vy, vz) && map_find(m, pack_voxel(vx, vy, vz), cnt) < 0) cnt = 0;
+        const int w = P.weight_base + cnt + (quad > 0 ? (cnt * cnt) / quad : 0);
+        granule_store(P.wts + q, epoch_base, (unsigned)w);
+        my_sum += w;
+    }
+    // workgroup sum (integers: any order)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_sum += __shfl_xor(my_sum, o, 64);
+    if ((tid & 63) == 0) reinterpret_cast<long long *>(sh.part)[tid >> 6] = my_sum;
+    __syncthreads();
+    unsigned long long *sum_gran = P.granules + (size_t)G * (2 * kIcpSums);  // the partials' buffer of odd iterations; first used by iteration 1
+    const __amdgpu_buffer_rsrc_t sum_rsrc = granule_rsrc(sum_gran, (unsigned)(G * 2 * kIcpSums * sizeof(unsigned long long)));
+    if (tid == 0) {
+        long long t = 0;
+#pragma unroll
+        for (int w = 0; w < kIcpThreads / 64; ++w) t += reinterpret_cast<long long *>(sh.part)[w];
+        granule_store_pair(sum_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums) * 16), epoch_base, (unsigned)(unsigned long long)t,
+                           (unsigned)((unsigned long long)t >> 32));
+    }
+    bool pfail = false;
+    if (tid < G) {  // thread t fetches the sum of slice t
+        unsigned long long lo, hi;
+        const unsigned off = (unsigned)(((size_t)tid * kIcpSums) * 16);
+        granule_load_pair(sum_rsrc, off, lo, hi);
+        unsigned spins = 0;
+        while ((unsigned)(lo >> 32) != epoch_base || (unsigned)(hi >> 32) != epoch_base) {
+            if (++spins > P.spin_limit || ((spins & 255u) == 0 && (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT))) {
+                pfail = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            granule_load_pair(sum_rsrc, off, lo, hi);
+        }
+        x_pref[tid + 1] = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    }
+    if (tid == 0) x_pref[0] = 0;
+    if (pfail) sh.run[0] = -1;  // (no __syncthreads_or: it brings static LDS, and this kernel's 160 KiB are all dynamic)
+    __syncthreads();
+    if (sh.run[0] < 0) {  // the workgroups are not all resident: give up like a failed exchange
+        return false;
+    }
+    if (tid == 0)
+        for (int g = 0; g < G; ++g) x_pref[g + 1] += x_pref[g];  // (G <= 256 additions)
+    __syncthreads();
+    if (tid < 128) {  // wave 0: where this run starts; wave 1: where the next one does
+        const int which = tid >> 6, l = tid & 63;
+        const long long W = x_pref[G];
+        const long long target = ((long long)blockIdx.x + which) * W;  // position q lies in front of the boundary iff E[q] * G < target
+        int result;
+        if (which == 1 && (int)blockIdx.x == G - 1) {
+            result = n;
+        } else {
+            int below = 0;  // slices whose first point lies in front of the boundary
+            for (int g = l; g < G; g += 64) below += (x_pref[g] * (long long)G < target) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o, 64);
+            if (below == 0) {
+                result = 0;
+            } else {
+                const int j = below - 1;  // the boundary falls into slice j: count its points in front of it
+                const int j0 = min(n, j * L), j1 = min(n, j0 + L);
+                long long run = x_pref[j];
+                int count = 0;
+                bool wfail = false;
+                for (int qb = j0; qb < j1 && !wfail; qb += 64) {
+                    const int q = qb + l;
+                    long long w = 0;
+                    if (q < j1) {
+                        unsigned long long gq = granule_load(P.wts + q);
+                        unsigned spins = 0;
+                        while ((unsigned)(gq >> 32) != epoch_base) {
+                            if (++spins > P.spin_limit) {
+                                wfail = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                            gq = granule_load(P.wts + q);
+                        }
+                        w = (long long)(unsigned)gq;
+                    }
+                    wfail = __ballot(wfail) != 0ull;
+                    long long incl = w;  // inclusive scan of the 64 weights
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const long long up = __shfl_up(incl, o, 64);
+                        if (l >= o) incl += up;
+                    }
+                    const long long excl = run + incl - w;
+                    count += __popcll(__ballot(q < j1 && excl * (long long)G < target));
+                    run += __shfl(incl, 63, 64);
+                }
+                result = wfail ? -1 : j0 + count;
+            }
+        }
+        if (l == 0) sh.run[which] = result;
+    }
+    __syncthreads();
+    if (sh.run[0] < 0 || sh.run[1] < 0) {
+        return false;
+    }
+    return true;
+}
+
 // low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
 __device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
 
@@ -93,7 +245,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 
     // a frame whose registration timed out (workgroups not co-resident) poisons the frames queued behind
     // it: they leave the state untouched so that the host can replay from the failed frame
-    if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) return;
+    if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) {
+        // (workgroup 0 advances the tag base on EVERY path it can leave by -- also when it only started after the others
+        // had given up: the replay must never meet granules that carry this launch's tags)
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->epoch_base = st->epoch_base + (unsigned)P.max_iters + 2u;
+        return;
+    }
     if (P.inject_timeout) {  // test hook: what a launch that never became co-resident leaves behind
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicOr(&st->err, E_TIMEOUT);
@@ -113,34 +270,45 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // keys); workgroup b serves the contiguous run [b * n_run, (b + 1) * n_run) of it -- a compact patch of
     // the scene, so that the map voxels its points can reach fit in the workgroup's LDS tile.  The first
     // n_meta points of a run use the tile; any beyond that search HBM directly.
+    SE3 guess;
+    double max_dist, ks;
+    if (P.pipeline_mode) {
+        // KissICP.cpp:44-47: sigma = ComputeThreshold(); initial_guess = last_pose * last_delta
+        const double sigma = sqrt(st->model_sse / (double)st->num_samples);
+        guess = se3_mul(st->last_pose, st->last_delta);
+        max_dist = 3.0 * sigma;
+        ks = sigma;
+    } else {
+        guess = st->guess;
+        max_dist = P.max_dist;
+        ks = P.kernel_scale;
+    }
+    const unsigned epoch_base = st->epoch_base;
+    const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143 (nothing to align to: no iteration, no exchange, no runs)
     int q0, n_local;
-    if (P.wprefix && n >= kIcpWeightedMin && P.force_blocks <= 0) {
-        // runs of equal WEIGHT (kicp_sort.hip): the point at sorted position q goes to workgroup
-        // floor(E[q] * G / W), E = exclusive weight prefix, W = total weight.  Waves 0 and 1 find the two ends of
-        // this workgroup's run by a 64-ary search over the inclusive prefix (three memory round trips).
-        if (tid < 128) {
-            const int which = tid >> 6, l = tid & 63;
-            const long long total = P.wprefix[n - 1];
-            const long long target = (((long long)blockIdx.x + which) * total) / G;  // first exclusive prefix of the run / of the next run
-            int lo = 0, hi = n;  // answer = number of inclusive prefixes < target (+ 1 unless target == 0)
-            while (hi > lo) {
-                const int step = (hi - lo + 63) / 64;
-                const int idx = lo + l * step;
-                const bool less = idx < hi && (long long)P.wprefix[idx] < target;
-                const int c = __popcll(__ballot(less));
-                if (c == 0) {
-                    hi = lo;
-                } else {
-                    const int nlo = lo + (c - 1) * step + 1, nhi = min(hi, lo + c * step);
-                    lo = nlo;
-                    hi = nhi;
-                }
+    if (P.wts && P.order && n >= kIcpWeightedMin && P.force_blocks <= 0 && !map_empty) {
+        IcpRunArgs R;
+        R.frame = P.frame;
+        R.order = P.order;
+        R.wts = P.wts;
+        R.granules = P.granules;
+        R.slots = m.slots;
+        R.mask = m.mask;
+        R.voxel_size = m.voxel_size;
+        R.state = st;
+        R.weight_base = P.weight_base;
+        R.weight_quad = P.weight_quad;
+        R.spin_limit = P.spin_limit;
+        if (!icp_weighted_run(R, &sh, guess, epoch_base, n, G)) {
+            if (tid == 0) {
+                atomicOr(&st->err, E_TIMEOUT);
+                if (blockIdx.x == 0) st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
             }
-            if (l == 0) sh.run[which] = (which == 1 && (int)blockIdx.x == G - 1) ? n : (target <= 0 ? 0 : min(n, lo + 1));
+            return;
         }
-        __syncthreads();
         q0 = sh.run[0];
         n_local = max(0, sh.run[1] - q0);
+        __syncthreads();  // sh.range_sum and sh.part are reused by the iterations
     } else {
         const int n_run = (n + G - 1) / G;
         q0 = (int)blockIdx.x * n_run;
@@ -175,24 +343,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         tile.ox = tile.oy = tile.oz = 0;  // set once the first point's voxel is known
     }
     double(*terms)[kIcpTerms] = sh.terms;
-    const unsigned epoch_base = st->epoch_base;
     unsigned t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
     unsigned gather_passes = 0;
 
-    SE3 guess;
-    double max_dist, ks;
-    if (P.pipeline_mode) {
-        // KissICP.cpp:44-47: sigma = ComputeThreshold(); initial_guess = last_pose * last_delta
-        const double sigma = sqrt(st->model_sse / (double)st->num_samples);
-        guess = se3_mul(st->last_pose, st->last_delta);
-        max_dist = 3.0 * sigma;
-        ks = sigma;
-    } else {
-        guess = st->guess;
-        max_dist = P.max_dist;
-        ks = P.kernel_scale;
-    }
-    const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143
     const double inv_voxel = 1.0 / m.voxel_size;
 
     if (tid == 0) {

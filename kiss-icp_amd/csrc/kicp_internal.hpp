@@ -47,21 +47,25 @@ struct BlockHdr {
     int slot;
 };
 
+// Every counter sits in a 128-byte line of its own: the hot ones are bumped by one lane per workgroup of k_map_apply /
+// k_map_prune (returning atomics, ~12 ns each where the line lives), and three of them in ONE line made 625 workgroups
+// x 3 atomics queue up behind each other (k_map_apply: 37 us, most of it that queue -- profiles/r03_j_timeline.txt).
+constexpr int kCtrStride = 32;  // ints per counter
 enum MapCtr {
-    C_BUMP = 0,   // blocks ever carved from the pool (high-water mark)
-    C_FHEAD = 1,  // free-block queue: pop cursor (may overshoot C_FTAIL during an insert; k_map_link clamps)
-    C_LIVE = 2,   // live voxels
-    C_TOMB = 3,   // tombstoned slots
-    C_USED = 4,   // slots ever claimed since the last rehash (live + tombstones)
-    C_ERR = 5,    // sticky error bits (ErrBits)
-    C_NPTS = 6,   // scratch: point count of the last pointcloud query
-    C_TOUCHED0 = 8,  // voxel records opened by the running insert (two words used alternately:
-    C_TOUCHED1 = 9,  //   an insert counts in one and re-arms the other for the next insert)
-    C_FTAIL = 10,    // free-block queue: end of the entries an insert may pop
-    C_FPEND = 11,    // free-block queue: push cursor of RemovePointsFarFromLocation (merged into
-                     //   C_FTAIL by the next k_map_link)
-    C_DONE = 12,     // workgroups of k_map_prune that have finished (the last one writes the frame record)
-    C_COUNT = 16
+    C_BUMP = 0 * kCtrStride,   // blocks ever carved from the pool (high-water mark)
+    C_FHEAD = 1 * kCtrStride,  // free-block queue: pop cursor (may overshoot C_FTAIL during an insert; k_map_link clamps)
+    C_LIVE = 2 * kCtrStride,   // live voxels
+    C_TOMB = 3 * kCtrStride,   // tombstoned slots
+    C_USED = 4 * kCtrStride,   // slots ever claimed since the last rehash (live + tombstones)
+    C_ERR = 5 * kCtrStride,    // sticky error bits (ErrBits)
+    C_NPTS = 6 * kCtrStride,   // scratch: point count of the last pointcloud query
+    C_TOUCHED0 = 7 * kCtrStride,  // voxel records opened by the running insert (two words used alternately:
+    C_TOUCHED1 = 8 * kCtrStride,  //   an insert counts in one and re-arms the other for the next insert)
+    C_FTAIL = 9 * kCtrStride,     // free-block queue: end of the entries an insert may pop
+    C_FPEND = 10 * kCtrStride,    // free-block queue: push cursor of RemovePointsFarFromLocation (merged into
+                                  //   C_FTAIL by the next k_map_link)
+    C_DONE = 11 * kCtrStride,     // workgroups of k_map_prune that have finished (the last one writes the frame record)
+    C_COUNT = 12 * kCtrStride
 };
 
 enum ErrBits { E_RANGE = 1, E_TABLE_FULL = 2, E_POOL_FULL = 4, E_TIMEOUT = 8 };
@@ -190,7 +194,9 @@ static_assert(sizeof(IcpQueryMeta) == 64, "IcpQueryMeta layout");
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
     const unsigned long long *order;  // sorted tile keys (low 24 bits: index into frame) or nullptr (identity)
-    const int *wprefix;   // inclusive prefix of the sorted points' weights (runs of equal weight), or nullptr (equal length)
+    unsigned long long *wts;  // one tagged granule per sorted position: the point's run weight, written by k_icp's prologue
+                              // (runs of equal weight), or nullptr (runs of equal length)
+    int weight_base, weight_quad;  // a point weighs base + c (+ c^2 / quad; quad < 0: when runs are short), c = population of its voxel
     double *work;         // N x 3 transformed source, private to the launch
     const int *n_ptr;     // device count (pipeline) or nullptr
     int n_imm;            // count when n_ptr == nullptr
@@ -304,7 +310,7 @@ struct kicp_registration {
     hipStream_t stream = nullptr;
     int max_iters = 500;
     double conv = 1e-4;
-    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_prefix;
+    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_wts;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

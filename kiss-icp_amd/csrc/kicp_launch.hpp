@@ -66,11 +66,6 @@ size_t tile_sort_temp_bytes(size_t n_max);
 int tile_sort_prepare(int device_id);  // LDS opt-in of the block sort, once per device
 int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_max, double voxel_size, unsigned long long *keys_in,
                      unsigned long long *keys_out, void *temp, size_t temp_bytes, hipStream_t s);
-// weights of the sorted source points (map points in the voxel each falls in under the initial guess) and their
-// inclusive prefix: k_icp cuts the cloud into runs of equal weight
-int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
-                        const PipeState *state, int pipeline_mode, int weight_base, int weight_quad, int small_limit, int *prefix,
-                        hipStream_t s);
 int icp_prepare(int device_id);
 int icp_blocks_per_cu(int lds_bytes);
 void launch_selftest_solve(const double *A, const double *b, int n, double *x, hipStream_t s);  // co-resident k_icp workgroups per CU (occupancy query, current device)

@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256) void k_closest_neighbor(MapView m, const doubl
 __global__ __launch_bounds__(256) void k_map_link(MapView m, InsertScratch sc, const double *in, const int *n_ptr,
                                                   int n_imm, const PipeState *state, int use_pose) {
     const int n = count_of(n_ptr, n_imm);
-    int *touched = &m.ctr[C_TOUCHED0 + sc.parity];
+    int *touched = &m.ctr[C_TOUCHED0 + sc.parity * kCtrStride];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        m.ctr[C_TOUCHED0 + (sc.parity ^ 1)] = 0;  // re-arm for the next insert
+        m.ctr[C_TOUCHED0 + (sc.parity ^ 1) * kCtrStride] = 0;  // re-arm for the next insert
         // free-block queue: undo the pop cursor's overshoot of the previous insert, then admit the
         // blocks recycled since (nothing else touches these words while k_map_link runs)
         const unsigned head = (unsigned)m.ctr[C_FHEAD], tail = (unsigned)m.ctr[C_FTAIL];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
     const int lane = threadIdx.x & 31;
     const int g = threadIdx.x >> 5;
     const int half_shift = threadIdx.x & 32;  // this group's half of the 64-bit wave ballot
-    const int touched = m.ctr[C_TOUCHED0 + sc.parity];
+    const int touched = m.ctr[C_TOUCHED0 + sc.parity * kCtrStride];
     // workgroup-uniform trip count: the eight groups of a workgroup allocate their blocks together
     for (int t0 = blockIdx.x * kGroups; t0 < touched; t0 += gridDim.x * kGroups) {
         const int t = t0 + g;

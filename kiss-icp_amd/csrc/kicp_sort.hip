@@ -47,10 +47,12 @@ constexpr int kSortRun = 16384;     // keys one workgroup sorts in LDS (128 KiB)
 constexpr int kSortThreads = 1024;
 
 // run r = keys of the points [r * kSortRun, min(n, (r + 1) * kSortRun)), sorted, written to out at the same positions
+// (a cloud of one run -- any full-size-voxel scan -- goes straight to `final`: the merge passes then have nothing to do)
 __global__ __launch_bounds__(kSortThreads) void k_tile_sort_blocks(const double *xyz, const int *n_ptr, int n_imm, double inv_cell,
-                                                                   unsigned long long *out) {
+                                                                   unsigned long long *runs, unsigned long long *final) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const int n = n_ptr ? *n_ptr : n_imm;
+    unsigned long long *out = n <= kSortRun ? final : runs;
     const int first = (int)blockIdx.x * kSortRun;
     if (first >= n) return;
     const int cnt = min(kSortRun, n - first);
@@ -58,10 +60,13 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort_blocks(const double 
     while (m < cnt) m <<= 1;
     for (int i = threadIdx.x; i < m; i += kSortThreads) skeys[i] = i < cnt ? tile_key(xyz, first + i, inv_cell) : ~0ull;
     __syncthreads();
+    // Bitonic network, pair index i -> elements {lo, lo + j}.  A wave's 64 consecutive pair indices touch one aligned
+    // segment of 128 elements whenever j <= 64, and the same segment in the next such stage: those stages (70 of the
+    // 91 for 8192 keys) need ordering inside the wave only, not a workgroup barrier.
     for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < (m >> 1); i += kSortThreads) {
-                const int lo = ((i / j) * 2 * j) + (i % j), hi = lo + j;
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo + j;
                 const unsigned long long a = skeys[lo], b = skeys[hi];
                 const bool up = (lo & k) == 0;
                 if ((a > b) == up) {
@@ -69,14 +74,17 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort_blocks(const double 
                     skeys[hi] = a;
                 }
             }
-            __syncthreads();
+            if (j > 64 || (j == 1 && (k << 1) > 128)) __syncthreads();  // the next stage leaves the segment (or was the last)
+            else group_lds_sync();
         }
+    __syncthreads();
     for (int i = threadIdx.x; i < cnt; i += kSortThreads) out[first + i] = skeys[i];
 }
 
 // one merge level: runs of `run` keys -> runs of 2 * run keys; a run without a partner is handed on as it is
 __global__ __launch_bounds__(256) void k_tile_merge(const unsigned long long *in, unsigned long long *out, const int *n_ptr, int n_imm, int run) {
     const int n = n_ptr ? *n_ptr : n_imm;
+    if (n <= kSortRun) return;  // a single run: k_tile_sort_blocks has already put it where the last pass would
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long key = in[i];
         const int r = i / run, base = (r & ~1) * run;
@@ -95,152 +103,6 @@ __global__ __launch_bounds__(256) void k_tile_merge(const unsigned long long *in
         }
         out[base + (i - r * run) + smaller] = key;
     }
-}
-
-// ---- run weights -------------------------------------------------------------------------------------------
-// A workgroup's tile must hold the map voxels its run of source points can reach, and the map is far from
-// uniform: next to the sensor voxels are full (max_points_per_voxel), far away they hold a point or two.  Runs
-// of equal LENGTH would need tiles of very different sizes -- and an iteration is as slow as its slowest
-// workgroup.  So runs are cut to equal WEIGHT: a point weighs kWeightBase plus the number of map points in the
-// voxel it falls in under the initial guess (one lookup per point), and workgroup b takes the points whose
-// exclusive weight prefix lies in [b W / G, (b + 1) W / G).
-
-// weights and their inclusive prefix in ONE launch of one 1024-thread workgroup (the source cloud has a few
-// thousand points, at most ~10^5: a multi-kernel device scan would cost more in launches -- on the serial chain
-// of the frame, right in front of the registration -- than the work itself)
-__global__ __launch_bounds__(1024) void k_tile_weights_scan(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm,
-                                                            MapView m, const PipeState *state, int pipeline_mode, int weight_base, int weight_quad_in, int small_limit,
-                                                            int *prefix) {
-    __shared__ int wave_sum[16];
-    constexpr int kLdsWeights = 24576;
-    __shared__ unsigned short lds_w[kLdsWeights];  // (a weight is at most base + 255)
-    const int n = n_ptr ? *n_ptr : n_imm;
-    if (n < kIcpWeightedMin) return;  // k_icp cuts runs of equal LENGTH below this and never reads the prefix
-    const SE3 guess = pipeline_mode ? se3_mul(state->last_pose, state->last_delta) : state->guess;
-    const int t = threadIdx.x;
-    const bool in_lds = n <= kLdsWeights && weight_base <= 1024;
-    // The quadratic term (weight_quad_in < 0: automatic) is for clouds of at most small_limit points, i.e. runs of
-    // a few dozen points with full-size voxels: there a workgroup's time is its tile's overflow and the number of
-    // 16-point rounds, and dense runs must be SHORT (measured: 17.3 vs 19.8 us per iteration on the KITTI-like
-    // scene with c^2 / 10); with hundreds of points per run the per-point work dominates and the term only
-    // starves the sparse runs (1M-point configuration: 136 -> 153 us with c^2 / 16).  profiles/r02_ak, r02_al.
-    const int weight_quad = weight_quad_in >= 0 ? weight_quad_in : (n <= small_limit ? 10 : 0);
-    // pass 1 (coalesced): the weights themselves.  This launch sits on the serial chain of a frame, right in front
-    // of the registration, and a thread's lookups are chains of dependent loads (sort key -> point -> map slot):
-    // kBatch of them are kept in flight per thread, stage by stage, instead of one after the other.  (What is left
-    // of the ~19 us of this launch on a KITTI-like frame is the chain itself -- count, key, point, slot: four
-    // dependent round trips to memory written by other XCDs a moment ago -- and the launch.)
-    constexpr int kBatch = 8;
-    for (int q0 = t; q0 < n; q0 += 1024 * kBatch) {
-        int pidx[kBatch];
-        double pin[kBatch][3];
-        unsigned long long key[kBatch];
-        uint32_t sidx[kBatch];
-        int cnt[kBatch];
-        bool pend[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int q = q0 + 1024 * u;
-            pidx[u] = q < n ? (order ? (int)(order[q] & 0xFFFFFFull) : q) : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u)
-            if (pidx[u] >= 0) {
-                pin[u][0] = frame[3 * pidx[u]];
-                pin[u][1] = frame[3 * pidx[u] + 1];
-                pin[u][2] = frame[3 * pidx[u] + 2];
-            }
-        Slot first[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            cnt[u] = 0;
-            pend[u] = false;
-            first[u].key = kKeyEmpty;
-            first[u].count = 0;
-            if (pidx[u] >= 0) {
-                double sp[3];
-                se3_act(guess, pin[u], sp);
-                const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
-                if (voxel_in_range(vx, vy, vz)) {
-                    key[u] = pack_voxel(vx, vy, vz);
-                    sidx[u] = hash_key(key[u], m.mask);
-                    pend[u] = true;
-                    first[u] = load_slot(m.slots + sidx[u]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            if (pend[u]) {
-                if (first[u].key == key[u]) {
-                    cnt[u] = first[u].count;
-                } else if (first[u].key != kKeyEmpty) {  // the rare longer chain: walk it
-                    uint32_t si = (sidx[u] + 1) & m.mask;
-                    for (uint32_t probes = 1; probes <= m.mask; ++probes) {
-                        const Slot sl = load_slot(m.slots + si);
-                        if (sl.key == key[u]) {
-                            cnt[u] = sl.count;
-                            break;
-                        }
-                        if (sl.key == kKeyEmpty) break;
-                        si = (si + 1) & m.mask;
-                    }
-                }
-            }
-            const int q = q0 + 1024 * u;
-            if (q < n) {
-                // base + c + c^2 / quad: the points a run's tile must hold grow faster than linearly with the
-                // population c of the voxels around it (full voxels have full neighbours)
-                const int w = weight_base + cnt[u] + (weight_quad > 0 ? (cnt[u] * cnt[u]) / weight_quad : 0);
-                if (in_lds) lds_w[q] = (unsigned short)min(w, 0xFFFF);
-                else prefix[q] = w;
-            }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // pass 2: thread t owns the contiguous slice [t E, (t + 1) E).  Up to kLdsWeights points (any full-size-voxel
-    // scan) the weights never leave the workgroup: re-reading them from L2 point by point was most of this launch.
-    const int E = (n + 1023) / 1024;
-    const int a = min(n, t * E), b = min(n, a + E);
-    int sum = 0;
-    if (in_lds) {
-        for (int q = a; q < b; ++q) sum += (int)lds_w[q];
-    } else {
-        for (int q = a; q < b; ++q) sum += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // exclusive scan of the 1024 slice sums
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if ((t & 63) >= o) incl += up;
-    }
-    if ((t & 63) == 63) wave_sum[t >> 6] = incl;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) base += (w < (t >> 6)) ? wave_sum[w] : 0;
-    int run = base + incl - sum;
-    if (in_lds) {
-        for (int q = a; q < b; ++q) {
-            run += (int)lds_w[q];
-            prefix[q] = run;
-        }
-    } else {
-        for (int q = a; q < b; ++q) {
-            run += __hip_atomic_load(&prefix[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            prefix[q] = run;
-        }
-    }
-}
-
-int launch_tile_weights(const unsigned long long *order, const double *frame, const int *n_ptr, int n_imm, size_t n_max, const MapView &m,
-                        const PipeState *state, int pipeline_mode, int weight_base, int weight_quad, int small_limit, int *prefix,
-                        hipStream_t s) {
-    if (n_max == 0) return 0;
-    hipLaunchKernelGGL(k_tile_weights_scan, dim3(1), dim3(1024), 0, s, order, frame, n_ptr, n_imm, m, state, pipeline_mode, weight_base, weight_quad, small_limit, prefix);
-    return (int)hipGetLastError();
 }
 
 size_t tile_sort_temp_bytes(size_t) { return 256; }  // (the sort needs no scratch beyond its two key buffers)
@@ -270,7 +132,7 @@ int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_ma
     // the passes alternate between the two buffers; the block sort starts in the one that makes the last pass end in keys_out
     unsigned long long *a = (passes & 1) ? keys_in : keys_out, *b = (passes & 1) ? keys_out : keys_in;
     hipLaunchKernelGGL(k_tile_sort_blocks, dim3(runs), dim3(kSortThreads), kSortRun * sizeof(unsigned long long), s, xyz, n_ptr, n_imm,
-                       1.0 / (2.0 * voxel_size), a);
+                       1.0 / (2.0 * voxel_size), a, keys_out);
     const int grid = (int)((n_max + 255) / 256 < 1024 ? (n_max + 255) / 256 : 1024);
     for (int l = 0; l < passes; ++l) {
         hipLaunchKernelGGL(k_tile_merge, dim3(grid), dim3(256), 0, s, a, b, n_ptr, n_imm, kSortRun << l);
