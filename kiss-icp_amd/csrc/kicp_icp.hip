@@ -116,8 +116,9 @@ __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 
     long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
     long long my_sum = 0;
     for (int q = s0 + tid; q < s1; q += kIcpThreads) {
-        // (clamped: positions at and beyond n hold stale keys, and a load the compiler lets run ahead of the loop
-        // condition must stay inside the cloud -- without the clamp this loop faulted on the device)
+        // (The clamp never changes a value -- checked on the device: every key read here has index < n -- yet without it
+        // this loop raised a memory fault (ROCm 7.2, gfx950): the point load evidently also executes, at some index
+        // made of a stale key, for lanes the loop condition excludes.  With the clamp any such load stays inside the cloud.)
         const int p = min((int)(P.order[q] & 0xFFFFFFull), n - 1);
         const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
         double sp[3];
