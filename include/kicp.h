@@ -374,14 +374,15 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src
  *                     on the device: ceil(N_src / (16 * icp_points_per_group)), at most 256)
  *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 1)
- *   "icp_weight_base" 1..1024: the workgroups take contiguous runs of the spatially sorted source cloud of equal
- *                     WEIGHT, a point weighing this + the population of its voxel (default 16: on the 1M-point /
- *                     0.1 m configuration 135 us per iteration against 175 at 4 and 146 at 64, flat on the
- *                     KITTI-like one: profiles/r02_w_sweep.txt, r02_ab_sweep_weights.txt)
- *   "icp_weight_quad" the weight also carries population^2 / this.  0: never; -1 (default): / 10 when the source
- *                     cloud has at most 64 points per workgroup -- short runs, where a workgroup's time is
- *                     whether its tile fits in LDS (17.3 vs 19.8 us per iteration on the KITTI-like scene) --
- *                     and never with longer runs (1M-point configuration: worse with it)
+ *   "icp_weight_base", "icp_weight_quad", "icp_weight_dense_min", "icp_weight_dense_div"
+ *                     the workgroups of the ICP kernel take contiguous runs of the spatially sorted source cloud of equal
+ *                     WEIGHT; a point weighs  base + c + c^2 / quad + max(0, E - dense_min) / dense_div,  c = population
+ *                     of the map voxel it falls in under the initial guess, E = population of the 27 voxels around it.
+ *                     Defaults 32, -1 (= 10 when the cloud has at most 64 points per workgroup, else no quadratic term),
+ *                     200, 2 (dense_div 0 switches the last term off).  The weights decide nothing but which workgroup
+ *                     serves which points -- hence the order of the sums, deterministically (integer arithmetic on data).
+ *                     What they are tuned for: no run's voxel neighbourhood may outgrow a workgroup's LDS (~5.3 k points:
+ *                     the densest runs near the sensor), and no run may need many more 16-point rounds than the others
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)

@@ -833,6 +833,8 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         P.wts = sorted ? r->run_wts.as<unsigned long long>() : nullptr;
         P.weight_base = (int)options().icp_weight_base;
         P.weight_quad = (int)options().icp_weight_quad;
+        P.weight_dense_min = (int)options().icp_weight_dense_min;
+        P.weight_dense_div = (int)options().icp_weight_dense_div;
         P.work = r->work.as<double>();
         P.n_ptr = nullptr;
         P.n_imm = (int)n;
@@ -1463,6 +1465,8 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         I.wts = p->run_wts.as<unsigned long long>();
         I.weight_base = (int)options().icp_weight_base;
         I.weight_quad = (int)options().icp_weight_quad;
+        I.weight_dense_min = (int)options().icp_weight_dense_min;
+        I.weight_dense_div = (int)options().icp_weight_dense_div;
     }
     I.work = p->work.as<double>();
     I.n_ptr = &prep->n_src;
@@ -2356,6 +2360,12 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (the prefix sums are 32-bit)
         options().icp_weight_base = value;
+    } else if (!strcmp(name, "icp_weight_dense_min")) {
+        if (value < 0 || value > 100000) return KICP_ERR_INVALID_ARG;
+        options().icp_weight_dense_min = value;
+    } else if (!strcmp(name, "icp_weight_dense_div")) {
+        if (value < 0 || value > 1024) return KICP_ERR_INVALID_ARG;
+        options().icp_weight_dense_div = value;
     } else if (!strcmp(name, "icp_weight_quad")) {
         if (value < -1 || value > 4096) return KICP_ERR_INVALID_ARG;
         options().icp_weight_quad = value;

@@ -80,8 +80,10 @@ static_assert(sizeof(IcpShared) % 16 == 0 && offsetof(IcpShared, pts) % 16 == 0 
 // A workgroup's tile must hold the map voxels its run can reach, and the map is far from uniform: next to the
 // sensor voxels are full, far away they hold a point or two.  Runs of equal LENGTH would need tiles of very
 // different sizes, and an iteration is as slow as its slowest workgroup; so runs are cut to equal weight, a
-// point weighing  base + c (+ c^2 / quad),  c = the population of the map voxel it falls in under the initial
-// guess.  (Until round 3 a single-workgroup kernel in front of this one computed the weights and their prefix:
+// point weighing  base + c (+ c^2 / quad) + max(0, E - dense_min) / dense_div,  c = the population of the map voxel it
+// falls in under the initial guess, E = the population of the 27 voxels around it (what the reference examines for
+// it).  The last term is what keeps the densest runs inside LDS: c saturates at max_points_per_voxel, E tells a point
+// whose whole neighbourhood is full (a tile of 500 points for it alone) from one at the edge of the map.  (Until round 3 a single-workgroup kernel in front of this one computed the weights and their prefix:
 // 19 us + a dispatch gap on the frame's serial chain.)  Here: workgroup b weighs the b-th slice of L points of
 // the sorted cloud (one map lookup per point, all in flight together), publishes the weights and their sum as
 // tagged granules; every workgroup gathers the G sums -- one hop -- and reads the two slices its own run
@@ -98,7 +100,7 @@ struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter 
     uint32_t mask;
     double voxel_size;
     PipeState *state;
-    int weight_base, weight_quad;
+    int weight_base, weight_quad, dense_min, dense_div;
     unsigned spin_limit;
 };
 __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
@@ -115,7 +117,9 @@ __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 
     const int quad = P.weight_quad >= 0 ? P.weight_quad : (n <= kIcpListRunMax * G ? 10 : 0);
     long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
     long long my_sum = 0;
-    for (int q = s0 + tid; q < s1; q += kIcpThreads) {
+    // one 32-lane group per point: lane j looks up the j-th voxel of the point's 27-neighbourhood (all in flight together)
+    const int lane = tid & (kIcpGroup - 1);
+    for (int q = s0 + tid / kIcpGroup; q < s1; q += kIcpGroupsPerBlock) {
         // (The clamp never changes a value -- checked on the device: every key read here has index < n -- yet without it
         // this loop raised a memory fault (ROCm 7.2, gfx950): the point load evidently also executes, at some index
         // made of a stale key, for lanes the loop condition excludes.  With the clamp any such load stays inside the cloud.)
@@ -123,12 +127,15 @@ __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 
         const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
         double sp[3];
         se3_act(guess, pin, sp);
-        const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
-        int cnt = 0;
-        if (voxel_in_range(vx, vy, vz) && map_find(m, pack_voxel(vx, vy, vz), cnt) < 0) cnt = 0;
-        const int w = P.weight_base + cnt + (quad > 0 ? (cnt * cnt) / quad : 0);
-        granule_store(P.wts + q, epoch_base, (unsigned)w);
-        my_sum += w;
+        int rerr = 0;
+        const Probe pr = probe27(m, sp[0], sp[1], sp[2], lane, rerr);
+        const int c = __shfl(pr.cnt, 0, kIcpGroup);  // the point's own voxel (shift 0 of the table)
+        const int dense = P.dense_div > 0 ? max(0, pr.E - P.dense_min) / P.dense_div : 0;
+        const int w = P.weight_base + c + (quad > 0 ? (c * c) / quad : 0) + dense;
+        if (lane == 0) {
+            granule_store(P.wts + q, epoch_base, (unsigned)w);
+            my_sum += w;
+        }
     }
     // workgroup sum (integers: any order)
 #pragma unroll
@@ -299,6 +306,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         R.state = st;
         R.weight_base = P.weight_base;
         R.weight_quad = P.weight_quad;
+        R.dense_min = P.weight_dense_min;
+        R.dense_div = P.weight_dense_div;
         R.spin_limit = P.spin_limit;
         if (!icp_weighted_run(R, &sh, guess, epoch_base, n, G)) {
             if (tid == 0) {
