@@ -374,19 +374,20 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_blocks"      workgroups taking part in the persistent ICP kernel (0 = derive from N_src
  *                     on the device: ceil(N_src / (16 * icp_points_per_group)), at most 256)
  *   "icp_points_per_group"  target source points per 32-lane group and iteration (default 1)
- *   "icp_weight_base", "icp_weight_quad", "icp_weight_dense_min", "icp_weight_dense_div"
+ *   "icp_weight_base", "icp_weight_quad", "icp_weight_dense_min", "icp_weight_dense_div", "icp_weight_long_base"
  *                     the workgroups of the ICP kernel take contiguous runs of the spatially sorted source cloud of equal
  *                     WEIGHT; a point weighs  base + c + c^2 / quad + max(0, E - dense_min) / dense_div,  c = population
  *                     of the map voxel it falls in under the initial guess, E = population of the 27 voxels around it.
  *                     Defaults 32, -1 (= 10 when the cloud has at most 64 points per workgroup, else no quadratic term),
- *                     200, 2 (dense_div 0 switches the last term off).  The weights decide nothing but which workgroup
+ *                     200, 2 (dense_div 0 switches the last term off).  Clouds of more than 64 points per workgroup (the
+ *                     1M-point / 0.1 m configuration) use  "icp_weight_long_base" (128) + c + E  instead.  The weights decide nothing but which workgroup
  *                     serves which points -- hence the order of the sums, deterministically (integer arithmetic on data).
  *                     What they are tuned for: no run's voxel neighbourhood may outgrow a workgroup's LDS (~5.3 k points:
  *                     the densest runs near the sensor), and no run may need many more 16-point rounds than the others
  *   "icp_use_lds"     1 = stage each query's candidate voxels in LDS and reuse them across ICP
  *                     iterations (default 1)
  *   "icp_timing"      1 = bracket every ICP launch with hipEvents (default 1)
- *   "icp_lds_kib"     LDS per ICP workgroup in KiB, 64..160 (0 = all 160: one workgroup per CU)
+ *   "icp_lds_kib"     LDS per ICP workgroup in KiB, 96..160 (0 = all 160: one workgroup per CU)
  *   "icp_reserve_cus" CUs left out of the ICP grid for the front stages of the next frame, which run
  *                     concurrently on a second stream (default 32 = one per shader engine: workgroups are
  *                     handed to the shader engines in turn, so a kernel whose next workgroup falls on a

@@ -121,7 +121,11 @@ struct IcpDeviceGate {
     std::mutex mu;
     hipStream_t last_stream = nullptr;  // stream of the most recent k_icp launch on this device
     hipEvent_t ev = nullptr;            // scratch event (a wait captures the record it was issued behind)
-    int max_blocks[2] = {0, 0};         // co-resident workgroups at kIcpLdsBytesShared / kIcpLdsBytesMax
+    // co-resident workgroups per dynamic-LDS size of the launch (the occupancy query is per size: a cache keyed on
+    // anything coarser would hand a grid sized for one LDS setting to a launch with another)
+    struct Entry {
+        int lds_bytes = -1, blocks = 0;
+    } max_blocks[8];
 };
 static IcpDeviceGate &icp_gate(int device_id) {
     static IcpDeviceGate gates[64];
@@ -130,16 +134,22 @@ static IcpDeviceGate &icp_gate(int device_id) {
 static int icp_max_blocks(int device_id, int lds_bytes) {
     IcpDeviceGate &g = icp_gate(device_id);
     std::lock_guard<std::mutex> lk(g.mu);
-    const int which = lds_bytes >= kIcpLdsBytesMax ? 1 : 0;
-    if (g.max_blocks[which] == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 1;
-        int per_cu = icp_blocks_per_cu(lds_bytes);
-        if (per_cu < 1) per_cu = 1;
-        long b = (long)per_cu * cus;
-        g.max_blocks[which] = (int)(b < kIcpMaxBlocks ? b : kIcpMaxBlocks);
+    int free_slot = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (g.max_blocks[i].lds_bytes == lds_bytes) return g.max_blocks[i].blocks;
+        if (g.max_blocks[i].lds_bytes < 0) {
+            free_slot = i;
+            break;
+        }
     }
-    return g.max_blocks[which];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 1;
+    int per_cu = icp_blocks_per_cu(lds_bytes);
+    if (per_cu < 1) per_cu = 1;
+    long b = (long)per_cu * cus;
+    g.max_blocks[free_slot].lds_bytes = lds_bytes;
+    g.max_blocks[free_slot].blocks = (int)(b < kIcpMaxBlocks ? b : kIcpMaxBlocks);
+    return g.max_blocks[free_slot].blocks;
 }
 // launch k_icp on `s`, behind any k_icp another stream of this device still has in flight
 static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s) {
@@ -174,7 +184,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     // streaming kernels hidden under the registration either way).
     long lds = options().icp_lds_kib > 0 ? options().icp_lds_kib * 1024 : kIcpLdsBytesMax;
     if (lds > kIcpLdsBytesMax) lds = kIcpLdsBytesMax;
-    if (lds < 64 * 1024) lds = 64 * 1024;
+    if (lds < 96 * 1024) lds = 96 * 1024;  // (the fixed part of the layout -- records, table, chunk buffers -- needs ~88 KiB)
     P.lds_bytes = (int)lds;
     (void)n_hint;
     int grid = icp_max_blocks(device_id, P.lds_bytes);
@@ -833,6 +843,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         P.wts = sorted ? r->run_wts.as<unsigned long long>() : nullptr;
         P.weight_base = (int)options().icp_weight_base;
         P.weight_quad = (int)options().icp_weight_quad;
+        P.weight_long_base = (int)options().icp_weight_long_base;
         P.weight_dense_min = (int)options().icp_weight_dense_min;
         P.weight_dense_div = (int)options().icp_weight_dense_div;
         P.work = r->work.as<double>();
@@ -1465,6 +1476,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         I.wts = p->run_wts.as<unsigned long long>();
         I.weight_base = (int)options().icp_weight_base;
         I.weight_quad = (int)options().icp_weight_quad;
+        I.weight_long_base = (int)options().icp_weight_long_base;
         I.weight_dense_min = (int)options().icp_weight_dense_min;
         I.weight_dense_div = (int)options().icp_weight_dense_div;
     }
@@ -2342,7 +2354,7 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_timing")) {
         options().icp_timing = value;
     } else if (!strcmp(name, "icp_lds_kib")) {
-        if (value != 0 && (value < 64 || value > 160)) return KICP_ERR_INVALID_ARG;
+        if (value != 0 && (value < 96 || value > 160)) return KICP_ERR_INVALID_ARG;  // below ~88 KiB the layout has no room for a tile
         options().icp_lds_kib = value;
     } else if (!strcmp(name, "icp_reserve_cus")) {
         if (value < 0 || value > 128) return KICP_ERR_INVALID_ARG;
@@ -2360,6 +2372,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (the prefix sums are 32-bit)
         options().icp_weight_base = value;
+    } else if (!strcmp(name, "icp_weight_long_base")) {
+        if (value < 1 || value > 4096) return KICP_ERR_INVALID_ARG;
+        options().icp_weight_long_base = value;
     } else if (!strcmp(name, "icp_weight_dense_min")) {
         if (value < 0 || value > 100000) return KICP_ERR_INVALID_ARG;
         options().icp_weight_dense_min = value;

@@ -100,7 +100,7 @@ struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter 
     uint32_t mask;
     double voxel_size;
     PipeState *state;
-    int weight_base, weight_quad, dense_min, dense_div;
+    int weight_base, weight_long_base, weight_quad, dense_min, dense_div;
     unsigned spin_limit;
 };
 __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
@@ -114,7 +114,15 @@ __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 
     const int L = (n + G - 1) / G;
     const int s0 = min(n, (int)blockIdx.x * L), s1 = min(n, s0 + L);
     if (tid == 0) sh.run[0] = sh.run[1] = 0;  // (a barrier follows before anybody reads or sets them)
-    const int quad = P.weight_quad >= 0 ? P.weight_quad : (n <= kIcpListRunMax * G ? 10 : 0);
+    // Two regimes, both measured: with a few dozen points per run (full-size voxels: at most 64 points per workgroup) a
+    // workgroup's time is whether its tile fits and the number of 16-point rounds -> base + c + c^2 / 10, plus the
+    // population of the whole neighbourhood where that is large (profiles/r03_n); with hundreds of points per run (the
+    // 1M-point / 0.1 m configuration) the per-point work dominates, and that is the neighbourhood's population E -> a
+    // larger base + c + E (462 -> 547 scans/s against the short-run rule, profiles/r03_p).
+    const bool long_runs = n > kIcpListRunMax * G;
+    const int quad = P.weight_quad >= 0 ? P.weight_quad : (long_runs ? 0 : 10);
+    const int w_base = long_runs ? P.weight_long_base : P.weight_base;
+    const int dense_min = long_runs ? 0 : P.dense_min, dense_div = long_runs ? 1 : P.dense_div;
     long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
     long long my_sum = 0;
     // one 32-lane group per point: lane j looks up the j-th voxel of the point's 27-neighbourhood (all in flight together)
@@ -130,8 +138,8 @@ __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 
         int rerr = 0;
         const Probe pr = probe27(m, sp[0], sp[1], sp[2], lane, rerr);
         const int c = __shfl(pr.cnt, 0, kIcpGroup);  // the point's own voxel (shift 0 of the table)
-        const int dense = P.dense_div > 0 ? max(0, pr.E - P.dense_min) / P.dense_div : 0;
-        const int w = P.weight_base + c + (quad > 0 ? (c * c) / quad : 0) + dense;
+        const int dense = dense_div > 0 ? max(0, pr.E - dense_min) / dense_div : 0;
+        const int w = w_base + c + (quad > 0 ? (c * c) / quad : 0) + dense;
         if (lane == 0) {
             granule_store(P.wts + q, epoch_base, (unsigned)w);
             my_sum += w;
@@ -306,6 +314,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         R.state = st;
         R.weight_base = P.weight_base;
         R.weight_quad = P.weight_quad;
+        R.weight_long_base = P.weight_long_base;
         R.dense_min = P.weight_dense_min;
         R.dense_div = P.weight_dense_div;
         R.spin_limit = P.spin_limit;

@@ -86,7 +86,7 @@ def test_point_arguments_accept_arrays_and_dlpack(m):
 
 
 def test_pose_writers(tmp_path):
-    from kiss_icp_amd.pipeline import OdometryPipeline, rotation_to_quaternion_wxyz
+    from kiss_icp_amd.pipeline import rotation_to_quaternion_wxyz, save_poses_kitti_format, save_poses_tum_format
 
     rng = np.random.default_rng(3)
     rots = Rotation.from_rotvec(rng.normal(0, 1.5, (40, 3)))
@@ -100,8 +100,8 @@ def test_pose_writers(tmp_path):
         np.testing.assert_allclose(Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(), R, atol=1e-9)
     base = str(tmp_path / "seq_poses")
     stamps = 0.1 * np.arange(len(poses))
-    OdometryPipeline.save_poses_kitti_format(base, poses)
-    OdometryPipeline.save_poses_tum_format(base, poses, stamps)
+    save_poses_kitti_format(base, poses)
+    save_poses_tum_format(base, poses, stamps)
     kitti = np.loadtxt(base + "_kitti.txt")
     assert kitti.shape == (len(poses), 12)
     assert np.array_equal(kitti.reshape(-1, 3, 4), poses[:, :3, :])  # np.savetxt's default %.18e round-trips float64
