@@ -145,6 +145,38 @@ def cpu_baseline(scans, warmup, steps, cfg, thread_counts=None):
     return best, detail
 
 
+def host_communicator(n_ranks, device):
+    """a kicp_batch_comm that moves the blocks through host memory with the C-ABI's own device copies: for N streams
+    stacked on ONE device (a plumbing run on a 1-GPU box), where RCCL cannot be used"""
+    import ctypes as C
+    import threading
+
+    from kiss_icp_amd import _cabi
+
+    L = _cabi.lib()
+    barrier = threading.Barrier(n_ranks)
+    blocks = [None] * n_ranks
+
+    def all_gather(ctx, rank, d_send, d_recv, nbytes, stream):
+        try:
+            if L.kicp_device_synchronize(device):
+                return 2
+            mine = (C.c_ubyte * nbytes)()
+            if L.kicp_device_download(device, mine, d_send, nbytes):
+                return 2
+            blocks[rank] = bytes(mine)
+            barrier.wait(timeout=120)
+            joined = b"".join(blocks)
+            if L.kicp_device_upload(device, d_recv, joined, len(joined)):
+                return 2
+            barrier.wait(timeout=120)
+            return 0
+        except Exception:  # noqa: BLE001 -- nothing may propagate into the C caller
+            return 2
+
+    return _cabi.BatchComm(None, _cabi.BatchComm.INIT(0), _cabi.BatchComm.ALL_GATHER(all_gather), _cabi.BatchComm.FINALIZE(0))
+
+
 def main_in_process(args, devices, exchange):
     """N > 1 streams from ONE process: the C-ABI's batch entry (worker thread per stream inside the library, each bound to
     its GPU), poses all-gathered once per batch by RCCL called directly.  No Python and no torch in the per-frame path

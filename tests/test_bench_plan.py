@@ -51,3 +51,36 @@ def test_bench_refuses_n_gpus_on_a_box_without_them():
     assert r.returncode != 0
     assert "needs 8 GPUs" in r.stderr
     assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_has_no_undefined_module_level_names():
+    """every global name a function of bench.py loads is defined in the module (a helper deleted by an edit shows up here,
+    not in the one GPU call that would have used it)"""
+    import ast
+    import builtins
+
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    defined = set(dir(builtins))
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            defined.add(node.name)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            defined.update((a.asname or a.name).split(".")[0] for a in node.names)
+        elif isinstance(node, ast.Assign):
+            defined.update(t.id for t in node.targets if isinstance(t, ast.Name))
+        elif isinstance(node, ast.For):
+            defined.update(n.id for n in ast.walk(node.target) if isinstance(n, ast.Name))
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        local = {a.arg for a in ast.walk(fn) if isinstance(a, ast.arg)}
+        for n in ast.walk(fn):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+                local.add(n.id)
+            elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                local.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, (ast.FunctionDef, ast.Lambda)) and n is not fn:
+                if isinstance(n, ast.FunctionDef):
+                    local.add(n.name)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                local.add(n.name)
+        missing = sorted({n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)} - local - defined)
+        assert not missing, (fn.name, missing)
