@@ -399,6 +399,9 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     the pinned, device-mapped staging slot themselves; 0 = hipMemcpyAsync into HBM first
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
+ *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
+ *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
+ *                     iterations.  Results are bitwise the same either way.
  *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if
  *                     their workgroups never became co-resident (exercises the replay path)
  *   "icp_inject_timeout_skip"  ... after leaving its first M registrations alone

@@ -178,6 +178,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 1);
     P.use_lds = options().icp_use_lds != 0;
+    P.bulk_fill = options().icp_bulk_fill != 0;
     // A workgroup owns its CU: 160 KiB of LDS for the candidate pool, and its eight waves fill the CU's
     // vector register file, so nothing else runs beside it.  The front stages of the NEXT frame run
     // concurrently on a second stream; a few CUs are left out of the grid for them (they are small
@@ -2349,6 +2350,8 @@ int kicp_set_option(const char *name, long value) {
         options().icp_points_per_group = value;
     } else if (!strcmp(name, "icp_use_lds")) {
         options().icp_use_lds = value;
+    } else if (!strcmp(name, "icp_bulk_fill")) {
+        options().icp_bulk_fill = value;
     } else if (!strcmp(name, "icp_profile")) {
         options().icp_profile = value;
     } else if (!strcmp(name, "icp_timing")) {

@@ -49,6 +49,7 @@ struct IcpPoint {
 };
 static_assert(sizeof(IcpPoint) == 80, "IcpPoint layout");
 
+constexpr int kBulkFailMax = 30;  // failed cells remembered one by one; more: every query of the chunk searches the map directly
 struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records and the candidate pool follow
     double part[kIcpGroupsPerBlock][kIcpSums];
     double range_sum[kIcpMaxMembers][kIcpSums];  // leader: its members' partials; every workgroup: the group sums (rows 0..7)
@@ -68,7 +69,11 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     int tile_entries;  // occupied slots of the tile's table
     int list_entries; // entries handed out from the scan-list pool
     int run[2];       // first sorted position of this workgroup's run, and of the next workgroup's
-    int pad[1];
+    int job_count;    // tile_fill_bulk: point-fetch jobs filed so far
+    int cell_count;   // tile_fill_bulk: distinct cells to look up
+    int bulk_failed;  // tile_fill_bulk: cells that could not be entered (table full / block id beyond 24 bits)
+    unsigned bulk_ticks[8];  // (profiling build) tile_fill_bulk's phases, 10 ns ticks (5 used)
+    unsigned bulk_fail_keys[kBulkFailMax];
     double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
@@ -92,6 +97,359 @@ static_assert(sizeof(IcpShared) % 16 == 0 && offsetof(IcpShared, pts) % 16 == 0 
 // Leaves the two ends of this workgroup's run in sh.run; false: a bounded wait gave up (the workgroups are not all
 // resident).  Not inlined: the kernel around it is at the limit of what the register allocator handles gracefully.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// The first iteration's window phase, workgroup-wide (tile_fill, kicp_search.hpp, does the same query by query and stays
+// in use for the occasional query that leaves its window later).  In the first iteration EVERY query must establish
+// its window, and query by query that is a chain of dependent memory round trips per query -- lookups, then the points
+// of the voxels won, eight voxels per trip -- over two rounds of 16 groups: 21 us on average, 37 at worst
+// (profiles/r03_q_icp_probe_steady.txt).  Here all cells of all windows are looked up in ONE wave of loads (a cell
+// shared by several queries is looked up by each -- the loads cost the same round trip -- and entered once), and all
+// voxels won are fetched in a second wave, a thread per voxel.  Which voxels end up in LDS and which stay "global" when
+// the store is full may differ from the query-by-query order; results never depend on that.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
+constexpr int kBulkSetLog2 = 12, kBulkSet = 1 << kBulkSetLog2;  // slots of the set of distinct cells (a chunk has at most 64 x 64 cell instances)
+constexpr int kBulkSetBytes = kBulkSet * 6;                 // the set (u32) and the list of its members (u16)
+constexpr int kBulkJobs = (int)(sizeof(double) * kIcpTermChunk * kIcpTerms / 8);  // jobs that fit into sh.terms (8 bytes each)
+__device__ __forceinline__ bool tile_fill_bulk(MapView m, Tile tile, IcpShared *shp, int cn, IcpQueryMeta *metas, int *range_err_out, bool prof) {
+    IcpShared &sh = *shp;
+    const int tid = threadIdx.x;
+    unsigned tk = prof ? ticks32() : 0u;
+    auto stamp = [&](int ph) {
+        if (prof && tid == 0) {
+            const unsigned now = ticks32();
+            sh.bulk_ticks[ph] = now - tk;
+            tk = now;
+        }
+    };
+    unsigned *jobs = reinterpret_cast<unsigned *>(sh.terms);  // {block id | count << 24, store offset | table slot << 16}
+    int range_err = 0;
+    const int s0 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the store's end before this chunk
+    // The region holds points from the bottom and (a later chunk of a long run) the scan lists of the chunks before from
+    // the top; neither moves during a fill phase.  This routine's scratch -- the set of distinct cells, the list of its
+    // members, later the owner map -- goes right below the lists, and needs that much room above the points.
+    const unsigned lists_bytes = tile.lists ? min(2u * (unsigned)__hip_atomic_load(tile.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), tile.region_bytes) : 0u;
+    const unsigned free_top = (tile.region_bytes - lists_bytes) & ~15u;  // points end here at the latest
+    if ((unsigned)s0 * 24u + (unsigned)kBulkSetBytes > free_top) return false;  // (the whole workgroup: query by query then)
+    // ---- 1: the windows (one thread per query); the cell set is cleared ---------------------------------------------------
+    // The set of distinct cells and the list of its members live at the top of the tile's point region, which the
+    // points of phase 3 may overwrite: by then both are dead.
+    unsigned *set = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tile.points) + free_top) - kBulkSet;
+    unsigned short *cells = reinterpret_cast<unsigned short *>(set) - kBulkSet;
+    for (int i = tid; i < kBulkSet; i += kIcpThreads) set[i] = kTileEmpty;
+    if (tid == 0) sh.job_count = sh.cell_count = sh.bulk_failed = 0;
+    if (tid < cn && sh.pts[tid].flag == 1) {
+        const IcpPoint &pt = sh.pts[tid];
+        IcpQueryMeta *meta = metas + tid;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double f = pt.s[a] / m.voxel_size - (double)pt.v[a];  // position inside the voxel, [0, 1)
+            meta->v[a] = pt.v[a];
+            meta->lo[a] = (signed char)((f < kWindowMargin) ? -2 : -1);
+            meta->hi[a] = (signed char)((f > 1.0 - kWindowMargin) ? 2 : 1);
+        }
+        meta->valid = 0;       // pending; -1 as soon as any of its cells cannot be served from the tile
+        meta->list_state = 0;  // whatever list there was belongs to the old window
+    }
+    __syncthreads();
+    // ---- 2a: the DISTINCT cells of all windows that the table does not know yet (LDS only).  Neighbouring queries share
+    // most of their cells: looked up query by query the map would be asked five times for the same voxel.
+    auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key) for every in-range cell of every pending window
+        for (int idx = tid; idx < cn * 64; idx += kIcpThreads) {
+            const int qt = idx >> 6;
+            if (sh.pts[qt].flag != 1) continue;
+            const IcpQueryMeta *meta = metas + qt;
+            const int ny = meta->hi[1] - meta->lo[1] + 1, nz = meta->hi[2] - meta->lo[2] + 1, nx = meta->hi[0] - meta->lo[0] + 1;
+            const int w = idx & 63;
+            if (w >= nx * ny * nz) continue;
+            // (window sides are 3 or 4 cells, w < 64: a shift or a multiplication instead of four integer divisions)
+            const int t2 = nz == 4 ? w >> 2 : (w * 43) >> 7, iz = w - t2 * nz;
+            const int ix = ny == 4 ? t2 >> 2 : (t2 * 43) >> 7, iy = t2 - ix * ny;
+            const int ox = meta->lo[0] + ix, oy = meta->lo[1] + iy, oz = meta->lo[2] + iz;
+            const int qx = meta->v[0] + ox, qy = meta->v[1] + oy, qz = meta->v[2] + oz;
+            if (!voxel_in_range(qx, qy, qz)) {
+                if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) range_err = 1;
+                continue;
+            }
+            unsigned rkey;
+            if (!tile_rel(tile, qx, qy, qz, rkey)) {
+                metas[qt].valid = -1;  // outside the span of the relative keys
+                continue;
+            }
+            fn(qt, rkey);
+        }
+    };
+    const bool fresh = __hip_atomic_load(tile.entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;  // (the run's first chunk)
+    for_each_cell([&](int qt, unsigned rkey) {
+        const int slot = fresh ? -1 : tile_find(tile, rkey);
+        if (slot >= 0) {
+            if (__hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kTileOverflow) metas[qt].valid = -1;
+            return;
+        }
+        unsigned s = (rkey * 0x9E3779B1u) >> (32 - kBulkSetLog2);
+        bool done = false;
+        for (int probes = 0; probes < 64; ++probes) {
+            const unsigned old = atomicCAS(&set[s], kTileEmpty, rkey);
+            // (one counter update per new cell: kept wave by wave -- ballot, leader, shuffle inside this divergent loop --
+            // the phase was half as slow again, 3.7 against 2.4 us, profiles/r03_aa)
+            if (old == kTileEmpty) cells[atomicAdd(&sh.cell_count, 1)] = (unsigned short)s;
+            if (old == kTileEmpty || old == rkey) {
+                done = true;
+                break;
+            }
+            s = (s + 1) & (unsigned)(kBulkSet - 1);
+        }
+        if (!done) metas[qt].valid = -1;  // (a set this crowded: thousands of distinct cells in one chunk)
+    });
+    __syncthreads();
+    stamp(0);
+    // ---- 2b: one map lookup per distinct cell, all in flight together; occupied voxels enter the table and file a fetch job
+    const int n_cells = sh.cell_count;
+    constexpr int kBatch = 3;  // lookups a thread keeps in flight (four: the kernel starts to spill)
+    for (int jb = 0; jb < n_cells; jb += kIcpThreads * kBatch) {  // (every thread takes every trip: the counters below are kept wave by wave)
+        const int j0 = jb + tid;
+        unsigned long long key[kBatch];
+        unsigned rkey[kBatch];
+        Slot a[kBatch][kProbeAhead];
+        uint32_t hs[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int j = j0 + u * kIcpThreads;
+            rkey[u] = kTileEmpty;
+            key[u] = 0;
+            hs[u] = 0;
+            if (j < n_cells) {
+                rkey[u] = set[cells[j]];
+                key[u] = pack_voxel(tile.ox + (int)(rkey[u] >> 20), tile.oy + (int)((rkey[u] >> 10) & 1023u), tile.oz + (int)(rkey[u] & 1023u));
+                hs[u] = hash_key(key[u], m.mask);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+            for (int i = 0; i < kProbeAhead; ++i) {
+                a[u][i].key = kKeyEmpty;
+                a[u][i].block = -1;
+                a[u][i].count = 0;
+                if (rkey[u] != kTileEmpty) a[u][i] = load_slot(m.slots + ((hs[u] + i) & m.mask));
+            }
+        int blks[kBatch], cnts[kBatch];
+        bool open_any = false;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const bool done = probe_resolve(a[u], key[u], blks[u], cnts[u]);  // (an unused entry resolves at once: its slots read "empty")
+            if (!done) {
+                hs[u] = (hs[u] + kProbeAhead) & m.mask;
+                open_any = true;
+            } else {
+                key[u] = kKeyEmpty;  // closed
+            }
+        }
+        for (uint32_t probes = kProbeAhead; open_any && probes <= m.mask; probes += kProbeAhead) {  // long chains: all of a thread's together
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+                for (int i = 0; i < kProbeAhead; ++i)
+                    if (key[u] != kKeyEmpty) a[u][i] = load_slot(m.slots + ((hs[u] + i) & m.mask));
+            open_any = false;
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (key[u] == kKeyEmpty) continue;
+                if (probe_resolve(a[u], key[u], blks[u], cnts[u])) {
+                    key[u] = kKeyEmpty;
+                } else {
+                    hs[u] = (hs[u] + kProbeAhead) & m.mask;
+                    open_any = true;
+                }
+            }
+        }
+        if (prof) {  // (profiling build, and only while the loop has a single trip: the lookups apart from the entering)
+            if (n_cells <= kIcpThreads * kBatch) {
+                __syncthreads();
+                stamp(4);
+            } else if (tid == 0) {
+                sh.bulk_ticks[4] = 0;
+            }
+        }
+        // Entering: the table slot is a CAS of the lane's own; the counters (slots occupied, points asked of the store, jobs
+        // filed, the store's end) are ONE LDS atomic per wave and counter -- 64 lanes adding to the same address one by
+        // one were the longest part of this phase (8 of 11 us in a workgroup with 1500 cells, profiles/r03_z).
+        const int lane64 = tid & 63;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int blk = blks[u], cnt = cnts[u];
+            const bool occ = rkey[u] != kTileEmpty && blk >= 0 && cnt > 0;  // (an empty voxel: the table holds occupied ones only)
+            const unsigned long long om = __ballot(occ);
+            if (om == 0ull) continue;  // (the whole wave)
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)om, 0u));
+            int pre = occ ? cnt : 0;  // inclusive prefix of the points asked for
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(pre, o, 64);
+                if (lane64 >= o) pre += t;
+            }
+            const int total = __shfl(pre, 63, 64);
+            int ebase = 0, obase = 0;
+            if (lane64 == 0) {
+                ebase = atomicAdd(tile.entries, (int)__popcll(om));  // slots are reserved before they are taken: the limit holds exactly
+                obase = atomicAdd(tile.count, total);
+            }
+            ebase = __shfl(ebase, 0, 64);
+            obase = __shfl(obase, 0, 64);
+            const int off = obase + pre - (occ ? cnt : 0);
+            unsigned sidx = 0;
+            bool won = false;
+            if (occ && ebase + rank < tile.load_limit) {
+                sidx = tile_hash(tile, rkey[u]);
+                for (int probes = 0; probes < kTileMaxProbes; ++probes) {
+                    if (atomicCAS(&tile.keys[sidx], kTileEmpty, rkey[u]) == kTileEmpty) {  // (no other thread enters this key)
+                        won = true;
+                        break;
+                    }
+                    sidx = (sidx + 1) & (unsigned)tile.slots_mask;
+                }
+            }
+            bool failed = occ && !won;  // table full
+            const bool fits = won && (unsigned)(off + cnt) * 24u <= free_top && off + cnt <= 0xFFFF;
+            const bool want = fits && (unsigned)blk < 0x1000000u;
+            const unsigned long long jm = __ballot(want);
+            int jbase = 0;
+            if (jm != 0ull) {
+                if (lane64 == 0) jbase = atomicAdd(&sh.job_count, (int)__popcll(jm));
+                jbase = __shfl(jbase, 0, 64);
+            }
+            const int job = jbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(jm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)jm, 0u));
+            const bool filed = want && job < kBulkJobs;
+            if (filed) {
+                jobs[2 * job] = (unsigned)blk | ((unsigned)cnt << 24);
+                jobs[2 * job + 1] = (unsigned)off | (sidx << 16);
+            }
+            const unsigned long long fm = __ballot(filed);
+            if (fm != 0ull) {  // the store's end: offsets ascend with the lane, so the highest lane that filed holds it
+                const int end = __shfl(off + cnt, 63 - (int)__clzll(fm), 64);
+                if (lane64 == 0) atomicMax(tile.stored, end);
+            }
+            if (won && !filed) {
+                // LDS store (or the job list) full: the table remembers where the voxel is in the map instead
+                const unsigned val = (unsigned)blk < 0x1000000u ? ((unsigned)blk | ((unsigned)cnt << 24) | kTileGlobal | kTileReady) : kTileOverflow;
+                __hip_atomic_store(&tile.vals[sidx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                failed = val == kTileOverflow;
+            }
+            if (failed) {  // the queries whose windows hold this cell must search the map directly (phase 4)
+                const int f = atomicAdd(&sh.bulk_failed, 1);
+                if (f < kBulkFailMax) sh.bulk_fail_keys[f] = rkey[u];
+            }
+        }
+    }
+    __syncthreads();
+    stamp(1);
+    // ---- 3: the points of the voxels won, in one or two memory round trips for the whole workgroup.  Far from the sensor a
+    // voxel holds a point or two: fetched voxel by voxel (a 32-lane group per voxel, below) a workgroup with 400 such
+    // voxels needed three trips of 4 us.  So: a thread per POINT of the store -- owner[p] names the job whose voxel point p
+    // belongs to (written by a thread per job), consecutive lanes read consecutive points of a block -- which makes every
+    // load instruction 64 points whatever the voxels' populations.  The owner map lies at the top of the region, where
+    // the cell set was; a store that reaches up there (dense voxels next to the sensor) is filled voxel by voxel instead.
+    const int n_jobs = min(sh.job_count, kBulkJobs);
+    const int s1 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((unsigned)s1 * 24u + (unsigned)kBulkSetBytes <= free_top) {
+        unsigned short *owner = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(tile.points) + free_top - kBulkSetBytes);
+        for (int p = s0 + tid; p < s1; p += kIcpThreads) owner[p - s0] = 0xFFFFu;  // (a voxel without a job leaves a gap)
+        __syncthreads();
+        for (int j = tid; j < n_jobs; j += kIcpThreads) {
+            const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+            const int cnt = (int)(w0 >> 24), off = (int)(w1 & 0xFFFFu) - s0;
+            for (int i = 0; i < cnt; ++i) owner[off + i] = (unsigned short)j;
+        }
+        __syncthreads();
+        constexpr int kPerThread = 6;  // points a thread keeps in flight: 3072 per trip
+        for (int p0 = s0 + tid; p0 < s1; p0 += kIcpThreads * kPerThread) {
+            double2 xy[kPerThread];
+            double zz[kPerThread];
+            bool ok[kPerThread];
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u) {
+                const int p = p0 + u * kIcpThreads;
+                ok[u] = false;
+                if (p < s1) {
+                    const unsigned j = owner[p - s0];
+                    if (j != 0xFFFFu) {
+                        const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+                        const int blk = (int)(w0 & 0xFFFFFFu), i = p - (int)(w1 & 0xFFFFu);
+                        xy[u] = block_xy(m, blk)[i];
+                        zz[u] = block_z(m, blk)[i];
+                        ok[u] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u)
+                if (ok[u]) {
+                    double *q = tile.points + 3 * (p0 + u * kIcpThreads);
+                    q[0] = xy[u].x;
+                    q[1] = xy[u].y;
+                    q[2] = zz[u];
+                }
+        }
+    } else {
+        constexpr int kFly = 12;  // voxels a 32-lane group keeps in flight (lane i fetches point i: one 16-byte and one 8-byte load)
+        const int lane = tid & (kIcpGroup - 1), grp = tid / kIcpGroup;
+        for (int j0 = grp; j0 < n_jobs; j0 += kIcpGroupsPerBlock * kFly) {  // job j0 + 16 u: the groups share every trip evenly
+            double2 xy[kFly];
+            double zz[kFly];
+            int dst[kFly];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) {
+                dst[u] = -1;
+                const int j = j0 + u * kIcpGroupsPerBlock;
+                if (j < n_jobs) {
+                    const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+                    const int blk = (int)(w0 & 0xFFFFFFu), cnt = (int)(w0 >> 24), off = (int)(w1 & 0xFFFFu);
+                    if (lane < cnt) {
+                        dst[u] = off + lane;
+                        xy[u] = block_xy(m, blk)[lane];
+                        zz[u] = block_z(m, blk)[lane];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kFly; ++u)
+                if (dst[u] >= 0) {
+                    double *q = tile.points + 3 * dst[u];
+                    q[0] = xy[u].x;
+                    q[1] = xy[u].y;
+                    q[2] = zz[u];
+                }
+        }
+    }
+    __syncthreads();  // the points are in the store before their table entries say so
+    for (int j = tid; j < n_jobs; j += kIcpThreads) {
+        const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+        __hip_atomic_store(&tile.vals[w1 >> 16], (w1 & 0xFFFFu) | (w0 & 0xFF000000u) | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    stamp(2);
+    // ---- 4: the queries' verdicts ----------------------------------------------------------------------------------------
+    if (sh.bulk_failed) {  // rare: which windows hold a cell that could not be entered
+        const int nf = sh.bulk_failed;
+        for_each_cell([&](int qt, unsigned rkey) {
+            bool hit = nf > kBulkFailMax;
+            for (int f = 0; f < min(nf, kBulkFailMax); ++f) hit = hit || sh.bulk_fail_keys[f] == rkey;
+            if (hit) metas[qt].valid = -1;
+        });
+        __syncthreads();
+    }
+    if (tid < cn && sh.pts[tid].flag == 1) {
+        IcpQueryMeta *meta = metas + tid;
+        const bool ok = meta->valid != -1;
+        meta->valid = ok ? 1 : -1;
+        sh.pts[tid].flag = ok ? 0 : 2;
+    }
+    if (range_err) *range_err_out = 1;
+    __syncthreads();
+    stamp(3);
+    return true;
+}
+
 struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter block and the guess in scratch memory)
     const double *frame;
     const unsigned long long *order;
@@ -103,7 +461,7 @@ struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter 
     int weight_base, weight_long_base, weight_quad, dense_min, dense_div;
     unsigned spin_limit;
 };
-__device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
+__device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
     IcpShared &sh = *shp;
     const int tid = threadIdx.x;
     MapView m;  // (only what a lookup reads)
@@ -244,7 +602,6 @@ __device__ __noinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 
 }
 
 // low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
-__device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
 
 template <bool PROF>
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
@@ -480,7 +837,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // now and then later) establish a new one.  Kept apart from the searches: a voxel one group is
             // still fetching may be the neighbour another group is about to look for.
             const unsigned tb00 = PROF ? ticks32() : 0u;
-            if (sh.any_fill) {
+            bool bulk_done = false;
+            if (sh.any_fill && it == 0 && P.bulk_fill) {
+                int rerr = 0;
+                bulk_done = tile_fill_bulk(m, tile, &sh, cn, metas + base, &rerr, PROF);
+                if (rerr) range_err = 1;
+            }
+            if (bulk_done) {
+                if (tid == 0) sh.any_fill = 0;
+            } else if (sh.any_fill) {
                 for (int t = grp; t < cn; t += kIcpGroupsPerBlock) {
                     IcpPoint &pt = sh.pts[t];
                     if (pt.flag != 1) continue;
@@ -551,6 +916,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
                                                    (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
                     r[0] = (unsigned)(tb0 - c0) | ((unsigned)(tb - tb0) << 16);  // phase A + barrier, wait inside B
+                    if (it == 0 && P.bulk_fill && grp < 5) r[0] = (r[0] & 0xFFFFu) | (min(sh.bulk_ticks[grp], 0xFFFFu) << 16);  // groups 0..4: tile_fill_bulk's phases instead
                     r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)(td - tc) << 16);  // window phase of the chunk, search
                     r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)E << 16);  // points in the tile so far, examined
                     r[3] = (unsigned)path;

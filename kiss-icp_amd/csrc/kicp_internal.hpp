@@ -215,6 +215,7 @@ struct IcpParams {
                            // of the launched workgroups take part: ceil(n / (8 * this)))
     int force_blocks;      // > 0: exactly this many workgroups take part
     int use_lds;           // stage candidate voxels in LDS (0 disables)
+    int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int inject_timeout;    // test hook: behave like a launch whose workgroups never became co-resident
     const PrepState *prep;  // pipeline mode: this frame's counts (copied into the frame record), or nullptr
@@ -245,6 +246,7 @@ struct Options {
     long icp_blocks = 0;
     long icp_points_per_group = 1;
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
+    long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)

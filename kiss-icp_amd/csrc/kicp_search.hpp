@@ -79,17 +79,16 @@ __device__ __forceinline__ bool probe_resolve(const Slot (&a)[kProbeAhead], unsi
     }
     return done;
 }
-// the rest of a chain longer than kProbeAhead (rare at load factor <= 1/2): one slot at a time
+// the rest of a chain longer than kProbeAhead (at load factor <= 1/2 one lookup in ten or twenty): kProbeAhead slots per
+// memory round trip again -- a slot at a time, a chain of twelve cost eight dependent round trips, and a workgroup that
+// looks up a thousand cells waits for the longest of them
 __device__ __forceinline__ void probe_tail(const MapView &m, uint32_t s, unsigned long long key, int &blk, int &cnt) {
-    for (uint32_t probes = kProbeAhead; probes <= m.mask; ++probes) {
-        const Slot sl = load_slot(m.slots + s);
-        if (sl.key == key) {
-            blk = sl.block;
-            cnt = sl.count;
-            return;
-        }
-        if (sl.key == kKeyEmpty) return;
-        s = (s + 1) & m.mask;
+    for (uint32_t probes = kProbeAhead; probes <= m.mask; probes += kProbeAhead) {
+        Slot a[kProbeAhead];
+#pragma unroll
+        for (int i = 0; i < kProbeAhead; ++i) a[i] = load_slot(m.slots + ((s + i) & m.mask));
+        if (probe_resolve(a, key, blk, cnt)) return;
+        s = (s + kProbeAhead) & m.mask;
     }
 }
 __device__ __forceinline__ int map_find(const MapView &m, unsigned long long key, int &count) {

@@ -7,7 +7,10 @@ export TMPDIR=/tmp
 T="${TAG:-r03_q}"
 O=gpurun_out
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 ) > $O/${T}_smoke.log
-( timeout 600 python -m pytest tests -m gpu -q --timeout 200 --durations=8 2>&1 | tail -30 ) > $O/${T}_pytest_gpu.log
+( timeout 600 python -m pytest tests -m gpu -q --timeout 200 --durations=8 --tb=short 2>&1 | tail -${PYTEST_TAIL:-30} ) > $O/${T}_pytest_gpu.log
+# STOP_ON_FAIL=1: a red suite ends the call here (GPU minutes are for the fix, not for profiles of a wrong kernel)
+if [ "${STOP_ON_FAIL:-0}" = 1 ] && ! grep -q " passed" $O/${T}_pytest_gpu.log; then cat $O/${T}_pytest_gpu.log; exit 1; fi
+if [ "${STOP_ON_FAIL:-0}" = 1 ] && grep -q " failed" $O/${T}_pytest_gpu.log; then cat $O/${T}_pytest_gpu.log; exit 1; fi
 # the driver's own command, first thing a fresh process does on the device
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${T}_bench_20_5.json 2> $O/${T}_bench_20_5.err
 # the steady-state map
@@ -17,7 +20,7 @@ timeout 400 python3 bench.py --gpus 1 --steps 200 --warmup 10 > $O/${T}_bench_20
 f=$(find $O/${T}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/${T}_kernel_stats.csv
 rm -rf $O/${T}_prof
 # HBM traffic (PMC), separate passes, corrected by a known-size copy on this box
-for wl in kitti livox; do
+for wl in kitti $([ "${LEAN:-0}" = 1 ] || echo livox); do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     d=$O/${T}_pmc_${wl}_${ctr}
     st=60; wu=10; [ $wl = livox ] && { st=12; wu=4; }

@@ -38,6 +38,17 @@ if gp.size:
             print('   %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (
                 nm, g[:, j].mean() / 100, np.percentile(g[:, j], 50) / 100, np.percentile(g[:, j], 99) / 100, g[:, j].max() / 100))
         print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (g[:, 4].mean(), g[:, 4].max(), g[:, 5].mean(), g[:, 5].max()))
+        if it == 0 and int(opts.get('icp_bulk_fill', 1)):
+            ph = g.reshape(-1, 16, g.shape[1])[:, 0:5, 1] / 100.0  # groups 0..4 carry tile_fill_bulk's phases in the xform field (4: the lookups alone)
+            for j, nm in enumerate(('windows+dedup', 'enter (+lookups)', 'fetch', 'verdicts', 'lookups alone')):
+                print('   bulk fill %-14s mean %6.2f  p50 %6.2f  max %6.2f us' % (nm, ph[:, j].mean(), np.percentile(ph[:, j], 50), ph[:, j].max()))
+            gw = g.reshape(-1, 16, g.shape[1])
+            tot_w = ph[:, 0:4].sum(axis=1) + ph[:, 4]
+            for w in np.argsort(-tot_w)[:8]:
+                print('      wg %3d: dedup %5.2f lookups %5.2f enter %5.2f fetch %5.2f verdicts %5.2f us   run %3d points, tile %4d points' % (
+                    w, ph[w, 0], ph[w, 4], ph[w, 1], ph[w, 2], ph[w, 3], gw[w, 0, 7], gw[w, :, 4].max()))
+            print('      correlation of the fill time with run points %.2f, with tile points %.2f' % (
+                np.corrcoef(tot_w, gw[:, 0, 7])[0, 1], np.corrcoef(tot_w, gw[:, :, 4].max(axis=1))[0, 1]))
         worst = np.argsort(-tot)[:6]
         for w in worst:
             print('   slow group %4d (wg %3d): wait %5.2f xform %5.2f fill %5.2f scan %5.2f us staged %4d examined %4d path %d' % (
