@@ -315,6 +315,41 @@ def test_icp_without_lds_staging(gpu, O):
     assert dt < TIGHT and dr < TIGHT
 
 
+@pytest.mark.parametrize("blocks", [0, 1, 16])
+def test_first_iteration_window_phase_is_bitwise_neutral(gpu, O, blocks):
+    """icp_bulk_fill: in the first iteration the workgroup establishes all windows together (distinct cells, one wave of
+    lookups, one of point fetches) instead of query by query.  Which voxels end up in LDS may differ, results may not:
+    same pose bit for bit, same counts -- with the default partition, with ONE workgroup taking all 2500 points (40
+    chunks: the table and the store fill up, later chunks find scan lists at the top of the region) and with 16."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(72)
+    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
+    world = random_cloud(rng, 30000, extent=25.0, z_extent=3.0)
+    g.add_points(world)
+    o.add_points(world)
+    src = world[rng.choice(len(world), 2500, replace=False)] + rng.normal(0, 0.03, (2500, 3))
+    guess = make_pose((0.2, -0.1, 0.02), (0.002, -0.001, 0.01))
+    out = {}
+    try:
+        _cabi.set_option("icp_blocks", blocks)
+        for bulk in (1, 0):
+            _cabi.set_option("icp_bulk_fill", bulk)
+            r = Registration(500, 1e-4)
+            out[bulk] = (r.align_points_to_map(src, g, guess, 3.0, 1.0), dict(r.last_stats))
+    finally:
+        _cabi.set_option("icp_bulk_fill", 1)
+        _cabi.set_option("icp_blocks", 0)
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
+        assert out[0][1][k] == out[1][1][k], k
+    To = O.Registration(500, 1e-4).align_points_to_map(src, o, guess, 3.0, 1.0)
+    dt, dr = pose_error(To, out[1][0])
+    assert dt < TIGHT and dr < TIGHT
+
+
 # ---- robustness ---------------------------------------------------------------------------------------------
 def test_two_pipelines_on_one_gpu_from_two_threads(gpu, O):
     """two LiDAR streams, two pipelines, two host threads, ONE GPU: the persistent registration kernels of the
