@@ -399,6 +399,10 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     the pinned, device-mapped staging slot themselves; 0 = hipMemcpyAsync into HBM first
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
+ *   "downsample_order"  order in which VoxelDownsample emits its survivors: 1 (default) = the reference's, i.e. the bucket
+ *                     order of the tsl::robin_map 1.4.0 it collects them in (VoxelUtils.cpp:7-21); 0 = ascending point index
+ *                     (rounds 1-2).  The order decides which points AddPoints' first-come rule and the second downsample
+ *                     keep: the two trajectories differ by centimetres
  *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
  *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
  *                     iterations.  Results are bitwise the same either way.

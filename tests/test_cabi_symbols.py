@@ -161,3 +161,28 @@ def test_staging_narrowing_is_lossless_or_refused():
     assert exact == 1 and np.array_equal(np.signbit(out), np.signbit(special)) and np.array_equal(out.astype(np.float64), special)
     for v in (np.nan, 1e39, -1e39, 1e-46, 0.1, 16777217.0):
         assert narrow(np.array([1.0, v, 2.0]))[1] == 0, v
+
+
+def test_every_tuning_knob_is_documented_and_every_documented_knob_exists(cabi):
+    """include/kicp.h lists the names kicp_set_option takes; the library's setter is the other side of that list.
+    Both directions: a knob added without a word in the header, or documented and gone, fails here.  Each name is also
+    SET (to a value its range admits) and an unknown one refused, on a box without a GPU."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "kicp.h")).read()
+    source = open(os.path.join(root, "kiss-icp_amd", "csrc", "kicp_api.hip")).read()
+    documented = set(re.findall(r'"([a-z0-9_]+)"', header[header.index("tuning knobs"):]))
+    implemented = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', source))
+    assert documented == implemented, (sorted(documented - implemented), sorted(implemented - documented))
+    legal = {"icp_blocks": 0, "icp_points_per_group": 1, "icp_lds_kib": 0, "icp_reserve_cus": 32, "staging_threads": 3,
+             "downsample_order": 1, "icp_weight_base": 32, "icp_weight_long_base": 128, "icp_weight_dense_min": 200,
+             "icp_weight_dense_div": 2, "icp_weight_quad": -1, "queue_depth": 4, "map_apply_threads": 512,
+             "icp_inject_timeout": 0, "icp_inject_timeout_skip": 0, "map_rehash_every": 0, "icp_profile": 0}
+    L = cabi.lib()
+    for name in sorted(implemented):
+        assert L.kicp_set_option(name.encode(), legal.get(name, 1)) == 0, name
+    assert L.kicp_set_option(b"icp_lds_kib", 64) == 1  # below what the kernel's LDS layout needs
+    assert L.kicp_set_option(b"queue_depth", 1) == 1
+    assert L.kicp_set_option(b"downsample_order", 2) == 1
