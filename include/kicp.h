@@ -378,8 +378,8 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     the workgroups of the ICP kernel take contiguous runs of the spatially sorted source cloud of equal
  *                     WEIGHT; a point weighs  base + c + c^2 / quad + max(0, E - dense_min) / dense_div,  c = population
  *                     of the map voxel it falls in under the initial guess, E = population of the 27 voxels around it.
- *                     Defaults 32, -1 (= 10 when the cloud has at most 64 points per workgroup, else no quadratic term),
- *                     200, 2 (dense_div 0 switches the last term off).  Clouds of more than 64 points per workgroup (the
+ *                     Defaults 128, -1 (= 10 when the cloud has at most 64 points per workgroup, else no quadratic term),
+ *                     200, 1 (dense_div 0 switches the last term off).  Clouds of more than 64 points per workgroup (the
  *                     1M-point / 0.1 m configuration) use  "icp_weight_long_base" (128) + c + E  instead.  The weights decide nothing but which workgroup
  *                     serves which points -- hence the order of the sums, deterministically (integer arithmetic on data).
  *                     What they are tuned for: no run's voxel neighbourhood may outgrow a workgroup's LDS (~5.3 k points:

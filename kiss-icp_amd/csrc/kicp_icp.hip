@@ -474,7 +474,10 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     if (tid == 0) sh.run[0] = sh.run[1] = 0;  // (a barrier follows before anybody reads or sets them)
     // Two regimes, both measured: with a few dozen points per run (full-size voxels: at most 64 points per workgroup) a
     // workgroup's time is whether its tile fits and the number of 16-point rounds -> base + c + c^2 / 10, plus the
-    // population of the whole neighbourhood where that is large (profiles/r03_n); with hundreds of points per run (the
+    // population of the whole neighbourhood where that is large (profiles/r03_n).  The base (128, with the last term
+    // undivided) is what bounds the LENGTH of the sparse runs: a search costs ~1.3 + 0.85 us per round of 16 points
+    // whatever the tile holds, and with base 32 the sparsest runs were 41-51 points -- four rounds against one for the
+    // dense ones (profiles/r03_ae: 16.4 -> 15.2 us per iteration).  With hundreds of points per run (the
     // 1M-point / 0.1 m configuration) the per-point work dominates, and that is the neighbourhood's population E -> a
     // larger base + c + E (462 -> 547 scans/s against the short-run rule, profiles/r03_p).
     const bool long_runs = n > kIcpListRunMax * G;

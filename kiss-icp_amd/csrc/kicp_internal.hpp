@@ -255,10 +255,10 @@ struct Options {
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
-    long icp_weight_base = 32;   // run boundaries: a source point weighs this + the population of its voxel
+    long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + E)
     long icp_weight_dense_min = 200;  // ... + (population of its 27 voxels - this) / icp_weight_dense_div when positive
-    long icp_weight_dense_div = 2;    //     (0: off)
+    long icp_weight_dense_div = 1;    //     (0: off)
     long icp_weight_quad = -1;   // the weight also carries population^2 / this; 0: never; -1: when runs are short (kicp_sort.hip)
     long icp_inject_timeout = 0; // test hook: the first N registrations of a new pipeline give up at once
     long icp_inject_timeout_skip = 0;  // ... after this many registrations that are left alone

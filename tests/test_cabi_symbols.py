@@ -177,8 +177,8 @@ def test_every_tuning_knob_is_documented_and_every_documented_knob_exists(cabi):
     implemented = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', source))
     assert documented == implemented, (sorted(documented - implemented), sorted(implemented - documented))
     legal = {"icp_blocks": 0, "icp_points_per_group": 1, "icp_lds_kib": 0, "icp_reserve_cus": 32, "staging_threads": 3,
-             "downsample_order": 1, "icp_weight_base": 32, "icp_weight_long_base": 128, "icp_weight_dense_min": 200,
-             "icp_weight_dense_div": 2, "icp_weight_quad": -1, "queue_depth": 4, "map_apply_threads": 512,
+             "downsample_order": 1, "icp_weight_base": 128, "icp_weight_long_base": 128, "icp_weight_dense_min": 200,
+             "icp_weight_dense_div": 1, "icp_weight_quad": -1, "queue_depth": 4, "map_apply_threads": 512,
              "icp_inject_timeout": 0, "icp_inject_timeout_skip": 0, "map_rehash_every": 0, "icp_profile": 0}
     L = cabi.lib()
     for name in sorted(implemented):
