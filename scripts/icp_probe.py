@@ -10,6 +10,7 @@ opts = dict(a.split('=') for a in sys.argv[1:])
 street = opts.pop('street', '0') == '1'  # street=1: round 1's bare street scene
 livox = opts.pop('livox', '0') == '1'    # livox=1: the 1M-point / 0.1 m configuration
 frames = int(opts.pop('frames', '0'))    # frames=N: drive N frames first (default 30 / 20 / 14)
+csv = opts.pop('csv', '')                 # csv=PATH: one row per workgroup of the last launch (for fitting the run weights)
 opts.setdefault('icp_profile', '1')
 for k, v in opts.items():
     _cabi.set_option(k, int(v))
@@ -69,3 +70,17 @@ if gp.size:
     order = np.argsort(-wg_t)
     for w in list(order[:12]) + list(order[used.sum() // 2: used.sum() // 2 + 4]) + list(order[used.sum() - 6: used.sum()]):
         print('   wg %3d: %6.2f us  run %4d points  tile %5d points  examined/first point %5.1f' % (w, wg_t[w], wg_n[w], wg_staged[w], wg_ex[w]))
+
+    if csv:
+        # per workgroup, a later iteration: what a weight rule can see (run points, tile points, examined points) against
+        # what it is meant to equalise (search time of the slowest group, window phase of the first iteration)
+        it = min(6, gp.shape[0] - 1)
+        g6, g0 = gp[it].reshape(-1, 16, 9), gp[0].reshape(-1, 16, 9)
+        with open(csv, 'w') as f:
+            f.write('wg,run_points,tile_points,examined_mean,examined_max,search_us_slowest_group,search_us_mean_group,fill0_us\n')
+            for w in range(g6.shape[0]):
+                if g6[w, 0, 7] == 0:
+                    continue
+                f.write('%d,%d,%d,%.1f,%d,%.2f,%.2f,%.2f\n' % (w, g6[w, 0, 7], g6[w, :, 4].max(), g6[w, :, 5].mean(), g6[w, :, 5].max(),
+                                                              g6[w, :, 8].max() / 100.0, g6[w, :, 8].mean() / 100.0, g0[w, :, 2].max() / 100.0))
+        print('wrote', csv)
