@@ -95,17 +95,24 @@ static_assert(sizeof(IcpShared) % 16 == 0 && offsetof(IcpShared, pts) % 16 == 0 
 // boundaries fall into.  The point at sorted position q goes to workgroup floor(E[q] G / W), E the exclusive
 // prefix of the weights, W their total: integer arithmetic on data, so the partition never depends on timing.
 // Leaves the two ends of this workgroup's run in sh.run; false: a bounded wait gave up (the workgroups are not all
-// resident).  Not inlined: the kernel around it is at the limit of what the register allocator handles gracefully.
+// resident).  (Inlined, like the window phase below: as functions of their own the two cost 3-6 us per call -- the
+// registers live around the call go to scratch memory and back, 11 MB of writes per launch -- profiles/r03_t, r03_ac.)
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // The first iteration's window phase, workgroup-wide (tile_fill, kicp_search.hpp, does the same query by query and stays
-// in use for the occasional query that leaves its window later).  In the first iteration EVERY query must establish
-// its window, and query by query that is a chain of dependent memory round trips per query -- lookups, then the points
-// of the voxels won, eight voxels per trip -- over two rounds of 16 groups: 21 us on average, 37 at worst
-// (profiles/r03_q_icp_probe_steady.txt).  Here all cells of all windows are looked up in ONE wave of loads (a cell
-// shared by several queries is looked up by each -- the loads cost the same round trip -- and entered once), and all
-// voxels won are fetched in a second wave, a thread per voxel.  Which voxels end up in LDS and which stay "global" when
-// the store is full may differ from the query-by-query order; results never depend on that.
+// in use for the occasional query that leaves its window later, and for chunks whose region has no room for this
+// routine's scratch).  In the first iteration EVERY query must establish its window, and query by query that is a chain
+// of dependent memory round trips per query -- lookups, then the points of the voxels won, eight voxels per trip -- over
+// two or three rounds of 16 groups: 21 us on average, 37 at worst (profiles/r03_q_icp_probe_steady.txt).  Here, between
+// barriers: (1) a thread per query writes its window; (2a) a thread per window cell enters the cell into a set of
+// DISTINCT cells in LDS (neighbouring queries share most of theirs); (2b) a thread per distinct cell looks it up in the
+// map -- one wave of loads for the workgroup -- and enters the occupied ones into the tile's table, filing a fetch job
+// each; (3) a thread per POINT of the store fetches it -- one more wave; (4) the entries are published and the queries
+// get their verdicts.  10 us on average, 18 at worst (profiles/r03_ac_icp_probe_steady.txt).  Which voxels end up in LDS
+// and which stay "global" when the store is full may differ from the query-by-query order; results never depend on
+// that (tests/test_gpu_paths.py::test_first_iteration_window_phase_is_bitwise_neutral).
+// (LDS is 160 KiB: the store holds fewer than 7 k points, so the 12 k entries of the owner map and the 16-bit job
+// and slot indices below always suffice.)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ticks32() { return (unsigned)wall_clock64(); }
 constexpr int kBulkSetLog2 = 12, kBulkSet = 1 << kBulkSetLog2;  // slots of the set of distinct cells (a chunk has at most 64 x 64 cell instances)
