@@ -406,6 +406,13 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
  *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
  *                     iterations.  Results are bitwise the same either way.
+ *   "icp_wide"        form of the registration's association phase: 0 = a 32-lane group per source point (a few dozen points
+ *                     per workgroup, neighbourhoods of hundreds of map points: full-size voxels); 1 = a thread per source
+ *                     point (hundreds of points per workgroup: small voxels, large clouds); -1 (default) = by the size of
+ *                     the cloud (more than 64 points per workgroup -> 1).  The pose is bitwise the same either way.
+ *   "icp_wide_prune"  thread-per-point form: 0 = visit every occupied voxel of the 27; 1 = skip voxels whose box lies farther
+ *                     than the best candidate / the correspondence threshold; 2 (default) = also bounded by the previous
+ *                     iteration's neighbour.  Exact: skipped voxels lose every comparison of VoxelHashMap.cpp:58-63 anyway.
  *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if
  *                     their workgroups never became co-resident (exercises the replay path)
  *   "icp_inject_timeout_skip"  ... after leaving its first M registrations alone

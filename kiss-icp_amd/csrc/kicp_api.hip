@@ -160,7 +160,7 @@ static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profil
         KICP_HIP(hipEventRecord(g.ev, g.last_stream));
         KICP_HIP(hipStreamWaitEvent(s, g.ev, 0));
     }
-    launch_icp(P, grid, profile, s);
+    launch_icp(P, grid, profile, P.use_wide != 0, s);
     g.last_stream = s;
     return KICP_OK;
 }
@@ -187,12 +187,17 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     if (lds > kIcpLdsBytesMax) lds = kIcpLdsBytesMax;
     if (lds < 96 * 1024) lds = 96 * 1024;  // (the fixed part of the layout -- records, table, chunk buffers -- needs ~88 KiB)
     P.lds_bytes = (int)lds;
-    (void)n_hint;
     int grid = icp_max_blocks(device_id, P.lds_bytes);
     const int reserve = (int)options().icp_reserve_cus;
     if (grid > 4 * reserve) grid -= reserve;
     if (cap > 0 && cap < grid) grid = cap;
     if (P.force_blocks > grid) P.force_blocks = grid;
+    // Which form of the association: a 32-lane group per source point (few points per workgroup, neighbourhoods of
+    // hundreds of map points) or a thread per source point (kicp_icp_wide.hpp: hundreds of points per workgroup).  Both
+    // give the same pose bit for bit, so going by a HINT of the cloud's size (the previous frame's) is safe.
+    const long per_wg = (long)(n_hint / (size_t)(P.force_blocks > 0 ? P.force_blocks : grid));
+    P.use_wide = options().icp_wide >= 0 ? (options().icp_wide != 0) : (per_wg > kIcpListRunMax);
+    P.wide_prune = (int)options().icp_wide_prune;
     return grid;
 }
 
@@ -2352,6 +2357,12 @@ int kicp_set_option(const char *name, long value) {
         options().icp_use_lds = value;
     } else if (!strcmp(name, "icp_bulk_fill")) {
         options().icp_bulk_fill = value;
+    } else if (!strcmp(name, "icp_wide")) {
+        if (value < -1 || value > 1) return KICP_ERR_INVALID_ARG;
+        options().icp_wide = value;
+    } else if (!strcmp(name, "icp_wide_prune")) {
+        if (value < 0 || value > 2) return KICP_ERR_INVALID_ARG;
+        options().icp_wide_prune = value;
     } else if (!strcmp(name, "icp_profile")) {
         options().icp_profile = value;
     } else if (!strcmp(name, "icp_timing")) {

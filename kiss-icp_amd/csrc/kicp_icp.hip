@@ -611,9 +611,13 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     return true;
 }
 
-// low 32 bits of the 100 MHz wall clock (enough for differences inside one launch)
+}  // namespace kicp
+#include "kicp_icp_wide.hpp"
+namespace kicp {
 
-template <bool PROF>
+// WIDE: the association phases of kicp_icp_wide.hpp (a thread per source point) instead of the 32-lane groups below;
+// everything else -- runs, the order of additions, exchange, solve -- is shared, so both forms give the same pose bit for bit.
+template <bool PROF, bool WIDE>
 __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (all LDS is carved from the dynamic region: a static __shared__ in front of it would
@@ -700,16 +704,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         q0 = (int)blockIdx.x * n_run;
         n_local = max(0, min(n_run, n - q0));
     }
-    const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, kIcpMaxMeta) : 0;
-    const bool use_lists = n_meta > 0 && n_local <= kIcpListRunMax;
+    const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, WIDE ? kWideChunk : kIcpMaxMeta) : 0;
+    const bool use_lists = !WIDE && n_meta > 0 && n_local <= kIcpListRunMax;
     // LDS behind the fixed part: only as many point slots of a chunk as the run can fill (a run of 16 points leaves
     // 9 KiB of the 128 to the tile), then the query records, the table, and the region of points and lists
-    const size_t head_bytes = offsetof(IcpShared, pts) + (size_t)min(kIcpChunk, max(n_local, 1)) * sizeof(IcpPoint);
+    // (WIDE: all of sh.pts stays -- the slow-path queue and, with sh.terms, phase C's rows; 20-byte query records)
+    const size_t head_bytes = WIDE ? sizeof(IcpShared) : offsetof(IcpShared, pts) + (size_t)min(kIcpChunk, max(n_local, 1)) * sizeof(IcpPoint);
     IcpQueryMeta *metas = reinterpret_cast<IcpQueryMeta *>(smem + head_bytes);
+    WideMeta *wmetas = reinterpret_cast<WideMeta *>(smem + head_bytes);
     Tile tile;
     {
-        char *q = smem + head_bytes + (size_t)n_meta * sizeof(IcpQueryMeta);
-        const int slots = n_local <= kIcpListRunMax ? kIcpTileSlots / 2 : kIcpTileSlots;
+        char *q = smem + head_bytes + (WIDE ? (((size_t)n_meta * sizeof(WideMeta) + 15) & ~(size_t)15) : (size_t)n_meta * sizeof(IcpQueryMeta));
+        const int slots = (!WIDE && n_local <= kIcpListRunMax) ? kIcpTileSlots / 2 : kIcpTileSlots;
         tile.slots_mask = slots - 1;
         tile.hash_shift = slots == kIcpTileSlots ? 20 : 21;
         tile.load_limit = (slots * 3) / 4;
@@ -754,11 +760,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
     }
-    for (int i = tid; i < n_meta; i += kIcpThreads) {
-        metas[i].valid = 0;
-        metas[i].list_state = 0;
-        metas[i].list_base = 0;
-        metas[i].list_n = metas[i].list_cap = 0;
+    if constexpr (WIDE) {
+        for (int i = tid; i < n_meta; i += kIcpThreads) {
+            wmetas[i].valid = 0;
+            wmetas[i].list_state = 0;
+        }
+    } else {
+        for (int i = tid; i < n_meta; i += kIcpThreads) {
+            metas[i].valid = 0;
+            metas[i].list_state = 0;
+            metas[i].list_base = 0;
+            metas[i].list_n = metas[i].list_cap = 0;
+        }
     }
     if (n_meta > 0)
         for (int i = tid; i <= tile.slots_mask; i += kIcpThreads) {
@@ -771,6 +784,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     int iterations = 0, converged = 0;
     int range_err = 0;
     bool failed = false;
+    WideQuery wq;  // (WIDE) this thread's query: kept in registers from iteration to iteration when the run is a single chunk
+    wq.have_nn = false;
+    wq.flag = 2;
+    wq.E = 0;
+    wq.d2 = DBL_MAX;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        wq.s[a] = wq.nn[a] = 0.0;
+        wq.v[a] = wq.pv[a] = 0;
+    }
 
     const int max_iters = map_empty ? 0 : P.max_iters;
     for (int it = 0; it < max_iters; ++it) {
@@ -786,6 +809,221 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         double acc = 0.0;
         unsigned t_group = 0;
         unsigned prof_path = 0;
+        if constexpr (WIDE) {
+            // ---- the thread-per-query form (kicp_icp_wide.hpp) ---------------------------------------------------
+            double(*rows)[kIcpTerms] = sh.terms;  // phase C: kWideTermRows rows, continued into sh.pts
+            const bool single = n_local <= kWideChunk;  // the whole run is one chunk: s / nn stay in registers between iterations
+            const double limit_corr = (max_dist * max_dist) * (1.0 + 0x1p-40);  // sqrt(d) < max_dist (Registration.cpp:72) implies d below this
+            for (int base = 0; base < n_local; base += kWideChunk) {
+                const int cn = min(kWideChunk, n_local - base);
+                const bool active = tid < cn;
+                const int j = base + tid;
+                const bool has_meta = active && j < n_meta;  // (n_meta <= kWideChunk: queries of the first chunk)
+                WideMeta *meta = wmetas + (has_meta ? j : 0);
+                const unsigned ta = PROF ? ticks32() : 0u;
+                // ---- A: s = est * s, its voxel, is the known window still good ------------------------------------
+                if (active) {
+                    double pin[3];
+                    if (it == 0) {
+                        const int p = P.order ? (int)(P.order[q0 + j] & 0xFFFFFFull) : q0 + j;
+                        pin[0] = P.frame[3 * p];
+                        pin[1] = P.frame[3 * p + 1];
+                        pin[2] = P.frame[3 * p + 2];
+                    } else if (single) {
+                        pin[0] = wq.s[0];
+                        pin[1] = wq.s[1];
+                        pin[2] = wq.s[2];
+                    } else {  // (a run of more than kWideChunk points: the running points live in HBM, by sorted position)
+                        pin[0] = P.work[3 * (size_t)(q0 + j)];
+                        pin[1] = P.work[3 * (size_t)(q0 + j) + 1];
+                        pin[2] = P.work[3 * (size_t)(q0 + j) + 2];
+                    }
+                    se3_act(est, pin, wq.s);
+                    if (!single) {
+                        P.work[3 * (size_t)(q0 + j)] = wq.s[0];
+                        P.work[3 * (size_t)(q0 + j) + 1] = wq.s[1];
+                        P.work[3 * (size_t)(q0 + j) + 2] = wq.s[2];
+                        wq.have_nn = false;
+                    }
+                    const int vx = voxel_coord_fast(wq.s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(wq.s[1], m.voxel_size, inv_voxel),
+                              vz = voxel_coord_fast(wq.s[2], m.voxel_size, inv_voxel);
+                    wq.v[0] = vx;
+                    wq.v[1] = vy;
+                    wq.v[2] = vz;
+                    bool cached = false;
+                    if (has_meta && meta->valid > 0)  // is the 27-neighbourhood of (vx, vy, vz) inside the known window?
+                        cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
+                                 meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
+                                 meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
+                    wq.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
+                    if (wq.flag == 1) sh.any_fill = 1;
+                    if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
+                        sh.origin[0] = vx - kTileSpan / 2;
+                        sh.origin[1] = vy - kTileSpan / 2;
+                        sh.origin[2] = vz - kTileSpan / 2;
+                    }
+                }
+                if (tid == 0) {
+                    sh.next_point = 0;    // queue of the window phase
+                    sh.list_entries = 0;  // queue of the map-direct searches (this form keeps no scan lists)
+                    sh.cell_count = 0;    // some query of the chunk needs the map-direct search
+                }
+                __syncthreads();
+                tile.ox = sh.origin[0];
+                tile.oy = sh.origin[1];
+                tile.oz = sh.origin[2];
+                // The slow paths: the queries that need one file themselves in a queue (sh.pts), the 32-lane groups serve it
+                // with the routines of the first form, the owners read the verdicts back.  mode 1: establish the window
+                // (tile_fill); mode 2: search the map directly (closest_neighbor_any).
+                auto serve = [&](int mode, int *counter) {
+                    bool pending = active && wq.flag == mode;
+                    for (;;) {
+                        int slot = -1;
+                        if (pending) {
+                            slot = atomicAdd(counter, 1);
+                            if (slot < kWideQueue) {
+                                IcpPoint &r = sh.pts[slot];
+                                r.s[0] = wq.s[0];
+                                r.s[1] = wq.s[1];
+                                r.s[2] = wq.s[2];
+                                r.v[0] = wq.v[0];
+                                r.v[1] = wq.v[1];
+                                r.v[2] = wq.v[2];
+                                r.flag = mode;
+                                r.pad = tid;
+                            }
+                        }
+                        __syncthreads();
+                        const int filed = min(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), kWideQueue);
+                        if (filed == 0) break;  // (the whole workgroup)
+                        for (int e = grp; e < filed; e += kIcpGroupsPerBlock) {
+                            IcpPoint &r = sh.pts[e];
+                            const double s[3] = {r.s[0], r.s[1], r.s[2]};
+                            const int v[3] = {r.v[0], r.v[1], r.v[2]};
+                            if (mode == 1) {
+                                const bool ok = tile_fill(m, tile, s, v, lane, wmetas + base + r.pad, range_err);
+                                if (lane == 0) r.flag = ok ? 0 : 2;
+                            } else {
+                                double nn[3];
+                                int E = 0;
+                                const double d2 = closest_neighbor_any(m, s[0], s[1], s[2], lane, nn, E, range_err);
+                                if (lane == 0) {
+                                    r.nn[0] = nn[0];
+                                    r.nn[1] = nn[1];
+                                    r.nn[2] = nn[2];
+                                    r.d2 = d2;
+                                    r.E = E;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        if (pending && slot < kWideQueue) {
+                            const IcpPoint &r = sh.pts[slot];
+                            if (mode == 1) {
+                                wq.flag = r.flag;
+                            } else {
+                                wq.nn[0] = r.nn[0];
+                                wq.nn[1] = r.nn[1];
+                                wq.nn[2] = r.nn[2];
+                                wq.d2 = r.d2;
+                                wq.E = r.E;
+                                wq.have_nn = false;
+                            }
+                            pending = false;
+                        }
+                        if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __syncthreads();
+                    }
+                };
+                // ---- B0: windows.  All of them in the first iteration (workgroup-wide), a few now and then later ----
+                const unsigned tb00 = PROF ? ticks32() : 0u;
+                if (sh.any_fill) {
+                    bool bulk_done = false;
+                    if (it == 0 && base == 0 && P.bulk_fill) {
+                        int rerr = 0;
+                        const bool mine = active && wq.flag == 1;
+                        bulk_done = wide_fill_bulk(m, tile, &sh, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF);
+                        if (rerr) range_err = 1;
+                        if (bulk_done && mine) wq.flag = meta->valid > 0 ? 0 : 2;
+                    }
+                    if (!bulk_done) serve(1, &sh.next_point);
+                    if (tid == 0) sh.any_fill = 0;  // (barriers inside both routes: everybody has read it)
+                }
+                const unsigned t_fill = PROF ? ticks32() - tb00 : 0u;
+                // ---- B: this thread's query against the tile ------------------------------------------------------
+                const unsigned tb0 = PROF ? ticks32() : 0u;
+                WideCounters ctr;
+                ctr.visited_lds = ctr.visited_map = 0u;
+                if (active && wq.flag == 0) {
+                    // what can still matter: the correspondence threshold and -- its voxel still among the 27 -- last iteration's neighbour
+                    double limit0 = limit_corr;
+                    if (P.wide_prune > 1 && wq.have_nn && abs(wq.pv[0] - wq.v[0]) <= 1 && abs(wq.pv[1] - wq.v[1]) <= 1 && abs(wq.pv[2] - wq.v[2]) <= 1) {
+                        const double ex = wq.nn[0] - wq.s[0], ey = wq.nn[1] - wq.s[1], ez = wq.nn[2] - wq.s[2];
+                        const double dp = (ex * ex + ey * ey) + ez * ez;
+                        limit0 = dp < limit0 ? dp : limit0;
+                    }
+                    int bad = 0;
+                    wide_search<PROF>(m, tile, wq, limit0, P.wide_prune > 0, bad, ctr);
+                    if (bad) {  // the tile cannot answer (a voxel outside the key span, an entry that did not fit): the map from now on
+                        meta->valid = -1;
+                        wq.flag = 2;
+                    }
+                }
+                if (active && wq.flag == 2) sh.cell_count = 1;
+                const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
+                __syncthreads();
+                if (sh.cell_count) serve(2, &sh.list_entries);
+                if (PROF) t_group += ticks32() - tb0;
+                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0) {
+                    // this thread's record of the iteration (10 ns ticks); same layout as the first form's group records
+                    unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) + (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+                    r[0] = (unsigned)(tb00 - ta) | (min(ctr.visited_lds, 255u) << 16) | (min(ctr.visited_map, 255u) << 24);  // phase A; voxels visited (LDS, map)
+                    if (it == 0 && P.bulk_fill && grp < 5) r[0] = (r[0] & 0xFFFFu) | (min(sh.bulk_ticks[grp], 0xFFFFu) << 16);  // groups 0..4: the window phase's parts instead
+                    r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)min(t_scan, 0xFFFFu) << 16);
+                    r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)min(wq.E, 0xFFFF) << 16);
+                    r[3] = 4u;
+                    prof_path = 4u;
+                }
+                // ---- C: products of kWideTermRows points at a time, added in the first form's order ----------------
+                for (int sub = 0; sub < cn; sub += kWideTermRows) {
+                    const int sn = min(kWideTermRows, cn - sub);
+                    if (tid >= sub && tid < sub + sn) {
+                        const double s[3] = {wq.s[0], wq.s[1], wq.s[2]};
+                        const double d2 = wq.d2;
+                        double *T = rows[tid - sub];
+#pragma unroll
+                        for (int k = 0; k < 17; ++k) T[k] = 0.0;
+                        T[17] = (double)wq.E;
+                        if (d2 < DBL_MAX && sqrt(d2) < max_dist) {  // Registration.cpp:72 (strict)
+                            const double rx = s[0] - wq.nn[0], ry = s[1] - wq.nn[1], rz = s[2] - wq.nn[2];
+                            const double r2 = (rx * rx + ry * ry) + rz * rz;
+                            const double w = (ks * ks) / ((ks + r2) * (ks + r2));
+                            T[0] = w;
+                            T[1] = w * s[0];
+                            T[2] = w * s[1];
+                            T[3] = w * s[2];
+                            T[4] = w * (s[1] * s[1] + s[2] * s[2]);
+                            T[5] = w * (-(s[0] * s[1]));
+                            T[6] = w * (-(s[0] * s[2]));
+                            T[7] = w * (s[0] * s[0] + s[2] * s[2]);
+                            T[8] = w * (-(s[1] * s[2]));
+                            T[9] = w * (s[0] * s[0] + s[1] * s[1]);
+                            T[10] = w * rx;
+                            T[11] = w * ry;
+                            T[12] = w * rz;
+                            T[13] = w * (s[1] * rz - s[2] * ry);
+                            T[14] = w * (s[2] * rx - s[0] * rz);
+                            T[15] = w * (s[0] * ry - s[1] * rx);
+                            T[16] = 1.0;
+                        }
+                    }
+                    __syncthreads();
+                    if (cg < kIcpGroupsPerBlock)
+                        for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += rows[i][ck];
+                    __syncthreads();
+                }
+            }
+        } else
         for (int base = 0; base < n_local; base += kIcpChunk) {
             const int cn = min(kIcpChunk, n_local - base);
             // ---- A -------------------------------------------------------------------------------------
@@ -1259,7 +1497,8 @@ int icp_prepare(int device_id) {
     std::lock_guard<std::mutex> lk(mu);
     if (device_id < 0 || device_id >= 64) return (int)hipErrorInvalidDevice;
     if (done[device_id]) return 0;
-    const void *kernels[2] = {reinterpret_cast<const void *>(k_icp<false>), reinterpret_cast<const void *>(k_icp<true>)};
+    const void *kernels[4] = {reinterpret_cast<const void *>(k_icp<false, false>), reinterpret_cast<const void *>(k_icp<true, false>),
+                              reinterpret_cast<const void *>(k_icp<false, true>), reinterpret_cast<const void *>(k_icp<true, true>)};
     for (const void *k : kernels) {
         const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kIcpLdsBytesMax);
         if (e != hipSuccess) return (int)e;
@@ -1285,16 +1524,28 @@ void launch_selftest_solve(const double *A, const double *b, int n, double *x, h
 }
 
 int icp_blocks_per_cu(int lds_bytes) {
-    int a = 0, b = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_icp<false>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_icp<true>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) b = 0;
-    return a < b ? a : b;
+    int a[4] = {0, 0, 0, 0};
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a[0], k_icp<false, false>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a[0] = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a[1], k_icp<true, false>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a[1] = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a[2], k_icp<false, true>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a[2] = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a[3], k_icp<true, true>, kIcpThreads, (size_t)lds_bytes) != hipSuccess) a[3] = 0;
+    int r = a[0];
+    for (int i = 1; i < 4; ++i) r = a[i] < r ? a[i] : r;
+    return r;
 }
-void launch_icp(IcpParams P, int G, bool profile, hipStream_t s) {
-    if (profile)
-        hipLaunchKernelGGL((k_icp<true>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
-    else
-        hipLaunchKernelGGL((k_icp<false>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+// wide: the thread-per-query form of the association (kicp_icp_wide.hpp) -- same result, for clouds of many points per workgroup
+void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s) {
+    if (wide) {
+        if (profile)
+            hipLaunchKernelGGL((k_icp<true, true>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+        else
+            hipLaunchKernelGGL((k_icp<false, true>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+    } else {
+        if (profile)
+            hipLaunchKernelGGL((k_icp<true, false>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+        else
+            hipLaunchKernelGGL((k_icp<false, false>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+    }
 }
 
 }  // namespace kicp

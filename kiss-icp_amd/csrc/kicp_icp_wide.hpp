@@ -1,0 +1,610 @@
+// kicp_icp_wide.hpp -- the association phases of k_icp<PROF, WIDE = true>: one THREAD per source point.
+//   DataAssociation                         core/Registration.cpp:60-78
+//   VoxelHashMap::GetClosestNeighbor        core/VoxelHashMap.cpp:46-70 (shift table :35-41)
+// Included by kicp_icp.hip (after IcpShared); nothing else includes it.
+//
+// k_icp's first form gives every query a 32-lane group: right when a workgroup has a few dozen queries whose
+// neighbourhoods hold hundreds of points (full-size voxels).  With small voxels and a large cloud (the 1M-point /
+// 0.1 m configuration: ~400 queries per workgroup, 27 voxels of one to five points each) a group spends its time in
+// dependent LDS / L2 round trips with two or three of its 32 lanes busy, 16 queries in flight per CU:
+// 2 .. 7 us per query and group, 171 us per iteration (profiles/r03_ac_icp_probe_livox.txt).  Here a THREAD owns a
+// query for the whole launch -- 512 queries in flight per CU, the running source point, the last neighbour and the
+// verdicts in registers -- and the search is arranged so that lanes of a wave rarely wait for each other:
+//   1. the 27 table lookups of a query are unrolled: the first two probe slots of all 27 chains are loaded together
+//      (54 independent LDS loads), values of the hits together (27 more); what is still open after two probes (a
+//      few per cent) is finished by one short loop.  Result: which cells are occupied (LDS / map resident), and E,
+//      the number of points the reference examines (VoxelHashMap.cpp:58-61) -- no point has been read yet;
+//   2. the occupied voxels are visited in shift order, but a voxel that CANNOT hold the answer is skipped: the
+//      squared distance from the query to the voxel's box is a lower bound of every distance the reference would
+//      compute there (built from the same operations, see wide_gaps), and a voxel whose bound exceeds what is
+//      already in hand loses every strict '<' of VoxelHashMap.cpp:58-63.  "In hand" = the best of this search, the
+//      correspondence threshold (a neighbour beyond it is dropped by Registration.cpp:72 whatever it is), and -- from
+//      the second iteration on -- the distance to the PREVIOUS iteration's neighbour when that point is still inside
+//      the 27 voxels (the map does not change during AlignPointsToMap): a converged query visits one to three voxels
+//      instead of fifteen.  The result (neighbour, distance, ties) is the reference's, bit for bit: visiting fewer
+//      voxels only removes comparisons that are lost anyway; the order among equals is kept by the key
+//      {shift position, index in the voxel} exactly as in tile_scan;
+//   3. voxels the LDS store had no room for (kTileGlobal) are visited last, by the thread itself, with the bound
+//      tightened by everything found in LDS.
+// Queries the tile cannot serve (outside the key span, table full) and queries of runs longer than one chunk go
+// through a small queue served by the 32-lane groups with the map-direct search of the first form (closest_neighbor_any).
+// The partition of the cloud (runs), the order in which products are added (phase C) and the exchange are those of
+// the first form, so both forms give the same sums and the same pose bit for bit (tests/test_gpu_paths.py::
+// test_thread_per_query_form_is_bitwise_the_group_form): which form a launch uses is a matter of speed only.
+#pragma once
+
+namespace kicp {
+
+constexpr int kWideChunk = kIcpThreads;  // queries a workgroup carries through an iteration at a time: one per thread
+constexpr int kWideQueue = kIcpChunk;    // records of the slow-path queue (sh.pts)
+constexpr int kWideTermRows = 128;       // phase C: products of this many points in LDS together (sh.terms continued into sh.pts)
+static_assert(offsetof(IcpShared, pts) == offsetof(IcpShared, terms) + sizeof(double) * kIcpTermChunk * kIcpTerms,
+              "phase C of the thread-per-query form uses terms and pts as one array");
+static_assert(sizeof(double) * kWideTermRows * kIcpTerms <= sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk, "term rows");
+static_assert(kWideTermRows % kIcpGroupsPerBlock == 0 && kIcpTermChunk % kIcpGroupsPerBlock == 0 && kIcpChunk % kIcpGroupsPerBlock == 0,
+              "the order of additions (points j = g, g + 16, ... per adder) must not depend on the chunking");
+constexpr int kWideJobs = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk) / 8);  // point-fetch jobs of the window phase
+
+// LDS record of a query: its known window (kicp_search.hpp).  The running point, the last neighbour and the flags
+// live in the owning thread's registers.
+struct WideMeta {
+    int v[3];                  // voxel the known window is centred on
+    signed char lo[3], hi[3];  // extent of the window per axis, in voxels relative to v
+    signed char valid;         // 1: every occupied voxel of the window is in the tile; 0: not looked yet; -1: cannot use the tile
+    signed char list_state;    // 2 while the query takes part in a workgroup-wide window phase (otherwise unused)
+};
+static_assert(sizeof(WideMeta) == 20, "WideMeta layout");
+
+struct WideQuery {  // registers of the owning thread
+    double s[3];   // transformed source point
+    double nn[3];  // closest map point (valid when d2 < DBL_MAX)
+    double d2;
+    int v[3];      // voxel of s
+    int pv[3];     // voxel nn was found in (have_nn)
+    int E;         // map points the reference examines for this query
+    int flag;      // 0 window valid, 1 window must be (re)established, 2 map-direct search
+    bool have_nn;  // nn / pv come from a tile search of this launch
+};
+
+// ---- lower bounds of the distances to the neighbouring voxel layers --------------------------------------------------
+// A point p stored in voxel c satisfies floor(fl(p / vs)) == c (PointToVoxel, VoxelUtils.hpp:33-37), hence
+// c vs (1 - 2^-52) <= p < (c + 1) vs (1 + 2^-52) in real arithmetic.  For the layer above the query's voxel v:
+// p - s >= (v + 1) vs - s - slack, for the layer below: s - p > s - v vs - slack, the slack (2^-48 of the magnitudes
+// involved) covering the rounding of the products, of the differences and of the voxel assignment at the face.  The
+// scan computes ex = fl(p - s) and d = fl(fl(fl(ex^2) + fl(ey^2)) + fl(ez^2)); rounding is monotone, so with
+// g <= |ex| the same expression over the g's is <= d.  m2 / p2: squared bounds for the layers v - 1 / v + 1.
+struct WideGaps {
+    double m2[3], p2[3];
+};
+__device__ __forceinline__ WideGaps wide_gaps(const double s[3], const int v[3], double vs) {
+    WideGaps g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double f0 = (double)v[a] * vs, f1 = (double)(v[a] + 1) * vs;
+        const double slack = (fabs(f0) + fabs(f1) + fabs(s[a])) * 0x1p-48 + DBL_MIN;
+        double gm = (s[a] - f0) - slack, gp = (f1 - s[a]) - slack;
+        gm = gm > 0.0 ? gm : 0.0;
+        gp = gp > 0.0 ? gp : 0.0;
+        g.m2[a] = gm * gm;
+        g.p2[a] = gp * gp;
+    }
+    return g;
+}
+__device__ __forceinline__ double wide_bound(const WideGaps &g, int j) {
+    const unsigned cx = (unsigned)(kShift.x >> (2 * j)) & 3u, cy = (unsigned)(kShift.y >> (2 * j)) & 3u, cz = (unsigned)(kShift.z >> (2 * j)) & 3u;
+    const double bx = cx == 0u ? g.m2[0] : (cx == 2u ? g.p2[0] : 0.0);
+    const double by = cy == 0u ? g.m2[1] : (cy == 2u ? g.p2[1] : 0.0);
+    const double bz = cz == 0u ? g.m2[2] : (cz == 2u ? g.p2[2] : 0.0);
+    return (bx + by) + bz;
+}
+
+struct WideCounters {  // profiling build
+    unsigned visited_lds, visited_map;
+};
+
+// the table entry of cell j of the 27 (any chain length); 0: not in the table
+__device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy, int vz, int j) {
+    const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+    unsigned rkey;
+    if (!tile_rel(tile, qx, qy, qz, rkey)) return 0u;
+    const int slot = tile_find(tile, rkey);
+    return slot >= 0 ? __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+}
+
+// GetClosestNeighbor for the query of THIS thread against the workgroup's tile.  limit0: an upper bound of every
+// distance that can still matter (see the head of this file); prune: skip voxels by their bound (off: every occupied
+// voxel is visited -- same result, for the tests and the measurements).  bad: the tile cannot answer (a voxel outside
+// the key span or one the table has no entry for): the caller sends the query to the map-direct search.
+template <bool PROF>
+__device__ __forceinline__ void wide_search(const MapView &m, const Tile &tile, WideQuery &q, double limit0, bool prune, int &bad, WideCounters &ctr) {
+    const int vx = q.v[0], vy = q.v[1], vz = q.v[2];
+    const double sx = q.s[0], sy = q.s[1], sz = q.s[2];
+    // ---- 1: which of the 27 cells are occupied (three batches of nine: 18 + 9 loads in flight, ~45 registers) -----------
+    bad = 0;
+    q.E = 0;
+    q.d2 = DBL_MAX;
+    q.have_nn = false;
+    {
+        bool span_ok = true;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {  // the corners of the 3 x 3 x 3 block decide for all 27 cells
+            unsigned rkey;
+            span_ok = tile_rel(tile, vx + ((c & 1) ? 1 : -1), vy + ((c & 2) ? 1 : -1), vz + ((c & 4) ? 1 : -1), rkey) && span_ok;
+        }
+        if (!span_ok) {
+            bad = 2;
+            return;
+        }
+    }
+    unsigned m_lds = 0u, m_map = 0u, open = 0u;
+    int E = 0;
+    auto classify = [&](unsigned v, int j) {
+        if (v == 0u) return;
+        if (v == kTileOverflow || !(v & kTileReady)) {
+            bad = 2;
+            return;
+        }
+        E += tile_cnt(v);
+        if (v & kTileGlobal)
+            m_map |= 1u << j;
+        else
+            m_lds |= 1u << j;
+    };
+#pragma unroll
+    for (int jb = 0; jb < 27; jb += 9) {
+        unsigned rk[9], h0[9], ka[9], kb[9], val[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int j = jb + u;
+            const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+            (void)tile_rel(tile, qx, qy, qz, rk[u]);
+            h0[u] = tile_hash(tile, rk[u]);
+            ka[u] = __hip_atomic_load(&tile.keys[h0[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            kb[u] = __hip_atomic_load(&tile.keys[(h0[u] + 1u) & (unsigned)tile.slots_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const bool hit_a = ka[u] == rk[u];
+            const bool go_b = !hit_a && ka[u] != kTileEmpty;
+            const bool hit_b = go_b && kb[u] == rk[u];
+            if (go_b && !hit_b && kb[u] != kTileEmpty) open |= 1u << (jb + u);
+            val[u] = 0u;
+            if (hit_a || hit_b) val[u] = __hip_atomic_load(&tile.vals[hit_a ? h0[u] : ((h0[u] + 1u) & (unsigned)tile.slots_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) classify(val[u], jb + u);
+    }
+    while (open) {  // chains longer than two slots
+        const int j = __ffs(open) - 1;
+        open &= open - 1u;
+        // (the key and its home slot are recomputed from j: no dynamically indexed register array)
+        const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+        unsigned rkey;
+        (void)tile_rel(tile, qx, qy, qz, rkey);
+        unsigned s = (tile_hash(tile, rkey) + 2u) & (unsigned)tile.slots_mask;
+        for (int probes = 2; probes < kTileMaxProbes; ++probes) {
+            const unsigned k = __hip_atomic_load(&tile.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == rkey) {
+                classify(__hip_atomic_load(&tile.vals[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), j);
+                break;
+            }
+            if (k == kTileEmpty) break;
+            s = (s + 1u) & (unsigned)tile.slots_mask;
+        }
+    }
+    if (bad) return;
+    q.E = E;
+    // ---- 2: the voxels in LDS, nearest layers first (shift order: the centre, the faces, the edges, the corners) ----
+    const WideGaps gaps = wide_gaps(q.s, q.v, m.voxel_size);
+    double limit = limit0;  // nothing at a distance above this can be, or tie with, the answer
+    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF;
+    auto take = [&](double x, double y, double z, int key, bool valid) {
+        const double ex = x - sx, ey = y - sy, ez = z - sz;
+        const double d = (ex * ex + ey * ey) + ez * ez;
+        if (valid && (d < best || (d == best && key < bkey))) {
+            best = d;
+            bkey = key;
+            bx = x;
+            by = y;
+            bz = z;
+        }
+    };
+    unsigned todo = m_lds;
+    for (;;) {
+        int j = -1;
+        while (todo) {
+            const int jj = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            if (!prune || !(wide_bound(gaps, jj) > limit)) {
+                j = jj;
+                break;
+            }
+        }
+        if (j < 0) break;
+        const unsigned v = wide_entry(tile, vx, vy, vz, j);
+        const int ref = tile_ref(v), cnt = tile_cnt(v);
+        const double *P = tile.points + 3 * ref;
+        for (int k0 = 0; k0 < cnt; k0 += 2) {
+            const int k1 = k0 + 1 < cnt ? k0 + 1 : k0;
+            const double x0 = P[3 * k0], y0 = P[3 * k0 + 1], z0 = P[3 * k0 + 2];
+            const double x1 = P[3 * k1], y1 = P[3 * k1 + 1], z1 = P[3 * k1 + 2];
+            take(x0, y0, z0, (j << 5) | k0, true);
+            take(x1, y1, z1, (j << 5) | k1, k1 != k0);
+        }
+        limit = best < limit ? best : limit;
+        if (PROF) ++ctr.visited_lds;
+    }
+    // ---- 3: the voxels left in the map (HBM / L2): this thread reads them itself, four points in flight ----------------
+    todo = m_map;
+    for (;;) {
+        int j = -1;
+        while (todo) {
+            const int jj = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            if (!prune || !(wide_bound(gaps, jj) > limit)) {
+                j = jj;
+                break;
+            }
+        }
+        if (j < 0) break;
+        const unsigned v = wide_entry(tile, vx, vy, vz, j);
+        const int blk = tile_ref(v), cnt = tile_cnt(v);
+        const double2 *XY = block_xy(m, blk);
+        const double *Z = block_z(m, blk);
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            double2 xy[4];
+            double zz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u < cnt ? k0 + u : k0;
+                xy[u] = XY[k];
+                zz[u] = Z[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(xy[u].x, xy[u].y, zz[u], (j << 5) | (k0 + u), k0 + u < cnt);
+        }
+        limit = best < limit ? best : limit;
+        if (PROF) ++ctr.visited_map;
+    }
+    q.d2 = best;
+    if (best < DBL_MAX) {
+        const int j = bkey >> 5;
+        q.nn[0] = bx;
+        q.nn[1] = by;
+        q.nn[2] = bz;
+        q.pv[0] = vx + (int)((kShift.x >> (2 * j)) & 3) - 1;
+        q.pv[1] = vy + (int)((kShift.y >> (2 * j)) & 3) - 1;
+        q.pv[2] = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+        q.have_nn = true;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The first iteration's window phase for up to 512 queries at once (the same four phases as tile_fill_bulk,
+// kicp_icp.hip; differences: the windows come from the owning threads' registers; the set of distinct cells has up
+// to 16384 slots -- 400 queries of the 1M-point configuration have five to eight thousand distinct cells, and a set
+// as crowded as 4096 slots were cost 45 us of probing in some workgroups (profiles/r03_ac_icp_probe_livox.txt) --
+// and no member list: the lookups walk the set's slots, three in flight per thread; the fetch jobs live in
+// sh.terms + sh.pts).  mine: this thread's query takes part (flag 1).  Leaves the verdict in metas[tid].valid
+// (1 / -1).  false: no room for the scratch (nothing was changed): the caller establishes the windows one by one.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &tile, IcpShared *shp, int cn, WideMeta *metas, bool mine, const double s[3], const int v[3],
+                                               int *range_err_out, bool prof) {
+    IcpShared &sh = *shp;
+    const int tid = threadIdx.x;
+    unsigned tk = prof ? ticks32() : 0u;
+    auto stamp = [&](int ph) {
+        if (prof && tid == 0) {
+            const unsigned now = ticks32();
+            sh.bulk_ticks[ph] = now - tk;
+            tk = now;
+        }
+    };
+    unsigned *jobs = reinterpret_cast<unsigned *>(sh.terms);  // {block id | count << 24, store offset | table slot << 16}
+    int range_err = 0;
+    const int s0 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the store's end before this phase
+    const unsigned free_top = tile.region_bytes & ~15u;  // (this form keeps no scan lists: the region is points only)
+    // the set of distinct cells: the largest power of two of slots that fits above the points, 32 per query at most
+    int set_log2 = 14;
+    while (set_log2 > 10 && ((1 << set_log2) > 32 * max(cn, 32) || (unsigned)s0 * 24u + (4u << set_log2) > free_top)) --set_log2;
+    if ((unsigned)s0 * 24u + (4u << set_log2) > free_top) return false;
+    const int S = 1 << set_log2;
+    unsigned *set = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tile.points) + free_top) - S;
+    // ---- 1: the windows; the set is cleared ---------------------------------------------------------------------------
+    for (int i = tid; i < S; i += kIcpThreads) set[i] = kTileEmpty;
+    if (tid == 0) sh.job_count = sh.bulk_failed = 0;
+    if (mine) {
+        WideMeta *meta = metas + tid;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double f = s[a] / m.voxel_size - (double)v[a];  // position inside the voxel, [0, 1)
+            meta->v[a] = v[a];
+            meta->lo[a] = (signed char)((f < kWindowMargin) ? -2 : -1);
+            meta->hi[a] = (signed char)((f > 1.0 - kWindowMargin) ? 2 : 1);
+        }
+        meta->valid = 0;       // pending; -1 as soon as any of its cells cannot be served from the tile
+        meta->list_state = 2;  // takes part
+    }
+    __syncthreads();
+    // ---- 2a: the DISTINCT cells of all windows that the table does not know yet ----------------------------------------
+    auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key) for every in-range cell of every window taking part
+        for (int idx = tid; idx < cn * 64; idx += kIcpThreads) {
+            const int qt = idx >> 6;
+            const WideMeta *meta = metas + qt;
+            if (meta->list_state != 2) continue;
+            const int ny = meta->hi[1] - meta->lo[1] + 1, nz = meta->hi[2] - meta->lo[2] + 1, nx = meta->hi[0] - meta->lo[0] + 1;
+            const int w = idx & 63;
+            if (w >= nx * ny * nz) continue;
+            // (window sides are 3 or 4 cells, w < 64: a shift or a multiplication instead of integer divisions)
+            const int t2 = nz == 4 ? w >> 2 : (w * 43) >> 7, iz = w - t2 * nz;
+            const int ix = ny == 4 ? t2 >> 2 : (t2 * 43) >> 7, iy = t2 - ix * ny;
+            const int ox = meta->lo[0] + ix, oy = meta->lo[1] + iy, oz = meta->lo[2] + iz;
+            const int qx = meta->v[0] + ox, qy = meta->v[1] + oy, qz = meta->v[2] + oz;
+            if (!voxel_in_range(qx, qy, qz)) {
+                if (ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1) range_err = 1;
+                continue;
+            }
+            unsigned rkey;
+            if (!tile_rel(tile, qx, qy, qz, rkey)) {
+                metas[qt].valid = -1;  // outside the span of the relative keys
+                continue;
+            }
+            fn(qt, rkey);
+        }
+    };
+    const bool fresh = __hip_atomic_load(tile.entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+    const unsigned set_mask = (unsigned)(S - 1);
+    for_each_cell([&](int qt, unsigned rkey) {
+        const int slot = fresh ? -1 : tile_find(tile, rkey);
+        if (slot >= 0) {
+            if (__hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kTileOverflow) metas[qt].valid = -1;
+            return;
+        }
+        unsigned si = (rkey * 0x9E3779B1u) >> (32 - set_log2);
+        bool done = false;
+        for (int probes = 0; probes < 64; ++probes) {
+            const unsigned old = atomicCAS(&set[si], kTileEmpty, rkey);
+            if (old == kTileEmpty || old == rkey) {
+                done = true;
+                break;
+            }
+            si = (si + 1u) & set_mask;
+        }
+        if (!done) metas[qt].valid = -1;  // (a set this crowded: the query looks the map up itself, one by one)
+    });
+    __syncthreads();
+    stamp(0);
+    // ---- 2b: one map lookup per distinct cell, three in flight per thread; occupied voxels enter the table and file a fetch job
+    constexpr int kBatch = 3;
+    for (int i0 = 0; i0 < S; i0 += kIcpThreads * kBatch) {  // (every thread takes every trip: the counters below are kept wave by wave)
+        unsigned long long key[kBatch];
+        unsigned rkey[kBatch];
+        Slot a[kBatch][kProbeAhead];
+        uint32_t hs[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int i = i0 + tid + u * kIcpThreads;
+            rkey[u] = i < S ? set[i] : kTileEmpty;
+            key[u] = 0;
+            hs[u] = 0;
+            if (rkey[u] != kTileEmpty) {
+                key[u] = pack_voxel(tile.ox + (int)(rkey[u] >> 20), tile.oy + (int)((rkey[u] >> 10) & 1023u), tile.oz + (int)(rkey[u] & 1023u));
+                hs[u] = hash_key(key[u], m.mask);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+            for (int i = 0; i < kProbeAhead; ++i) {
+                a[u][i].key = kKeyEmpty;
+                a[u][i].block = -1;
+                a[u][i].count = 0;
+                if (rkey[u] != kTileEmpty) a[u][i] = load_slot(m.slots + ((hs[u] + i) & m.mask));
+            }
+        int blks[kBatch], cnts[kBatch];
+        bool open_any = false;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const bool done = probe_resolve(a[u], key[u], blks[u], cnts[u]);  // (an unused entry resolves at once: its slots read "empty")
+            if (!done) {
+                hs[u] = (hs[u] + kProbeAhead) & m.mask;
+                open_any = true;
+            } else {
+                key[u] = kKeyEmpty;  // closed
+            }
+        }
+        for (uint32_t probes = kProbeAhead; open_any && probes <= m.mask; probes += kProbeAhead) {  // long chains: all of a thread's together
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+                for (int i = 0; i < kProbeAhead; ++i)
+                    if (key[u] != kKeyEmpty) a[u][i] = load_slot(m.slots + ((hs[u] + i) & m.mask));
+            open_any = false;
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (key[u] == kKeyEmpty) continue;
+                if (probe_resolve(a[u], key[u], blks[u], cnts[u])) {
+                    key[u] = kKeyEmpty;
+                } else {
+                    hs[u] = (hs[u] + kProbeAhead) & m.mask;
+                    open_any = true;
+                }
+            }
+        }
+        // Entering: the table slot is a CAS of the lane's own; the counters (slots occupied, points asked of the store, jobs
+        // filed, the store's end) are ONE LDS atomic per wave and counter (prefix sums over ballots), as in tile_fill_bulk.
+        const int lane64 = tid & 63;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int blk = blks[u], cnt = cnts[u];
+            const bool occ = rkey[u] != kTileEmpty && blk >= 0 && cnt > 0;  // (an empty voxel: the table holds occupied ones only)
+            const unsigned long long om = __ballot(occ);
+            if (om == 0ull) continue;  // (the whole wave)
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)om, 0u));
+            int pre = occ ? cnt : 0;  // inclusive prefix of the points asked for
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(pre, o, 64);
+                if (lane64 >= o) pre += t;
+            }
+            const int total = __shfl(pre, 63, 64);
+            int ebase = 0, obase = 0;
+            if (lane64 == 0) {
+                ebase = atomicAdd(tile.entries, (int)__popcll(om));  // slots are reserved before they are taken: the limit holds exactly
+                obase = atomicAdd(tile.count, total);
+            }
+            ebase = __shfl(ebase, 0, 64);
+            obase = __shfl(obase, 0, 64);
+            const int off = obase + pre - (occ ? cnt : 0);
+            unsigned sidx = 0;
+            bool won = false;
+            if (occ && ebase + rank < tile.load_limit) {
+                sidx = tile_hash(tile, rkey[u]);
+                for (int probes = 0; probes < kTileMaxProbes; ++probes) {
+                    if (atomicCAS(&tile.keys[sidx], kTileEmpty, rkey[u]) == kTileEmpty) {  // (no other thread enters this key)
+                        won = true;
+                        break;
+                    }
+                    sidx = (sidx + 1) & (unsigned)tile.slots_mask;
+                }
+            }
+            bool failed = occ && !won;  // table full
+            // (offsets only: the points arrive in phase 3, when the set is dead)
+            const bool fits = won && (unsigned)(off + cnt) * 24u <= free_top && off + cnt <= 0xFFFF;
+            const bool want = fits && (unsigned)blk < 0x1000000u;
+            const unsigned long long jm = __ballot(want);
+            int jbase = 0;
+            if (jm != 0ull) {
+                if (lane64 == 0) jbase = atomicAdd(&sh.job_count, (int)__popcll(jm));
+                jbase = __shfl(jbase, 0, 64);
+            }
+            const int job = jbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(jm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)jm, 0u));
+            const bool filed = want && job < kWideJobs;
+            if (filed) {
+                jobs[2 * job] = (unsigned)blk | ((unsigned)cnt << 24);
+                jobs[2 * job + 1] = (unsigned)off | (sidx << 16);
+            }
+            const unsigned long long fm = __ballot(filed);
+            if (fm != 0ull) {  // the store's end: offsets ascend with the lane, so the highest lane that filed holds it
+                const int end = __shfl(off + cnt, 63 - (int)__clzll(fm), 64);
+                if (lane64 == 0) atomicMax(tile.stored, end);
+            }
+            if (won && !filed) {
+                // LDS store (or the job list) full: the table remembers where the voxel is in the map instead
+                const unsigned val = (unsigned)blk < 0x1000000u ? ((unsigned)blk | ((unsigned)cnt << 24) | kTileGlobal | kTileReady) : kTileOverflow;
+                __hip_atomic_store(&tile.vals[sidx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                failed = val == kTileOverflow;
+            }
+            if (failed) {  // the queries whose windows hold this cell must search the map directly (phase 4)
+                const int f = atomicAdd(&sh.bulk_failed, 1);
+                if (f < kBulkFailMax) sh.bulk_fail_keys[f] = rkey[u];
+            }
+        }
+    }
+    __syncthreads();
+    stamp(1);
+    // ---- 3: the points of the voxels won: a thread per POINT of the store (owner[p]: the job whose voxel point p belongs to;
+    // the owner map lies where the set was), or -- a store that reaches up there -- a 32-lane group per voxel
+    const int n_jobs = min(sh.job_count, kWideJobs);
+    const int s1 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned owner_bytes = ((unsigned)(s1 - s0) * 2u + 15u) & ~15u;
+    if ((unsigned)s1 * 24u + owner_bytes <= free_top) {
+        unsigned short *owner = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(tile.points) + free_top - owner_bytes);
+        for (int p = s0 + tid; p < s1; p += kIcpThreads) owner[p - s0] = 0xFFFFu;  // (a voxel without a job leaves a gap)
+        __syncthreads();
+        for (int j = tid; j < n_jobs; j += kIcpThreads) {
+            const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+            const int cnt = (int)(w0 >> 24), off = (int)(w1 & 0xFFFFu) - s0;
+            for (int i = 0; i < cnt; ++i) owner[off + i] = (unsigned short)j;
+        }
+        __syncthreads();
+        constexpr int kPerThread = 6;  // points a thread keeps in flight: 3072 per trip
+        for (int p0 = s0 + tid; p0 < s1; p0 += kIcpThreads * kPerThread) {
+            double2 xy[kPerThread];
+            double zz[kPerThread];
+            bool ok[kPerThread];
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u) {
+                const int p = p0 + u * kIcpThreads;
+                ok[u] = false;
+                if (p < s1) {
+                    const unsigned j = owner[p - s0];
+                    if (j != 0xFFFFu) {
+                        const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+                        const int blk = (int)(w0 & 0xFFFFFFu), i = p - (int)(w1 & 0xFFFFu);
+                        xy[u] = block_xy(m, blk)[i];
+                        zz[u] = block_z(m, blk)[i];
+                        ok[u] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPerThread; ++u)
+                if (ok[u]) {
+                    double *q = tile.points + 3 * (p0 + u * kIcpThreads);
+                    q[0] = xy[u].x;
+                    q[1] = xy[u].y;
+                    q[2] = zz[u];
+                }
+        }
+    } else {
+        constexpr int kFly = 12;  // voxels a 32-lane group keeps in flight (lane i fetches point i: one 16-byte and one 8-byte load)
+        const int lane = tid & (kIcpGroup - 1), grp = tid / kIcpGroup;
+        for (int j0 = grp; j0 < n_jobs; j0 += kIcpGroupsPerBlock * kFly) {  // job j0 + 16 u: the groups share every trip evenly
+            double2 xy[kFly];
+            double zz[kFly];
+            int dst[kFly];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) {
+                dst[u] = -1;
+                const int j = j0 + u * kIcpGroupsPerBlock;
+                if (j < n_jobs) {
+                    const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+                    const int blk = (int)(w0 & 0xFFFFFFu), cnt = (int)(w0 >> 24), off = (int)(w1 & 0xFFFFu);
+                    if (lane < cnt) {
+                        dst[u] = off + lane;
+                        xy[u] = block_xy(m, blk)[lane];
+                        zz[u] = block_z(m, blk)[lane];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kFly; ++u)
+                if (dst[u] >= 0) {
+                    double *q = tile.points + 3 * dst[u];
+                    q[0] = xy[u].x;
+                    q[1] = xy[u].y;
+                    q[2] = zz[u];
+                }
+        }
+    }
+    __syncthreads();  // the points are in the store before their table entries say so
+    for (int j = tid; j < n_jobs; j += kIcpThreads) {
+        const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
+        __hip_atomic_store(&tile.vals[w1 >> 16], (w1 & 0xFFFFu) | (w0 & 0xFF000000u) | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    stamp(2);
+    // ---- 4: the queries' verdicts ----------------------------------------------------------------------------------------
+    if (sh.bulk_failed) {  // rare: which windows hold a cell that could not be entered
+        const int nf = sh.bulk_failed;
+        for_each_cell([&](int qt, unsigned rkey) {
+            bool hit = nf > kBulkFailMax;
+            for (int f = 0; f < min(nf, kBulkFailMax); ++f) hit = hit || sh.bulk_fail_keys[f] == rkey;
+            if (hit) metas[qt].valid = -1;
+        });
+        __syncthreads();
+    }
+    if (mine) {
+        WideMeta *meta = metas + tid;
+        meta->valid = meta->valid != -1 ? 1 : -1;
+        meta->list_state = 0;
+    }
+    if (range_err) *range_err_out = 1;
+    __syncthreads();
+    stamp(3);
+    return true;
+}
+
+}  // namespace kicp

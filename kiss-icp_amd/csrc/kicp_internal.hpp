@@ -217,6 +217,9 @@ struct IcpParams {
     int use_lds;           // stage candidate voxels in LDS (0 disables)
     int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
+    int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
+    int wide_prune;        // thread-per-query form: 0 visit every occupied voxel, 1 skip voxels by their box distance, 2 also bounded
+                           // by the previous iteration's neighbour (kicp_icp_wide.hpp; the result is the same)
     int inject_timeout;    // test hook: behave like a launch whose workgroups never became co-resident
     const PrepState *prep;  // pipeline mode: this frame's counts (copied into the frame record), or nullptr
     unsigned *prof_groups;  // profiling variant only: [kIcpProfIters][256 * 16][4] per-group records, or nullptr
@@ -247,6 +250,8 @@ struct Options {
     long icp_points_per_group = 1;
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
+    long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
+    long icp_wide_prune = 2;     // thread-per-query form: 0 visit every occupied voxel, 1 skip by box distance, 2 + bound from the last neighbour
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
     long icp_timing = 1;
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)

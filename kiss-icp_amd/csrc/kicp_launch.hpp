@@ -70,7 +70,7 @@ int icp_prepare(int device_id);
 int icp_blocks_per_cu(int lds_bytes);
 void launch_selftest_solve(const double *A, const double *b, int n, double *x, hipStream_t s);  // co-resident k_icp workgroups per CU (occupancy query, current device)
 size_t icp_granule_words(int G);
-void launch_icp(IcpParams P, int G, bool profile, hipStream_t s);
+void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s);
 void launch_ts_minmax(const double *ts, int n_ts, PrepState *prep, hipStream_t s);

@@ -455,8 +455,10 @@ __device__ __forceinline__ void group_min_dist_key(double &best, int &key) {
 // Establish the known window of the query s (voxel v): make sure every occupied voxel of the window is in
 // the tile.  Lane l answers for the window cells l and l + 32.  Returns false when the query cannot use the
 // tile (a voxel outside the tile's coordinate span, table or store full): it then searches HBM directly.
+// (Meta: IcpQueryMeta, or the 20-byte record of the thread-per-query variant -- v, lo, hi, valid, list_state)
+template <class Meta>
 __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, const double s[3], const int v[3], int lane,
-                                          IcpQueryMeta *meta, int &range_err) {
+                                          Meta *meta, int &range_err) {
     int lo[3], nn[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

@@ -350,6 +350,121 @@ def test_first_iteration_window_phase_is_bitwise_neutral(gpu, O, blocks):
     assert dt < TIGHT and dr < TIGHT
 
 
+def _wide_scene(kind, rng):
+    """(map points, source points, voxel size, guess) for the two regimes of the association"""
+    if kind == "full_voxels":  # 1 m voxels, up to 20 points each: long neighbourhoods, few queries per workgroup
+        world = random_cloud(rng, 30000, extent=25.0, z_extent=3.0)
+        src = world[rng.choice(len(world), 2500, replace=False)] + rng.normal(0, 0.03, (2500, 3))
+        return world, src, 1.0, make_pose((0.2, -0.1, 0.02), (0.002, -0.001, 0.01))
+    # small voxels over thin surfaces (floor + two walls): one to five points per voxel, half of the 27 cells empty
+    n = 40000
+    floor = np.stack([rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), rng.normal(0, 0.01, n)], axis=1)
+    wall1 = np.stack([np.full(n // 2, 6.0) + rng.normal(0, 0.01, n // 2), rng.uniform(-12, 12, n // 2), rng.uniform(0, 4, n // 2)], axis=1)
+    wall2 = np.stack([rng.uniform(-12, 12, n // 2), np.full(n // 2, -5.0) + rng.normal(0, 0.01, n // 2), rng.uniform(0, 4, n // 2)], axis=1)
+    world = np.concatenate([floor, wall1, wall2])
+    src = world[rng.choice(len(world), 6000, replace=False)] + rng.normal(0, 0.01, (6000, 3))
+    return world, src, 0.25, make_pose((0.06, -0.04, 0.01), (0.001, -0.001, 0.004))
+
+
+@pytest.mark.parametrize("kind", ["full_voxels", "small_voxels"])
+@pytest.mark.parametrize("blocks", [0, 1, 16])
+def test_thread_per_query_form_is_bitwise_the_group_form(gpu, O, kind, blocks):
+    """icp_wide: the association by a thread per source point (kicp_icp_wide.hpp) instead of a 32-lane group -- with every
+    level of its voxel skipping (icp_wide_prune 0 / 1 / 2).  Same runs, same order of additions: the pose must be the group
+    form's bit for bit, the counts (iterations, correspondences, points the REFERENCE examines) equal, the oracle's within
+    rounding.  blocks = 1: one workgroup takes the whole cloud -- runs of several 512-query chunks, whose later chunks go
+    through the map-direct queue; blocks = 16: a few hundred queries per workgroup (one chunk, the tile fills up)."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(73)
+    world, src, voxel, guess = _wide_scene(kind, rng)
+    g, o = VoxelHashMap(voxel, 100.0, 20), O.VoxelHashMap(voxel, 100.0, 20)
+    g.add_points(world)
+    o.add_points(world)
+    out = {}
+    try:
+        _cabi.set_option("icp_blocks", blocks)
+        for form in ("group", "wide0", "wide1", "wide2"):
+            _cabi.set_option("icp_wide", 0 if form == "group" else 1)
+            _cabi.set_option("icp_wide_prune", int(form[-1]) if form != "group" else 2)
+            r = Registration(500, 1e-4)
+            out[form] = (r.align_points_to_map(src, g, guess, 3.0 * voxel, voxel), dict(r.last_stats))
+    finally:
+        _cabi.set_option("icp_wide", -1)
+        _cabi.set_option("icp_wide_prune", 2)
+        _cabi.set_option("icp_blocks", 0)
+    for form in ("wide0", "wide1", "wide2"):
+        assert np.array_equal(out["group"][0], out[form][0]), form
+        for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
+            assert out["group"][1][k] == out[form][1][k], (form, k)
+    ro = O.Registration(500, 1e-4)
+    To = ro.align_points_to_map(src, o, guess, 3.0 * voxel, voxel)
+    dt, dr = pose_error(To, out["wide2"][0])
+    assert dt < TIGHT and dr < TIGHT
+    assert out["wide2"][1]["iterations"] == ro.last_stats["iterations"] > 1
+    assert out["wide2"][1]["points_examined"] == ro.last_stats["points_examined"]
+
+
+@pytest.mark.parametrize("prune", [0, 2])
+def test_thread_per_query_form_keeps_the_references_tie_order(gpu, O, prune):
+    """lattice map, queries exactly between lattice points (several candidates at EXACTLY the same distance in different
+    voxels), searched by the thread-per-query form: a voxel may only be skipped when its box is STRICTLY farther than what
+    is in hand, and among equals the smaller {shift position, index} wins -- VoxelHashMap.cpp:55-63's strict '<'."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
+    ax = np.arange(-6.0, 6.0, 0.25)
+    lattice = np.stack(np.meshgrid(ax, ax, np.arange(-1.0, 1.0, 0.25), indexing="ij"), axis=-1).reshape(-1, 3)
+    lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]
+    g.add_points(lattice)
+    o.add_points(lattice)
+    qa = np.arange(-4.0, 4.0, 0.5)
+    try:
+        _cabi.set_option("icp_wide", 1)
+        _cabi.set_option("icp_wide_prune", prune)
+        for offset in ((0.125, 0.125, 0.125), (0.0625, 0.125, 0.125), (0.9375, 0.125, 0.0625), (0.5, 0.0, 0.25)):
+            src = np.stack(np.meshgrid(qa, qa, np.array([-0.5, 0.0]), indexing="ij"), axis=-1).reshape(-1, 3) + np.array(offset)
+            for guess in (np.eye(4), make_pose((0.5, -0.25, 0.0))):
+                for iters in (1, 4):
+                    rg, ro = Registration(iters, 1e-12), O.Registration(iters, 1e-12)
+                    Tg = rg.align_points_to_map(src, g, guess, 3.0, 1.0)
+                    To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
+                    dt, dr = pose_error(To, Tg)
+                    assert dt < 1e-10 and dr < 1e-10, (offset, iters, dt, dr)
+                    assert rg.last_stats["n_corr_last"] == ro.last_stats["n_corr_last"]
+                    assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
+    finally:
+        _cabi.set_option("icp_wide", -1)
+        _cabi.set_option("icp_wide_prune", 2)
+
+
+def test_thread_per_query_form_in_the_pipeline(gpu, O):
+    """the same drive with the association forced to either form: trajectories and maps bit for bit equal (the pipeline
+    picks the form from the previous frame's cloud size, so a stream may change form from one frame to the next)"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like_vegetated
+
+    ds = kitti_like_vegetated(seed=3, n_frames=6, beams=32, azimuth_steps=1024)
+    poses = {}
+    try:
+        for wide in (0, 1):
+            _cabi.set_option("icp_wide", wide)
+            k = _pipe(deskew=False, voxel_size=0.5)
+            traj = []
+            for i in range(6):
+                k.register_frame(*ds[i])
+                traj.append(np.array(k.last_pose))
+            poses[wide] = (np.array(traj), k.local_map.num_voxels(), k.last_stats()["icp"]["points_examined"])
+    finally:
+        _cabi.set_option("icp_wide", -1)
+    assert np.array_equal(poses[0][0], poses[1][0])
+    assert poses[0][1:] == poses[1][1:]
+
+
 # ---- robustness ---------------------------------------------------------------------------------------------
 def test_two_pipelines_on_one_gpu_from_two_threads(gpu, O):
     """two LiDAR streams, two pipelines, two host threads, ONE GPU: the persistent registration kernels of the
