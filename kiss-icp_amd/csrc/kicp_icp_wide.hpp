@@ -284,10 +284,15 @@ __device__ __forceinline__ void wide_search(const MapView &m, const Tile &tile, 
 // The first iteration's window phase for up to 512 queries at once (the same four phases as tile_fill_bulk,
 // kicp_icp.hip; differences: the windows come from the owning threads' registers; the set of distinct cells has up
 // to 16384 slots -- 400 queries of the 1M-point configuration have five to eight thousand distinct cells, and a set
-// as crowded as 4096 slots were cost 45 us of probing in some workgroups (profiles/r03_ac_icp_probe_livox.txt) --
-// and no member list: the lookups walk the set's slots, three in flight per thread; the fetch jobs live in
-// sh.terms + sh.pts).  mine: this thread's query takes part (flag 1).  Leaves the verdict in metas[tid].valid
-// (1 / -1).  false: no room for the scratch (nothing was changed): the caller establishes the windows one by one.
+// as crowded as 4096 slots were cost 45 us of probing in some workgroups (profiles/r03_ac_icp_probe_livox.txt); the
+// fetch jobs live in sh.terms + sh.pts).  NEAR CELLS FIRST: the LDS store holds ~3.8 k points, the windows of a
+// workgroup of the 1M-point configuration ask for 6 .. 10 k, and what does not fit is read from the map by single
+// threads at every search (60 - 70 us per iteration in such workgroups against 8 where everything fits,
+// profiles/r04_a_icp_probe_livox.txt).  But a search that skips voxels by their distance visits the query's own voxel
+// and a face neighbour or two: so the cells within one step of some query's voxel (a flag bit in the set) are looked up
+// and given room in the store first, edges / corners / window extensions take what is left.
+// mine: this thread's query takes part (flag 1).  Leaves the verdict in metas[tid].valid (1 / -1).  false: no room
+// for the scratch (nothing was changed): the caller establishes the windows one by one.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &tile, IcpShared *shp, int cn, WideMeta *metas, bool mine, const double s[3], const int v[3],
                                                int *range_err_out, bool prof) {
@@ -305,15 +310,21 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     int range_err = 0;
     const int s0 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the store's end before this phase
     const unsigned free_top = tile.region_bytes & ~15u;  // (this form keeps no scan lists: the region is points only)
-    // the set of distinct cells: the largest power of two of slots that fits above the points, 32 per query at most
+    // the set of distinct cells (u32 {relative key | near bit}) and, below it, the list of its members (u16 slot numbers:
+    // near cells from the bottom, the others from the top): the largest power of two of slots, 64 per query at most,
+    // that leaves the list 3/4 of the slots (at least 1024 entries) above the points
+    constexpr unsigned kNearBit = 0x40000000u;  // (relative keys have 30 bits; kTileEmpty has bit 31 set)
+    const unsigned room = free_top - min(free_top, (unsigned)s0 * 24u);
     int set_log2 = 14;
-    while (set_log2 > 10 && ((1 << set_log2) > 32 * max(cn, 32) || (unsigned)s0 * 24u + (4u << set_log2) > free_top)) --set_log2;
-    if ((unsigned)s0 * 24u + (4u << set_log2) > free_top) return false;
+    while (set_log2 > 10 && ((1 << set_log2) > 64 * max(cn, 16) || (4u << set_log2) + (6u << (set_log2 - 2)) > room)) --set_log2;
+    if ((4u << set_log2) + 2048u > room) return false;
     const int S = 1 << set_log2;
+    const int Lcap = (int)min((unsigned)S, ((room - (4u << set_log2)) / 2u) & ~7u);
     unsigned *set = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tile.points) + free_top) - S;
+    unsigned short *cells = reinterpret_cast<unsigned short *>(set) - Lcap;
     // ---- 1: the windows; the set is cleared ---------------------------------------------------------------------------
     for (int i = tid; i < S; i += kIcpThreads) set[i] = kTileEmpty;
-    if (tid == 0) sh.job_count = sh.bulk_failed = 0;
+    if (tid == 0) sh.job_count = sh.bulk_failed = sh.cell_count = sh.list_entries = 0;  // (cell_count: near cells, list_entries: the others)
     if (mine) {
         WideMeta *meta = metas + tid;
 #pragma unroll
@@ -328,7 +339,7 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     }
     __syncthreads();
     // ---- 2a: the DISTINCT cells of all windows that the table does not know yet ----------------------------------------
-    auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key) for every in-range cell of every window taking part
+    auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key, within one step of the query's voxel) for every in-range cell of every window taking part
         for (int idx = tid; idx < cn * 64; idx += kIcpThreads) {
             const int qt = idx >> 6;
             const WideMeta *meta = metas + qt;
@@ -350,12 +361,12 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
                 metas[qt].valid = -1;  // outside the span of the relative keys
                 continue;
             }
-            fn(qt, rkey);
+            fn(qt, rkey, abs(ox) + abs(oy) + abs(oz) <= 1);
         }
     };
     const bool fresh = __hip_atomic_load(tile.entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
     const unsigned set_mask = (unsigned)(S - 1);
-    for_each_cell([&](int qt, unsigned rkey) {
+    for_each_cell([&](int qt, unsigned rkey, bool near) {
         const int slot = fresh ? -1 : tile_find(tile, rkey);
         if (slot >= 0) {
             if (__hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kTileOverflow) metas[qt].valid = -1;
@@ -364,8 +375,9 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
         unsigned si = (rkey * 0x9E3779B1u) >> (32 - set_log2);
         bool done = false;
         for (int probes = 0; probes < 64; ++probes) {
-            const unsigned old = atomicCAS(&set[si], kTileEmpty, rkey);
-            if (old == kTileEmpty || old == rkey) {
+            const unsigned old = atomicCAS(&set[si], kTileEmpty, near ? (rkey | kNearBit) : rkey);
+            if (old == kTileEmpty || (old & ~kNearBit) == rkey) {
+                if (near && old != kTileEmpty && !(old & kNearBit)) atomicOr(&set[si], kNearBit);
                 done = true;
                 break;
             }
@@ -374,18 +386,46 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
         if (!done) metas[qt].valid = -1;  // (a set this crowded: the query looks the map up itself, one by one)
     });
     __syncthreads();
+    // the members: near cells from the bottom of the list, the others from its top (one LDS atomic per wave and class)
+    for (int i = tid; i < S; i += kIcpThreads) {  // (S is a multiple of the workgroup size: every wave takes every trip)
+        const unsigned e = set[i];
+        const bool occ = e != kTileEmpty, nr = occ && (e & kNearBit), fr = occ && !nr;
+        const unsigned long long nm = __ballot(nr), fm = __ballot(fr);
+        int nb = 0, fb = 0;
+        if ((tid & 63) == 0) {
+            if (nm) nb = atomicAdd(&sh.cell_count, (int)__popcll(nm));
+            if (fm) fb = atomicAdd(&sh.list_entries, (int)__popcll(fm));
+        }
+        nb = __shfl(nb, 0, 64);
+        fb = __shfl(fb, 0, 64);
+        const int nrank = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+        const int frank = fb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        if (nr && nrank < Lcap) cells[nrank] = (unsigned short)i;
+        if (fr && frank < Lcap) cells[Lcap - 1 - frank] = (unsigned short)i;
+    }
+    __syncthreads();
+    const int n_near = sh.cell_count, n_far = sh.list_entries, n_cells = n_near + n_far;
+    const bool cells_lost = n_cells > Lcap;  // (more distinct cells than the list holds: every query of the chunk searches the map directly)
+    __syncthreads();
+    if (tid == 0) {
+        sh.cell_count = sh.list_entries = 0;  // (the caller's counters again)
+        if (cells_lost) sh.bulk_failed = kBulkFailMax + 1;
+    }
     stamp(0);
     // ---- 2b: one map lookup per distinct cell, three in flight per thread; occupied voxels enter the table and file a fetch job
     constexpr int kBatch = 3;
-    for (int i0 = 0; i0 < S; i0 += kIcpThreads * kBatch) {  // (every thread takes every trip: the counters below are kept wave by wave)
+    // (two segments with a barrier between them: every near cell has its room in the store before the first of the others asks)
+    for (int seg = 0; seg < 2 && !cells_lost; ++seg) {
+    const int j_end = seg == 0 ? n_near : n_cells;
+    for (int jb = seg == 0 ? 0 : n_near; jb < j_end; jb += kIcpThreads * kBatch) {  // (every thread takes every trip: the counters below are kept wave by wave)
         unsigned long long key[kBatch];
         unsigned rkey[kBatch];
         Slot a[kBatch][kProbeAhead];
         uint32_t hs[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const int i = i0 + tid + u * kIcpThreads;
-            rkey[u] = i < S ? set[i] : kTileEmpty;
+            const int j = jb + tid + u * kIcpThreads;  // near cells first: they take their room in the store before the others ask
+            rkey[u] = j < j_end ? (set[cells[j < n_near ? j : Lcap - 1 - (j - n_near)]] & ~kNearBit) : kTileEmpty;
             key[u] = 0;
             hs[u] = 0;
             if (rkey[u] != kTileEmpty) {
@@ -503,6 +543,7 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
         }
     }
     __syncthreads();
+    }
     stamp(1);
     // ---- 3: the points of the voxels won: a thread per POINT of the store (owner[p]: the job whose voxel point p belongs to;
     // the owner map lies where the set was), or -- a store that reaches up there -- a 32-lane group per voxel
@@ -589,7 +630,7 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     // ---- 4: the queries' verdicts ----------------------------------------------------------------------------------------
     if (sh.bulk_failed) {  // rare: which windows hold a cell that could not be entered
         const int nf = sh.bulk_failed;
-        for_each_cell([&](int qt, unsigned rkey) {
+        for_each_cell([&](int qt, unsigned rkey, bool) {
             bool hit = nf > kBulkFailMax;
             for (int f = 0; f < min(nf, kBulkFailMax); ++f) hit = hit || sh.bulk_fail_keys[f] == rkey;
             if (hit) metas[qt].valid = -1;

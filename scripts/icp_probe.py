@@ -39,6 +39,12 @@ if gp.size:
             print('   %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (
                 nm, g[:, j].mean() / 100, np.percentile(g[:, j], 50) / 100, np.percentile(g[:, j], 99) / 100, g[:, j].max() / 100))
         print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (g[:, 4].mean(), g[:, 4].max(), g[:, 5].mean(), g[:, 5].max()))
+        if (g[:, 6] == 4).all():
+            # thread-per-query form: the 'xform' field of a record carries the voxels its thread visited {LDS | map << 8}
+            # (the 'wait-in' field is phase A); in iteration 0 the records of groups 0..4 carry the window phase's parts instead
+            vis = g[:, 1] if it > 0 else g.reshape(-1, 16, g.shape[1])[:, 5:, 1].reshape(-1)
+            print('   voxels visited per query: in LDS mean %.2f max %d, in the map mean %.2f max %d (of ~%.1f occupied)' % (
+                (vis & 255).mean(), (vis & 255).max(), (vis >> 8).mean(), (vis >> 8).max(), 0.0))
         if it == 0 and int(opts.get('icp_bulk_fill', 1)):
             ph = g.reshape(-1, 16, g.shape[1])[:, 0:5, 1] / 100.0  # groups 0..4 carry tile_fill_bulk's phases in the xform field (4: the lookups alone)
             for j, nm in enumerate(('windows+dedup', 'enter (+lookups)', 'fetch', 'verdicts', 'lookups alone')):
