@@ -867,6 +867,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     sh.next_point = 0;    // queue of the window phase
                     sh.list_entries = 0;  // queue of the map-direct searches (this form keeps no scan lists)
                     sh.cell_count = 0;    // some query of the chunk needs the map-direct search
+                    sh.job_count = 0;     // queue of the map-resident voxels
                 }
                 __syncthreads();
                 tile.ox = sh.origin[0];
@@ -954,7 +955,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const unsigned tb0 = PROF ? ticks32() : 0u;
                 WideCounters ctr;
                 ctr.visited_lds = ctr.visited_map = 0u;
-                if (active && wq.flag == 0) {
+                WideBest wb;
+                wb.m_map = 0u;
+                bool searching = active && wq.flag == 0;
+                if (searching) {
                     // what can still matter: the correspondence threshold and -- its voxel still among the 27 -- last iteration's neighbour
                     double limit0 = limit_corr;
                     if (P.wide_prune > 1 && wq.have_nn && abs(wq.pv[0] - wq.v[0]) <= 1 && abs(wq.pv[1] - wq.v[1]) <= 1 && abs(wq.pv[2] - wq.v[2]) <= 1) {
@@ -963,15 +967,54 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         limit0 = dp < limit0 ? dp : limit0;
                     }
                     int bad = 0;
-                    wide_search<PROF>(m, tile, wq, limit0, P.wide_prune > 0, bad, ctr);
+                    wide_search_lds<PROF>(m, tile, wq, limit0, P.wide_prune > 0, bad, ctr, wb);
                     if (bad) {  // the tile cannot answer (a voxel outside the key span, an entry that did not fit): the map from now on
                         meta->valid = -1;
                         wq.flag = 2;
+                        searching = false;
                     }
+                }
+                // the voxels of this query that are in the map only go into the queue the groups serve below
+                WideItem *items = reinterpret_cast<WideItem *>(sh.terms);
+                int item_base = 0, n_mine = 0;
+                if (searching && wb.m_map) {
+                    n_mine = __popc(wb.m_map);
+                    item_base = atomicAdd(&sh.job_count, n_mine);
+                    unsigned todo = wb.m_map;
+                    for (int r = 0; r < n_mine; ++r) {
+                        const int jj = __ffs(todo) - 1;
+                        todo &= todo - 1u;
+                        if (item_base + r < kWideItems) {
+                            WideItem &it = items[item_base + r];
+                            it.s[0] = wq.s[0];
+                            it.s[1] = wq.s[1];
+                            it.s[2] = wq.s[2];
+                            it.d2 = DBL_MAX;
+                            it.blk_cnt = wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & ~(kTileReady | kTileGlobal);
+                            it.owner = (unsigned short)tid;
+                            it.j = (unsigned char)jj;
+                            it.k = 0;
+                        } else {  // (no room in the queue: this thread reads the voxel itself)
+                            wide_visit_map(m, tile, wq, jj, wb);
+                        }
+                    }
+                    if (PROF) ctr.visited_map += (unsigned)n_mine;
                 }
                 if (active && wq.flag == 2) sh.cell_count = 1;
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
                 __syncthreads();
+                const int n_items = min(sh.job_count, kWideItems);  // (the whole workgroup)
+                if (n_items > 0) {
+                    wide_serve_items(m, items, n_items, grp, lane);
+                    __syncthreads();
+                    for (int r = 0; r < n_mine; ++r)
+                        if (item_base + r < kWideItems) {
+                            const WideItem &it = items[item_base + r];
+                            wide_take(wb, wq.s[0], wq.s[1], wq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
+                        }
+                    __syncthreads();  // (the queue's memory is the slow paths' and phase C's next)
+                }
+                if (searching) wide_finish(wq, wb);
                 if (sh.cell_count) serve(2, &sh.list_entries);
                 if (PROF) t_group += ticks32() - tb0;
                 if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0) {

@@ -24,8 +24,12 @@
 //      instead of fifteen.  The result (neighbour, distance, ties) is the reference's, bit for bit: visiting fewer
 //      voxels only removes comparisons that are lost anyway; the order among equals is kept by the key
 //      {shift position, index in the voxel} exactly as in tile_scan;
-//   3. voxels the LDS store had no room for (kTileGlobal) are visited last, by the thread itself, with the bound
-//      tightened by everything found in LDS.
+//   3. voxels the LDS store had no room for (kTileGlobal) come last, with the bound tightened by everything found in
+//      LDS -- and not by the thread itself: a lane walking a full voxel in the map is five dependent HBM / L2 round
+//      trips, its wave, its workgroup and the whole grid wait for it (one such lane in a dense workgroup: 75 us per
+//      iteration, profiles/r04_b_icp_probe_livox.txt).  The thread files {query, block, count} in a queue in LDS; after
+//      a barrier the 32-lane groups serve the queue the way the first form reads map voxels (lane i point i, six
+//      voxels in flight), and the owners merge the answers.
 // Queries the tile cannot serve (outside the key span, table full) and queries of runs longer than one chunk go
 // through a small queue served by the 32-lane groups with the map-direct search of the first form (closest_neighbor_any).
 // The partition of the cloud (runs), the order in which products are added (phase C) and the exchange are those of
@@ -102,6 +106,35 @@ struct WideCounters {  // profiling build
     unsigned visited_lds, visited_map;
 };
 
+// a map-resident voxel some query still has to look at (the queue lives in sh.terms + sh.pts)
+struct WideItem {
+    double s[3];       // in: the query; out: the voxel's point closest to it
+    double d2;         // out: its squared distance
+    unsigned blk_cnt;  // block id | point count << 24
+    unsigned short owner;
+    unsigned char j, k;  // shift position of the voxel; out: index of the point in it
+};
+static_assert(sizeof(WideItem) == 40, "WideItem layout");
+constexpr int kWideItems = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk) / sizeof(WideItem));
+
+struct WideBest {  // a search in progress (between the LDS part and the map part)
+    double best, bx, by, bz;
+    double limit;  // nothing at a distance above this can be, or tie with, the answer
+    int bkey;
+    unsigned m_map;  // occupied cells whose points are in the map only
+};
+__device__ __forceinline__ void wide_take(WideBest &b, double sx, double sy, double sz, double x, double y, double z, int key, bool valid) {
+    const double ex = x - sx, ey = y - sy, ez = z - sz;
+    const double d = (ex * ex + ey * ey) + ez * ez;
+    if (valid && (d < b.best || (d == b.best && key < b.bkey))) {
+        b.best = d;
+        b.bkey = key;
+        b.bx = x;
+        b.by = y;
+        b.bz = z;
+    }
+}
+
 // the table entry of cell j of the 27 (any chain length); 0: not in the table
 __device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy, int vz, int j) {
     const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
@@ -115,8 +148,14 @@ __device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy,
 // distance that can still matter (see the head of this file); prune: skip voxels by their bound (off: every occupied
 // voxel is visited -- same result, for the tests and the measurements).  bad: the tile cannot answer (a voxel outside
 // the key span or one the table has no entry for): the caller sends the query to the map-direct search.
+// (first part: the table lookups and the voxels in LDS; the voxels in the map are left in b.m_map)
 template <bool PROF>
-__device__ __forceinline__ void wide_search(const MapView &m, const Tile &tile, WideQuery &q, double limit0, bool prune, int &bad, WideCounters &ctr) {
+__device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &tile, WideQuery &q, double limit0, bool prune, int &bad, WideCounters &ctr, WideBest &b) {
+    b.best = DBL_MAX;
+    b.bx = b.by = b.bz = 0.0;
+    b.bkey = 0x7FFFFFFF;
+    b.limit = limit0;
+    b.m_map = 0u;
     const int vx = q.v[0], vy = q.v[1], vz = q.v[2];
     const double sx = q.s[0], sy = q.s[1], sz = q.s[2];
     // ---- 1: which of the 27 cells are occupied (three batches of nine: 18 + 9 loads in flight, ~45 registers) -----------
@@ -196,27 +235,13 @@ __device__ __forceinline__ void wide_search(const MapView &m, const Tile &tile, 
     q.E = E;
     // ---- 2: the voxels in LDS, nearest layers first (shift order: the centre, the faces, the edges, the corners) ----
     const WideGaps gaps = wide_gaps(q.s, q.v, m.voxel_size);
-    double limit = limit0;  // nothing at a distance above this can be, or tie with, the answer
-    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
-    int bkey = 0x7FFFFFFF;
-    auto take = [&](double x, double y, double z, int key, bool valid) {
-        const double ex = x - sx, ey = y - sy, ez = z - sz;
-        const double d = (ex * ex + ey * ey) + ez * ez;
-        if (valid && (d < best || (d == best && key < bkey))) {
-            best = d;
-            bkey = key;
-            bx = x;
-            by = y;
-            bz = z;
-        }
-    };
     unsigned todo = m_lds;
     for (;;) {
         int j = -1;
         while (todo) {
             const int jj = __ffs(todo) - 1;
             todo &= todo - 1u;
-            if (!prune || !(wide_bound(gaps, jj) > limit)) {
+            if (!prune || !(wide_bound(gaps, jj) > b.limit)) {
                 j = jj;
                 break;
             }
@@ -229,53 +254,101 @@ __device__ __forceinline__ void wide_search(const MapView &m, const Tile &tile, 
             const int k1 = k0 + 1 < cnt ? k0 + 1 : k0;
             const double x0 = P[3 * k0], y0 = P[3 * k0 + 1], z0 = P[3 * k0 + 2];
             const double x1 = P[3 * k1], y1 = P[3 * k1 + 1], z1 = P[3 * k1 + 2];
-            take(x0, y0, z0, (j << 5) | k0, true);
-            take(x1, y1, z1, (j << 5) | k1, k1 != k0);
+            wide_take(b, sx, sy, sz, x0, y0, z0, (j << 5) | k0, true);
+            wide_take(b, sx, sy, sz, x1, y1, z1, (j << 5) | k1, k1 != k0);
         }
-        limit = best < limit ? best : limit;
+        b.limit = b.best < b.limit ? b.best : b.limit;
         if (PROF) ++ctr.visited_lds;
     }
-    // ---- 3: the voxels left in the map (HBM / L2): this thread reads them itself, four points in flight ----------------
+    // ---- 3 (prepared): the voxels in the map that can still matter ------------------------------------------------------
     todo = m_map;
-    for (;;) {
-        int j = -1;
+    if (prune)
         while (todo) {
             const int jj = __ffs(todo) - 1;
             todo &= todo - 1u;
-            if (!prune || !(wide_bound(gaps, jj) > limit)) {
-                j = jj;
-                break;
-            }
+            if (wide_bound(gaps, jj) > b.limit) m_map &= ~(1u << jj);
         }
-        if (j < 0) break;
-        const unsigned v = wide_entry(tile, vx, vy, vz, j);
-        const int blk = tile_ref(v), cnt = tile_cnt(v);
-        const double2 *XY = block_xy(m, blk);
-        const double *Z = block_z(m, blk);
-        for (int k0 = 0; k0 < cnt; k0 += 4) {
-            double2 xy[4];
-            double zz[4];
+    b.m_map = m_map;
+}
+
+// one map-resident voxel, read by the thread itself (items the queue had no room for)
+__device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &tile, const WideQuery &q, int j, WideBest &b) {
+    const unsigned v = wide_entry(tile, q.v[0], q.v[1], q.v[2], j);
+    const int blk = tile_ref(v), cnt = tile_cnt(v);
+    const double2 *XY = block_xy(m, blk);
+    const double *Z = block_z(m, blk);
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        double2 xy[4];
+        double zz[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u < cnt ? k0 + u : k0;
-                xy[u] = XY[k];
-                zz[u] = Z[k];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) take(xy[u].x, xy[u].y, zz[u], (j << 5) | (k0 + u), k0 + u < cnt);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u < cnt ? k0 + u : k0;
+            xy[u] = XY[k];
+            zz[u] = Z[k];
         }
-        limit = best < limit ? best : limit;
-        if (PROF) ++ctr.visited_map;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wide_take(b, q.s[0], q.s[1], q.s[2], xy[u].x, xy[u].y, zz[u], (j << 5) | (k0 + u), k0 + u < cnt);
     }
-    q.d2 = best;
-    if (best < DBL_MAX) {
-        const int j = bkey >> 5;
-        q.nn[0] = bx;
-        q.nn[1] = by;
-        q.nn[2] = bz;
-        q.pv[0] = vx + (int)((kShift.x >> (2 * j)) & 3) - 1;
-        q.pv[1] = vy + (int)((kShift.y >> (2 * j)) & 3) - 1;
-        q.pv[2] = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+}
+
+// the queue of map-resident voxels, served by the 32-lane groups: lane i reads point i of the voxel (one 16-byte and one
+// 8-byte load, coalesced), kChunk voxels of a group in flight; the closest point of the voxel -- the smaller index among
+// equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back into the item
+__device__ __forceinline__ void wide_serve_items(const MapView &m, WideItem *items, int n_items, int grp, int lane) {
+    for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kChunk) {  // wave-uniform trip count
+        double2 xy[kChunk];
+        double zz[kChunk];
+        double qs[kChunk][3];
+        bool ld[kChunk], valid[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            const int e = e0 + kIcpGroupsPerBlock * u;
+            valid[u] = e < n_items;
+            const WideItem &it = items[valid[u] ? e : 0];
+            const int blk = (int)(it.blk_cnt & 0xFFFFFFu), cnt = (int)(it.blk_cnt >> 24);
+            qs[u][0] = it.s[0];
+            qs[u][1] = it.s[1];
+            qs[u][2] = it.s[2];
+            ld[u] = valid[u] && lane < cnt;
+            if (ld[u]) {
+                xy[u] = block_xy(m, blk)[lane];
+                zz[u] = block_z(m, blk)[lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            double d = DBL_MAX;
+            if (ld[u]) {
+                const double ex = xy[u].x - qs[u][0], ey = xy[u].y - qs[u][1], ez = zz[u] - qs[u][2];
+                d = (ex * ex + ey * ey) + ez * ez;
+            }
+            double gd = d;
+            int gk = ld[u] ? lane : 0x7FFFFFFF;
+            group_min_dist_key(gd, gk);
+            if (valid[u] && ld[u] && gk == lane) {
+                WideItem &it = items[e0 + kIcpGroupsPerBlock * u];
+                it.s[0] = xy[u].x;
+                it.s[1] = xy[u].y;
+                it.s[2] = zz[u];
+                it.d2 = gd;
+                it.k = (unsigned char)lane;
+            }
+        }
+    }
+}
+
+// the search's result into the query's registers
+__device__ __forceinline__ void wide_finish(WideQuery &q, const WideBest &b) {
+    q.d2 = b.best;
+    q.have_nn = false;
+    if (b.best < DBL_MAX) {
+        const int j = b.bkey >> 5;
+        q.nn[0] = b.bx;
+        q.nn[1] = b.by;
+        q.nn[2] = b.bz;
+        q.pv[0] = q.v[0] + (int)((kShift.x >> (2 * j)) & 3) - 1;
+        q.pv[1] = q.v[1] + (int)((kShift.y >> (2 * j)) & 3) - 1;
+        q.pv[2] = q.v[2] + (int)((kShift.z >> (2 * j)) & 3) - 1;
         q.have_nn = true;
     }
 }
@@ -643,6 +716,7 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
         meta->list_state = 0;
     }
     if (range_err) *range_err_out = 1;
+    if (tid == 0) sh.job_count = 0;  // (the caller's queue counter again)
     __syncthreads();
     stamp(3);
     return true;
