@@ -955,6 +955,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const unsigned tb0 = PROF ? ticks32() : 0u;
                 WideCounters ctr;
                 ctr.visited_lds = ctr.visited_map = 0u;
+                ctr.t_lookup = ctr.t_chains = ctr.t_walk = 0u;
                 WideBest wb;
                 wb.m_map = 0u;
                 bool searching = active && wq.flag == 0;
@@ -974,45 +975,49 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         searching = false;
                     }
                 }
-                // the voxels of this query that are in the map only go into the queue the groups serve below
+                // Whatever this query still has to look at -- voxels in the LDS store beyond the first, voxels in the map -- goes
+                // into the queue the groups serve; what does not fit waits for the next round.
                 WideItem *items = reinterpret_cast<WideItem *>(sh.terms);
-                int item_base = 0, n_mine = 0;
-                if (searching && wb.m_map) {
-                    n_mine = __popc(wb.m_map);
-                    item_base = atomicAdd(&sh.job_count, n_mine);
-                    unsigned todo = wb.m_map;
-                    for (int r = 0; r < n_mine; ++r) {
-                        const int jj = __ffs(todo) - 1;
-                        todo &= todo - 1u;
-                        if (item_base + r < kWideItems) {
+                unsigned pend_lds = searching ? wb.m_lds : 0u, pend_map = searching ? wb.m_map : 0u;
+                if (active && wq.flag == 2) sh.cell_count = 1;
+                const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
+                for (;;) {
+                    const int n_want = __popc(pend_lds) + __popc(pend_map);
+                    int item_base = 0, n_filed = 0;
+                    if (n_want) {
+                        item_base = atomicAdd(&sh.job_count, n_want);
+                        n_filed = max(0, min(n_want, kWideItems - item_base));
+                        for (int r = 0; r < n_filed; ++r) {
+                            const bool from_lds = pend_lds != 0u;
+                            const unsigned pend = from_lds ? pend_lds : pend_map;
+                            const int jj = __ffs(pend) - 1;
+                            if (from_lds)
+                                pend_lds = pend & (pend - 1u);
+                            else
+                                pend_map = pend & (pend - 1u);
                             WideItem &it = items[item_base + r];
                             it.s[0] = wq.s[0];
                             it.s[1] = wq.s[1];
                             it.s[2] = wq.s[2];
                             it.d2 = DBL_MAX;
-                            it.blk_cnt = wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & ~(kTileReady | kTileGlobal);
+                            it.blk_cnt = (wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & ~(kTileReady | kTileGlobal)) | (from_lds ? kWideItemLds : 0u);
                             it.owner = (unsigned short)tid;
                             it.j = (unsigned char)jj;
                             it.k = 0;
-                        } else {  // (no room in the queue: this thread reads the voxel itself)
-                            wide_visit_map(m, tile, wq, jj, wb);
                         }
+                        if (PROF) ctr.visited_map += (unsigned)n_filed;  // (items filed, of either kind)
                     }
-                    if (PROF) ctr.visited_map += (unsigned)n_mine;
-                }
-                if (active && wq.flag == 2) sh.cell_count = 1;
-                const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
-                __syncthreads();
-                const int n_items = min(sh.job_count, kWideItems);  // (the whole workgroup)
-                if (n_items > 0) {
-                    wide_serve_items(m, items, n_items, grp, lane);
                     __syncthreads();
-                    for (int r = 0; r < n_mine; ++r)
-                        if (item_base + r < kWideItems) {
-                            const WideItem &it = items[item_base + r];
-                            wide_take(wb, wq.s[0], wq.s[1], wq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
-                        }
-                    __syncthreads();  // (the queue's memory is the slow paths' and phase C's next)
+                    const int n_items = min(sh.job_count, kWideItems);  // (the whole workgroup)
+                    if (n_items == 0) break;
+                    wide_serve_items(m, tile, items, n_items, grp, lane);
+                    __syncthreads();
+                    for (int r = 0; r < n_filed; ++r) {
+                        const WideItem &it = items[item_base + r];
+                        wide_take(wb, wq.s[0], wq.s[1], wq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
+                    }
+                    if (tid == 0) sh.job_count = 0;
+                    __syncthreads();  // (the queue's memory is the next round's, the slow paths' and phase C's)
                 }
                 if (searching) wide_finish(wq, wb);
                 if (sh.cell_count) serve(2, &sh.list_entries);
@@ -1024,6 +1029,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (it == 0 && P.bulk_fill && grp < 5) r[0] = (r[0] & 0xFFFFu) | (min(sh.bulk_ticks[grp], 0xFFFFu) << 16);  // groups 0..4: the window phase's parts instead
                     r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)min(t_scan, 0xFFFFu) << 16);
                     r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)min(wq.E, 0xFFFF) << 16);
+                    if (grp & 1) {  // the odd groups (same wave as the even one in front): where the search's time went instead
+                        r[0] = (r[0] & 0xFFFFu) | (min(ctr.t_walk, 0xFFFFu) << 16);
+                        r[2] = min(ctr.t_lookup, 0xFFFFu) | (min(ctr.t_chains, 0xFFFFu) << 16);
+                    }
                     r[3] = 4u;
                     prof_path = 4u;
                 }

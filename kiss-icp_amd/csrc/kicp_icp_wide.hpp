@@ -14,22 +14,22 @@
 //      (54 independent LDS loads), values of the hits together (27 more); what is still open after two probes (a
 //      few per cent) is finished by one short loop.  Result: which cells are occupied (LDS / map resident), and E,
 //      the number of points the reference examines (VoxelHashMap.cpp:58-61) -- no point has been read yet;
-//   2. the occupied voxels are visited in shift order, but a voxel that CANNOT hold the answer is skipped: the
-//      squared distance from the query to the voxel's box is a lower bound of every distance the reference would
-//      compute there (built from the same operations, see wide_gaps), and a voxel whose bound exceeds what is
-//      already in hand loses every strict '<' of VoxelHashMap.cpp:58-63.  "In hand" = the best of this search, the
-//      correspondence threshold (a neighbour beyond it is dropped by Registration.cpp:72 whatever it is), and -- from
-//      the second iteration on -- the distance to the PREVIOUS iteration's neighbour when that point is still inside
-//      the 27 voxels (the map does not change during AlignPointsToMap): a converged query visits one to three voxels
-//      instead of fifteen.  The result (neighbour, distance, ties) is the reference's, bit for bit: visiting fewer
-//      voxels only removes comparisons that are lost anyway; the order among equals is kept by the key
-//      {shift position, index in the voxel} exactly as in tile_scan;
-//   3. voxels the LDS store had no room for (kTileGlobal) come last, with the bound tightened by everything found in
-//      LDS -- and not by the thread itself: a lane walking a full voxel in the map is five dependent HBM / L2 round
-//      trips, its wave, its workgroup and the whole grid wait for it (one such lane in a dense workgroup: 75 us per
-//      iteration, profiles/r04_b_icp_probe_livox.txt).  The thread files {query, block, count} in a queue in LDS; after
-//      a barrier the 32-lane groups serve the queue the way the first form reads map voxels (lane i point i, six
-//      voxels in flight), and the owners merge the answers.
+//   2. a voxel that CANNOT hold the answer is never read: the squared distance from the query to the voxel's box is a
+//      lower bound of every distance the reference would compute there (built from the same operations, see
+//      wide_gaps), and a voxel whose bound exceeds what is already in hand loses every strict '<' of
+//      VoxelHashMap.cpp:58-63.  "In hand" = the best of this search, the correspondence threshold (a neighbour beyond it
+//      is dropped by Registration.cpp:72 whatever it is), and -- from the second iteration on -- the distance to the
+//      PREVIOUS iteration's neighbour when that point is still inside the 27 voxels (the map does not change during
+//      AlignPointsToMap): a converged query reads one voxel or two instead of fifteen.  The result (neighbour, distance,
+//      ties) is the reference's, bit for bit: reading fewer voxels only removes comparisons that are lost anyway, and
+//      the order among equals is kept by the key {shift position, index in the voxel} exactly as in tile_scan;
+//   3. the thread walks ONE voxel itself -- the first occupied one in shift order: its own voxel, else a face
+//      neighbour --, which gives it a distance to skip by.  Whatever survives that (in dense surroundings a query
+//      that floats beside a surface keeps ten voxels of twenty points; its 63 neighbours in the wave would wait for
+//      it: 52 us per iteration in such workgroups, profiles/r04_d_icp_probe_livox.txt) is filed as {query, voxel}
+//      items in a queue in LDS and served by the 32-lane groups: lane i point i, six voxels in flight, voxels in the
+//      LDS store and voxels the store had no room for (kTileGlobal: read from the map in HBM / L2) alike; the owners
+//      merge the answers.  The work is spread over all 512 lanes whatever the queries look like.
 // Queries the tile cannot serve (outside the key span, table full) and queries of runs longer than one chunk go
 // through a small queue served by the 32-lane groups with the map-direct search of the first form (closest_neighbor_any).
 // The partition of the cloud (runs), the order in which products are added (phase C) and the exchange are those of
@@ -94,34 +94,28 @@ __device__ __forceinline__ WideGaps wide_gaps(const double s[3], const int v[3],
     }
     return g;
 }
-__device__ __forceinline__ double wide_bound(const WideGaps &g, int j) {
-    const unsigned cx = (unsigned)(kShift.x >> (2 * j)) & 3u, cy = (unsigned)(kShift.y >> (2 * j)) & 3u, cz = (unsigned)(kShift.z >> (2 * j)) & 3u;
-    const double bx = cx == 0u ? g.m2[0] : (cx == 2u ? g.p2[0] : 0.0);
-    const double by = cy == 0u ? g.m2[1] : (cy == 2u ? g.p2[1] : 0.0);
-    const double bz = cz == 0u ? g.m2[2] : (cz == 2u ? g.p2[2] : 0.0);
-    return (bx + by) + bz;
-}
-
 struct WideCounters {  // profiling build
     unsigned visited_lds, visited_map;
+    unsigned t_lookup, t_chains, t_walk;  // 10 ns ticks: the unrolled lookups, chains longer than two slots, the voxels in LDS
 };
 
 // a map-resident voxel some query still has to look at (the queue lives in sh.terms + sh.pts)
 struct WideItem {
     double s[3];       // in: the query; out: the voxel's point closest to it
     double d2;         // out: its squared distance
-    unsigned blk_cnt;  // block id | point count << 24
+    unsigned blk_cnt;  // block id (kWideItemLds: position in the LDS store) | point count << 24
     unsigned short owner;
     unsigned char j, k;  // shift position of the voxel; out: index of the point in it
 };
 static_assert(sizeof(WideItem) == 40, "WideItem layout");
+constexpr unsigned kWideItemLds = 0x40000000u;  // the voxel's points are in the workgroup's LDS store
 constexpr int kWideItems = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk) / sizeof(WideItem));
 
 struct WideBest {  // a search in progress (between the LDS part and the map part)
     double best, bx, by, bz;
     double limit;  // nothing at a distance above this can be, or tie with, the answer
     int bkey;
-    unsigned m_map;  // occupied cells whose points are in the map only
+    unsigned m_lds, m_map;  // occupied cells that can still matter and have not been read: points in the LDS store / in the map only
 };
 __device__ __forceinline__ void wide_take(WideBest &b, double sx, double sy, double sz, double x, double y, double z, int key, bool valid) {
     const double ex = x - sx, ey = y - sy, ez = z - sz;
@@ -135,13 +129,20 @@ __device__ __forceinline__ void wide_take(WideBest &b, double sx, double sy, dou
     }
 }
 
-// the table entry of cell j of the 27 (any chain length); 0: not in the table
+// the table entry of cell j of the 27 (any chain length); 0: not in the table.  (Plain loads here and in the search:
+// in this form nobody writes the table while it is searched -- fills and searches are separated by barriers.)
 __device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy, int vz, int j) {
     const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
     unsigned rkey;
     if (!tile_rel(tile, qx, qy, qz, rkey)) return 0u;
-    const int slot = tile_find(tile, rkey);
-    return slot >= 0 ? __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    unsigned s = tile_hash(tile, rkey);
+    for (int probes = 0; probes < kTileMaxProbes; ++probes) {
+        const unsigned k = tile.keys[s];
+        if (k == rkey) return tile.vals[s];
+        if (k == kTileEmpty) return 0u;
+        s = (s + 1u) & (unsigned)tile.slots_mask;
+    }
+    return 0u;
 }
 
 // GetClosestNeighbor for the query of THIS thread against the workgroup's tile.  limit0: an upper bound of every
@@ -156,6 +157,7 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     b.bkey = 0x7FFFFFFF;
     b.limit = limit0;
     b.m_map = 0u;
+    const unsigned tp0 = PROF ? ticks32() : 0u;
     const int vx = q.v[0], vy = q.v[1], vz = q.v[2];
     const double sx = q.s[0], sy = q.s[1], sz = q.s[2];
     // ---- 1: which of the 27 cells are occupied (three batches of nine: 18 + 9 loads in flight, ~45 registers) -----------
@@ -198,8 +200,8 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
             (void)tile_rel(tile, qx, qy, qz, rk[u]);
             h0[u] = tile_hash(tile, rk[u]);
-            ka[u] = __hip_atomic_load(&tile.keys[h0[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            kb[u] = __hip_atomic_load(&tile.keys[(h0[u] + 1u) & (unsigned)tile.slots_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ka[u] = tile.keys[h0[u]];
+            kb[u] = tile.keys[(h0[u] + 1u) & (unsigned)tile.slots_mask];
         }
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
@@ -208,11 +210,12 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             const bool hit_b = go_b && kb[u] == rk[u];
             if (go_b && !hit_b && kb[u] != kTileEmpty) open |= 1u << (jb + u);
             val[u] = 0u;
-            if (hit_a || hit_b) val[u] = __hip_atomic_load(&tile.vals[hit_a ? h0[u] : ((h0[u] + 1u) & (unsigned)tile.slots_mask)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hit_a || hit_b) val[u] = tile.vals[hit_a ? h0[u] : ((h0[u] + 1u) & (unsigned)tile.slots_mask)];
         }
 #pragma unroll
         for (int u = 0; u < 9; ++u) classify(val[u], jb + u);
     }
+    const unsigned tp1 = PROF ? ticks32() : 0u;
     while (open) {  // chains longer than two slots
         const int j = __ffs(open) - 1;
         open &= open - 1u;
@@ -222,9 +225,9 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
         (void)tile_rel(tile, qx, qy, qz, rkey);
         unsigned s = (tile_hash(tile, rkey) + 2u) & (unsigned)tile.slots_mask;
         for (int probes = 2; probes < kTileMaxProbes; ++probes) {
-            const unsigned k = __hip_atomic_load(&tile.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned k = tile.keys[s];
             if (k == rkey) {
-                classify(__hip_atomic_load(&tile.vals[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), j);
+                classify(tile.vals[s], j);
                 break;
             }
             if (k == kTileEmpty) break;
@@ -233,20 +236,12 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     }
     if (bad) return;
     q.E = E;
-    // ---- 2: the voxels in LDS, nearest layers first (shift order: the centre, the faces, the edges, the corners) ----
+    const unsigned tp2 = PROF ? ticks32() : 0u;
+    // ---- 2: the first occupied voxel in shift order (the query's own, else a face neighbour ...), walked by this thread ----
     const WideGaps gaps = wide_gaps(q.s, q.v, m.voxel_size);
-    unsigned todo = m_lds;
-    for (;;) {
-        int j = -1;
-        while (todo) {
-            const int jj = __ffs(todo) - 1;
-            todo &= todo - 1u;
-            if (!prune || !(wide_bound(gaps, jj) > b.limit)) {
-                j = jj;
-                break;
-            }
-        }
-        if (j < 0) break;
+    const unsigned first = m_lds ? (m_lds & (0u - m_lds)) : 0u;  // (lowest set bit)
+    if (first) {
+        const int j = __ffs(first) - 1;
         const unsigned v = wide_entry(tile, vx, vy, vz, j);
         const int ref = tile_ref(v), cnt = tile_cnt(v);
         const double *P = tile.points + 3 * ref;
@@ -258,23 +253,42 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             wide_take(b, sx, sy, sz, x1, y1, z1, (j << 5) | k1, k1 != k0);
         }
         b.limit = b.best < b.limit ? b.best : b.limit;
+        m_lds &= ~first;
         if (PROF) ++ctr.visited_lds;
     }
-    // ---- 3 (prepared): the voxels in the map that can still matter ------------------------------------------------------
-    todo = m_map;
-    if (prune)
-        while (todo) {
-            const int jj = __ffs(todo) - 1;
-            todo &= todo - 1u;
-            if (wide_bound(gaps, jj) > b.limit) m_map &= ~(1u << jj);
+    // ---- 3 (prepared): what can still matter after that -- the bounds of all 27 cells, unrolled (sums of three of the
+    // nine squared gaps picked at compile time) -------------------------------------------------------------------------
+    if (prune) {
+        unsigned keep = 0u;
+#pragma unroll
+        for (int j = 0; j < 27; ++j) {
+            const int cx = (int)((kShift.x >> (2 * j)) & 3), cy = (int)((kShift.y >> (2 * j)) & 3), cz = (int)((kShift.z >> (2 * j)) & 3);
+            const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
+            const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
+            const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
+            if (!((bx + by) + bz > b.limit)) keep |= 1u << j;
         }
+        m_lds &= keep;
+        m_map &= keep;
+    }
+    b.m_lds = m_lds;
     b.m_map = m_map;
+    if (PROF) {
+        ctr.t_lookup = tp1 - tp0;
+        ctr.t_chains = tp2 - tp1;
+        ctr.t_walk = ticks32() - tp2;
+    }
 }
 
-// one map-resident voxel, read by the thread itself (items the queue had no room for)
+// one voxel read by the thread itself (not used while the queue has rounds; kept for a caller that cannot wait)
 __device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &tile, const WideQuery &q, int j, WideBest &b) {
     const unsigned v = wide_entry(tile, q.v[0], q.v[1], q.v[2], j);
     const int blk = tile_ref(v), cnt = tile_cnt(v);
+    if (!(v & kTileGlobal)) {
+        const double *P = tile.points + 3 * blk;
+        for (int k = 0; k < cnt; ++k) wide_take(b, q.s[0], q.s[1], q.s[2], P[3 * k], P[3 * k + 1], P[3 * k + 2], (j << 5) | k, true);
+        return;
+    }
     const double2 *XY = block_xy(m, blk);
     const double *Z = block_z(m, blk);
     for (int k0 = 0; k0 < cnt; k0 += 4) {
@@ -291,10 +305,11 @@ __device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &til
     }
 }
 
-// the queue of map-resident voxels, served by the 32-lane groups: lane i reads point i of the voxel (one 16-byte and one
-// 8-byte load, coalesced), kChunk voxels of a group in flight; the closest point of the voxel -- the smaller index among
-// equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back into the item
-__device__ __forceinline__ void wide_serve_items(const MapView &m, WideItem *items, int n_items, int grp, int lane) {
+// the queue of {query, voxel} items, served by the 32-lane groups: lane i reads point i of the voxel (from the LDS store,
+// or from the map: one 16-byte and one 8-byte load, coalesced), kChunk voxels of a group in flight; the closest point of
+// the voxel -- the smaller index among equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back
+// into the item
+__device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane) {
     for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kChunk) {  // wave-uniform trip count
         double2 xy[kChunk];
         double zz[kChunk];
@@ -305,14 +320,21 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, WideItem *ite
             const int e = e0 + kIcpGroupsPerBlock * u;
             valid[u] = e < n_items;
             const WideItem &it = items[valid[u] ? e : 0];
-            const int blk = (int)(it.blk_cnt & 0xFFFFFFu), cnt = (int)(it.blk_cnt >> 24);
+            const int blk = (int)(it.blk_cnt & 0xFFFFFFu), cnt = (int)((it.blk_cnt >> 24) & 63u);
             qs[u][0] = it.s[0];
             qs[u][1] = it.s[1];
             qs[u][2] = it.s[2];
             ld[u] = valid[u] && lane < cnt;
             if (ld[u]) {
-                xy[u] = block_xy(m, blk)[lane];
-                zz[u] = block_z(m, blk)[lane];
+                if (it.blk_cnt & kWideItemLds) {
+                    const double *P = tile.points + 3 * (blk + lane);
+                    xy[u].x = P[0];
+                    xy[u].y = P[1];
+                    zz[u] = P[2];
+                } else {
+                    xy[u] = block_xy(m, blk)[lane];
+                    zz[u] = block_z(m, blk)[lane];
+                }
             }
         }
 #pragma unroll

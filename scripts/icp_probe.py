@@ -42,9 +42,17 @@ if gp.size:
         if (g[:, 6] == 4).all():
             # thread-per-query form: the 'xform' field of a record carries the voxels its thread visited {LDS | map << 8}
             # (the 'wait-in' field is phase A); in iteration 0 the records of groups 0..4 carry the window phase's parts instead
-            vis = g[:, 1] if it > 0 else g.reshape(-1, 16, g.shape[1])[:, 5:, 1].reshape(-1)
-            print('   voxels visited per query: in LDS mean %.2f max %d, in the map mean %.2f max %d (of ~%.1f occupied)' % (
-                (vis & 255).mean(), (vis & 255).max(), (vis >> 8).mean(), (vis >> 8).max(), 0.0))
+            gw = g.reshape(-1, 16, g.shape[1])
+            ev = gw[:, (6 if it == 0 else 0)::2, :].reshape(-1, g.shape[1])  # even groups: visits
+            od = gw[:, (5 if it == 0 else 1)::2, :].reshape(-1, g.shape[1])  # odd groups: walk | lookup, chains
+            vis = ev[:, 1]
+            print('   voxels per query: walked by the thread mean %.2f max %d, filed as items mean %.2f max %d' % (
+                (vis & 255).mean(), (vis & 255).max(), (vis >> 8).mean(), (vis >> 8).max()))
+            for nm, col in (('lookups', od[:, 4]), ('chains', od[:, 5]), ('walk', od[:, 1])):
+                print('   wave %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (nm, col.mean() / 100, np.percentile(col, 50) / 100, np.percentile(col, 99) / 100, col.max() / 100))
+            slow = np.argsort(-od[:, 3])[:6]
+            for w in slow:
+                print('   slow wave: scan %6.2f = lookups %6.2f + chains %6.2f + walk %6.2f us (+ queueing)' % (od[w, 3] / 100, od[w, 4] / 100, od[w, 5] / 100, od[w, 1] / 100))
         if it == 0 and int(opts.get('icp_bulk_fill', 1)):
             ph = g.reshape(-1, 16, g.shape[1])[:, 0:5, 1] / 100.0  # groups 0..4 carry tile_fill_bulk's phases in the xform field (4: the lookups alone)
             for j, nm in enumerate(('windows+dedup', 'enter (+lookups)', 'fetch', 'verdicts', 'lookups alone')):
