@@ -380,7 +380,7 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     of the map voxel it falls in under the initial guess, E = population of the 27 voxels around it.
  *                     Defaults 128, -1 (= 10 when the cloud has at most 64 points per workgroup, else no quadratic term),
  *                     200, 1 (dense_div 0 switches the last term off).  Clouds of more than 64 points per workgroup (the
- *                     1M-point / 0.1 m configuration) use  "icp_weight_long_base" (128) + c + E  instead.  The weights decide nothing but which workgroup
+ *                     1M-point / 0.1 m configuration) use  "icp_weight_long_base" (128) + c + "icp_weight_long_emul" (1) * E  instead.  The weights decide nothing but which workgroup
  *                     serves which points -- hence the order of the sums, deterministically (integer arithmetic on data).
  *                     What they are tuned for: no run's voxel neighbourhood may outgrow a workgroup's LDS (~5.3 k points:
  *                     the densest runs near the sensor), and no run may need many more 16-point rounds than the others

@@ -850,6 +850,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         P.weight_base = (int)options().icp_weight_base;
         P.weight_quad = (int)options().icp_weight_quad;
         P.weight_long_base = (int)options().icp_weight_long_base;
+        P.weight_long_emul = (int)options().icp_weight_long_emul;
         P.weight_dense_min = (int)options().icp_weight_dense_min;
         P.weight_dense_div = (int)options().icp_weight_dense_div;
         P.work = r->work.as<double>();
@@ -1483,6 +1484,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         I.weight_base = (int)options().icp_weight_base;
         I.weight_quad = (int)options().icp_weight_quad;
         I.weight_long_base = (int)options().icp_weight_long_base;
+        I.weight_long_emul = (int)options().icp_weight_long_emul;
         I.weight_dense_min = (int)options().icp_weight_dense_min;
         I.weight_dense_div = (int)options().icp_weight_dense_div;
     }
@@ -2389,6 +2391,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_weight_long_base")) {
         if (value < 1 || value > 4096) return KICP_ERR_INVALID_ARG;
         options().icp_weight_long_base = value;
+    } else if (!strcmp(name, "icp_weight_long_emul")) {
+        if (value < 0 || value > 64) return KICP_ERR_INVALID_ARG;
+        options().icp_weight_long_emul = value;
     } else if (!strcmp(name, "icp_weight_dense_min")) {
         if (value < 0 || value > 100000) return KICP_ERR_INVALID_ARG;
         options().icp_weight_dense_min = value;

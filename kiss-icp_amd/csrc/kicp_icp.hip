@@ -227,7 +227,7 @@ __device__ __forceinline__ bool tile_fill_bulk(MapView m, Tile tile, IcpShared *
             hs[u] = 0;
             if (j < n_cells) {
                 rkey[u] = set[cells[j]];
-                key[u] = pack_voxel(tile.ox + (int)(rkey[u] >> 20), tile.oy + (int)((rkey[u] >> 10) & 1023u), tile.oz + (int)(rkey[u] & 1023u));
+                key[u] = tile_unrel(tile, rkey[u]);
                 hs[u] = hash_key(key[u], m.mask);
             }
         }
@@ -465,7 +465,7 @@ struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter 
     uint32_t mask;
     double voxel_size;
     PipeState *state;
-    int weight_base, weight_long_base, weight_quad, dense_min, dense_div;
+    int weight_base, weight_long_base, weight_long_emul, weight_quad, dense_min, dense_div;
     unsigned spin_limit;
 };
 __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
@@ -506,7 +506,7 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
         int rerr = 0;
         const Probe pr = probe27(m, sp[0], sp[1], sp[2], lane, rerr);
         const int c = __shfl(pr.cnt, 0, kIcpGroup);  // the point's own voxel (shift 0 of the table)
-        const int dense = dense_div > 0 ? max(0, pr.E - dense_min) / dense_div : 0;
+        const int dense = (dense_div > 0 ? max(0, pr.E - dense_min) / dense_div : 0) * (long_runs ? P.weight_long_emul : 1);
         const int w = w_base + c + (quad > 0 ? (c * c) / quad : 0) + dense;
         if (lane == 0) {
             granule_store(P.wts + q, epoch_base, (unsigned)w);
@@ -686,6 +686,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         R.weight_base = P.weight_base;
         R.weight_quad = P.weight_quad;
         R.weight_long_base = P.weight_long_base;
+        R.weight_long_emul = P.weight_long_emul;
         R.dense_min = P.weight_dense_min;
         R.dense_div = P.weight_dense_div;
         R.spin_limit = P.spin_limit;
@@ -858,16 +859,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     wq.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
                     if (wq.flag == 1) sh.any_fill = 1;
                     if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
-                        sh.origin[0] = vx - kTileSpan / 2;
-                        sh.origin[1] = vy - kTileSpan / 2;
-                        sh.origin[2] = vz - kTileSpan / 2;
+                        sh.origin[0] = vx - kTileSpanXY / 2;
+                        sh.origin[1] = vy - kTileSpanXY / 2;
+                        sh.origin[2] = vz - kTileSpanZ / 2;
                     }
                 }
                 if (tid == 0) {
                     sh.next_point = 0;    // queue of the window phase
                     sh.list_entries = 0;  // queue of the map-direct searches (this form keeps no scan lists)
                     sh.cell_count = 0;    // some query of the chunk needs the map-direct search
-                    sh.job_count = 0;     // queue of the map-resident voxels
+                    sh.job_count = 0;     // queue of the voxels in the LDS store that are left to the groups
+                    sh.bulk_failed = 0;   // queue of the voxels in the map
                 }
                 __syncthreads();
                 tile.ox = sh.origin[0];
@@ -876,8 +878,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 // The slow paths: the queries that need one file themselves in a queue (sh.pts), the 32-lane groups serve it
                 // with the routines of the first form, the owners read the verdicts back.  mode 1: establish the window
                 // (tile_fill); mode 2: search the map directly (closest_neighbor_any).
-                auto serve = [&](int mode, int *counter) {
+                auto serve = [&](int mode, int *counter) -> int {
                     bool pending = active && wq.flag == mode;
+                    int served = 0;
                     for (;;) {
                         int slot = -1;
                         if (pending) {
@@ -897,6 +900,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         __syncthreads();
                         const int filed = min(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), kWideQueue);
                         if (filed == 0) break;  // (the whole workgroup)
+                        served += filed;
                         for (int e = grp; e < filed; e += kIcpGroupsPerBlock) {
                             IcpPoint &r = sh.pts[e];
                             const double s[3] = {r.s[0], r.s[1], r.s[2]};
@@ -935,6 +939,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __syncthreads();
                     }
+                    return served;
                 };
                 // ---- B0: windows.  All of them in the first iteration (workgroup-wide), a few now and then later ----
                 const unsigned tb00 = PROF ? ticks32() : 0u;
@@ -943,9 +948,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (it == 0 && base == 0 && P.bulk_fill) {
                         int rerr = 0;
                         const bool mine = active && wq.flag == 1;
-                        bulk_done = wide_fill_bulk(m, tile, &sh, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF);
-                        if (rerr) range_err = 1;
+                        int r = wide_fill_bulk(m, tile, &sh, 0, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF);
+                        bulk_done = r == 1;
                         if (bulk_done && mine) wq.flag = meta->valid > 0 ? 0 : 2;
+                        if (r == 2) {
+                            // more distinct cells than the scratch holds (sparse surroundings: nobody shares a cell): 128 queries at a
+                            // time, whose windows have 8192 cells at most
+                            bulk_done = true;
+                            for (int lo = 0; lo < cn; lo += 128) {
+                                const int hi = min(cn, lo + 128);
+                                const bool part = mine && tid >= lo && tid < hi;
+                                r = wide_fill_bulk(m, tile, &sh, lo, hi, wmetas, part, wq.s, wq.v, &rerr, false);
+                                if (r == 1) {
+                                    if (part) wq.flag = meta->valid > 0 ? 0 : 2;
+                                } else {
+                                    bulk_done = false;  // (the rest one by one, below)
+                                }
+                            }
+                        }
+                        if (rerr) range_err = 1;
                     }
                     if (!bulk_done) serve(1, &sh.next_point);
                     if (tid == 0) sh.any_fill = 0;  // (barriers inside both routes: everybody has read it)
@@ -976,51 +997,62 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                 }
                 // Whatever this query still has to look at -- voxels in the LDS store beyond the first, voxels in the map -- goes
-                // into the queue the groups serve; what does not fit waits for the next round.
+                // into the two queues the groups serve; what does not fit waits for the next round.
                 WideItem *items = reinterpret_cast<WideItem *>(sh.terms);
                 unsigned pend_lds = searching ? wb.m_lds : 0u, pend_map = searching ? wb.m_map : 0u;
                 if (active && wq.flag == 2) sh.cell_count = 1;
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
-                for (;;) {
-                    const int n_want = __popc(pend_lds) + __popc(pend_map);
-                    int item_base = 0, n_filed = 0;
-                    if (n_want) {
-                        item_base = atomicAdd(&sh.job_count, n_want);
-                        n_filed = max(0, min(n_want, kWideItems - item_base));
-                        for (int r = 0; r < n_filed; ++r) {
-                            const bool from_lds = pend_lds != 0u;
-                            const unsigned pend = from_lds ? pend_lds : pend_map;
-                            const int jj = __ffs(pend) - 1;
-                            if (from_lds)
-                                pend_lds = pend & (pend - 1u);
-                            else
-                                pend_map = pend & (pend - 1u);
-                            WideItem &it = items[item_base + r];
-                            it.s[0] = wq.s[0];
-                            it.s[1] = wq.s[1];
-                            it.s[2] = wq.s[2];
-                            it.d2 = DBL_MAX;
-                            it.blk_cnt = (wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & ~(kTileReady | kTileGlobal)) | (from_lds ? kWideItemLds : 0u);
-                            it.owner = (unsigned short)tid;
-                            it.j = (unsigned char)jj;
-                            it.k = 0;
-                        }
-                        if (PROF) ctr.visited_map += (unsigned)n_filed;  // (items filed, of either kind)
-                    }
-                    __syncthreads();
-                    const int n_items = min(sh.job_count, kWideItems);  // (the whole workgroup)
-                    if (n_items == 0) break;
-                    wide_serve_items(m, tile, items, n_items, grp, lane);
-                    __syncthreads();
+                int prof_items = 0, prof_map_items = 0, prof_rounds = 0, prof_direct = 0;
+                auto file_items = [&](unsigned &pend, int *counter, int cap, WideItem *dst, int &base, int &n_filed) {
+                    const int n_want = __popc(pend);
+                    base = 0;
+                    n_filed = 0;
+                    if (n_want == 0) return;
+                    base = atomicAdd(counter, n_want);
+                    n_filed = max(0, min(n_want, cap - base));
                     for (int r = 0; r < n_filed; ++r) {
-                        const WideItem &it = items[item_base + r];
+                        const int jj = __ffs(pend) - 1;
+                        pend &= pend - 1u;
+                        WideItem &it = dst[base + r];
+                        it.s[0] = wq.s[0];
+                        it.s[1] = wq.s[1];
+                        it.s[2] = wq.s[2];
+                        it.d2 = DBL_MAX;
+                        it.blk_cnt = wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & ~(kTileReady | kTileGlobal);
+                        it.owner = (unsigned short)tid;
+                        it.j = (unsigned char)jj;
+                        it.k = 0;
+                    }
+                    if (PROF) ctr.visited_map += (unsigned)n_filed;  // (items filed, of either kind)
+                };
+                auto merge_items = [&](const WideItem *src, int base, int n_filed) {
+                    for (int r = 0; r < n_filed; ++r) {
+                        const WideItem &it = src[base + r];
                         wide_take(wb, wq.s[0], wq.s[1], wq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
                     }
-                    if (tid == 0) sh.job_count = 0;
-                    __syncthreads();  // (the queue's memory is the next round's, the slow paths' and phase C's)
+                };
+                for (;;) {
+                    int base_l, nf_l, base_m, nf_m;
+                    file_items(pend_lds, &sh.job_count, kWideItemsLds, items, base_l, nf_l);
+                    file_items(pend_map, &sh.bulk_failed, kWideItemsMap, items + kWideItemsLds, base_m, nf_m);
+                    __syncthreads();
+                    const int n_l = min(sh.job_count, kWideItemsLds), n_m = min(sh.bulk_failed, kWideItemsMap);  // (the whole workgroup)
+                    if (n_l + n_m == 0) break;
+                    if (PROF) {
+                        prof_items += n_l + n_m;
+                        prof_map_items += n_m;
+                        ++prof_rounds;
+                    }
+                    if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane);
+                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane);
+                    __syncthreads();
+                    merge_items(items, base_l, nf_l);
+                    merge_items(items + kWideItemsLds, base_m, nf_m);
+                    if (tid == 0) sh.job_count = sh.bulk_failed = 0;
+                    __syncthreads();  // (the queues' memory is the next round's, the slow paths' and phase C's)
                 }
                 if (searching) wide_finish(wq, wb);
-                if (sh.cell_count) serve(2, &sh.list_entries);
+                if (sh.cell_count) prof_direct = serve(2, &sh.list_entries);
                 if (PROF) t_group += ticks32() - tb0;
                 if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0) {
                     // this thread's record of the iteration (10 ns ticks); same layout as the first form's group records
@@ -1033,6 +1065,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         r[0] = (r[0] & 0xFFFFu) | (min(ctr.t_walk, 0xFFFFu) << 16);
                         r[2] = min(ctr.t_lookup, 0xFFFFu) | (min(ctr.t_chains, 0xFFFFu) << 16);
                     }
+                    if (grp == 2) r[2] = (unsigned)min(prof_direct, 0xFFFF) | ((unsigned)min(prof_rounds, 0xFFFF) << 16);  // workgroup: map-direct queries, queue rounds
+                    if (grp == 4) r[2] = (unsigned)min(prof_items, 0xFFFF) | ((unsigned)min(prof_map_items, 0xFFFF) << 16);  // workgroup: items served, of them in the map
                     r[3] = 4u;
                     prof_path = 4u;
                 }
@@ -1123,9 +1157,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 pt.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
                 if (pt.flag == 1) sh.any_fill = 1;
                 if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
-                    sh.origin[0] = vx - kTileSpan / 2;
-                    sh.origin[1] = vy - kTileSpan / 2;
-                    sh.origin[2] = vz - kTileSpan / 2;
+                    sh.origin[0] = vx - kTileSpanXY / 2;
+                    sh.origin[1] = vy - kTileSpanXY / 2;
+                    sh.origin[2] = vz - kTileSpanZ / 2;
                 }
             }
             if (tid == 0) sh.next_point = kIcpGroupsPerBlock;  // points 0..15 go to the groups directly

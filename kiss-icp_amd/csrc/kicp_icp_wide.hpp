@@ -103,13 +103,16 @@ struct WideCounters {  // profiling build
 struct WideItem {
     double s[3];       // in: the query; out: the voxel's point closest to it
     double d2;         // out: its squared distance
-    unsigned blk_cnt;  // block id (kWideItemLds: position in the LDS store) | point count << 24
+    unsigned blk_cnt;  // block id (LDS queue: position in the LDS store) | point count << 24
     unsigned short owner;
     unsigned char j, k;  // shift position of the voxel; out: index of the point in it
 };
 static_assert(sizeof(WideItem) == 40, "WideItem layout");
-constexpr unsigned kWideItemLds = 0x40000000u;  // the voxel's points are in the workgroup's LDS store
 constexpr int kWideItems = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk) / sizeof(WideItem));
+// Two queues in that memory: voxels in the LDS store (a trip of the serving loop is an LDS round trip) and voxels in the
+// map (a trip is an HBM / L2 round trip) -- mixed, every trip of every group waited for a map voxel
+// (17 us per round of 486 items, profiles/r04_f_icp_probe_livox.txt).
+constexpr int kWideItemsLds = 320, kWideItemsMap = kWideItems - kWideItemsLds;
 
 struct WideBest {  // a search in progress (between the LDS part and the map part)
     double best, bx, by, bz;
@@ -309,6 +312,7 @@ __device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &til
 // or from the map: one 16-byte and one 8-byte load, coalesced), kChunk voxels of a group in flight; the closest point of
 // the voxel -- the smaller index among equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back
 // into the item
+template <bool LDS>
 __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane) {
     for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kChunk) {  // wave-uniform trip count
         double2 xy[kChunk];
@@ -326,7 +330,7 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
             qs[u][2] = it.s[2];
             ld[u] = valid[u] && lane < cnt;
             if (ld[u]) {
-                if (it.blk_cnt & kWideItemLds) {
+                if (LDS) {
                     const double *P = tile.points + 3 * (blk + lane);
                     xy[u].x = P[0];
                     xy[u].y = P[1];
@@ -389,8 +393,11 @@ __device__ __forceinline__ void wide_finish(WideQuery &q, const WideBest &b) {
 // mine: this thread's query takes part (flag 1).  Leaves the verdict in metas[tid].valid (1 / -1).  false: no room
 // for the scratch (nothing was changed): the caller establishes the windows one by one.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &tile, IcpShared *shp, int cn, WideMeta *metas, bool mine, const double s[3], const int v[3],
-                                               int *range_err_out, bool prof) {
+// Returns 1 done, 0 no room for the scratch, 2 more distinct cells than the member list holds (nothing was entered; the
+// caller comes again with fewer queries: 128 queries have at most 8192 cells).  Queries q_lo <= q < q_hi take part.
+__device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile, IcpShared *shp, int q_lo, int q_hi, WideMeta *metas, bool mine, const double s[3], const int v[3],
+                                              int *range_err_out, bool prof) {
+    const int cn = q_hi - q_lo;
     IcpShared &sh = *shp;
     const int tid = threadIdx.x;
     unsigned tk = prof ? ticks32() : 0u;
@@ -405,23 +412,24 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     int range_err = 0;
     const int s0 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the store's end before this phase
     const unsigned free_top = tile.region_bytes & ~15u;  // (this form keeps no scan lists: the region is points only)
-    // the set of distinct cells (u32 {relative key | near bit}) and, below it, the list of its members (u16 slot numbers:
-    // near cells from the bottom, the others from the top): the largest power of two of slots, 64 per query at most,
-    // that leaves the list 3/4 of the slots (at least 1024 entries) above the points
-    constexpr unsigned kNearBit = 0x40000000u;  // (relative keys have 30 bits; kTileEmpty has bit 31 set)
+    // the set of distinct cells (u32 relative keys), a bit per slot ("near"), and the list of the set's members (u16 slot
+    // numbers: near cells from the bottom, the others from the top): the largest power of two of slots, 64 per query at
+    // most, that leaves the list 3/4 of the slots (at least 1024 entries) above the points
     const unsigned room = free_top - min(free_top, (unsigned)s0 * 24u);
     int set_log2 = 14;
-    while (set_log2 > 10 && ((1 << set_log2) > 64 * max(cn, 16) || (4u << set_log2) + (6u << (set_log2 - 2)) > room)) --set_log2;
-    if ((4u << set_log2) + 2048u > room) return false;
+    while (set_log2 > 10 && ((1 << set_log2) > 64 * max(cn, 16) || (4u << set_log2) + (1u << (set_log2 - 3)) + (6u << (set_log2 - 2)) > room)) --set_log2;
+    if ((4u << set_log2) + (1u << (set_log2 - 3)) + 2048u > room) return 0;
     const int S = 1 << set_log2;
-    const int Lcap = (int)min((unsigned)S, ((room - (4u << set_log2)) / 2u) & ~7u);
+    const int Lcap = (int)min((unsigned)S, ((room - (4u << set_log2) - (1u << (set_log2 - 3))) / 2u) & ~7u);
     unsigned *set = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(tile.points) + free_top) - S;
-    unsigned short *cells = reinterpret_cast<unsigned short *>(set) - Lcap;
+    unsigned *near_bits = set - S / 32;
+    unsigned short *cells = reinterpret_cast<unsigned short *>(near_bits) - Lcap;
     // ---- 1: the windows; the set is cleared ---------------------------------------------------------------------------
     for (int i = tid; i < S; i += kIcpThreads) set[i] = kTileEmpty;
+    for (int i = tid; i < S / 32; i += kIcpThreads) near_bits[i] = 0u;
     if (tid == 0) sh.job_count = sh.bulk_failed = sh.cell_count = sh.list_entries = 0;  // (cell_count: near cells, list_entries: the others)
     if (mine) {
-        WideMeta *meta = metas + tid;
+        WideMeta *meta = metas + tid;  // (the chunk's queries are the threads': query tid, q_lo <= tid < q_hi)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double f = s[a] / m.voxel_size - (double)v[a];  // position inside the voxel, [0, 1)
@@ -436,7 +444,7 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     // ---- 2a: the DISTINCT cells of all windows that the table does not know yet ----------------------------------------
     auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key, within one step of the query's voxel) for every in-range cell of every window taking part
         for (int idx = tid; idx < cn * 64; idx += kIcpThreads) {
-            const int qt = idx >> 6;
+            const int qt = q_lo + (idx >> 6);
             const WideMeta *meta = metas + qt;
             if (meta->list_state != 2) continue;
             const int ny = meta->hi[1] - meta->lo[1] + 1, nz = meta->hi[2] - meta->lo[2] + 1, nx = meta->hi[0] - meta->lo[0] + 1;
@@ -470,9 +478,9 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
         unsigned si = (rkey * 0x9E3779B1u) >> (32 - set_log2);
         bool done = false;
         for (int probes = 0; probes < 64; ++probes) {
-            const unsigned old = atomicCAS(&set[si], kTileEmpty, near ? (rkey | kNearBit) : rkey);
-            if (old == kTileEmpty || (old & ~kNearBit) == rkey) {
-                if (near && old != kTileEmpty && !(old & kNearBit)) atomicOr(&set[si], kNearBit);
+            const unsigned old = atomicCAS(&set[si], kTileEmpty, rkey);
+            if (old == kTileEmpty || old == rkey) {
+                if (near) atomicOr(&near_bits[si >> 5], 1u << (si & 31u));
                 done = true;
                 break;
             }
@@ -484,7 +492,7 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     // the members: near cells from the bottom of the list, the others from its top (one LDS atomic per wave and class)
     for (int i = tid; i < S; i += kIcpThreads) {  // (S is a multiple of the workgroup size: every wave takes every trip)
         const unsigned e = set[i];
-        const bool occ = e != kTileEmpty, nr = occ && (e & kNearBit), fr = occ && !nr;
+        const bool occ = e != kTileEmpty, nr = occ && ((near_bits[i >> 5] >> (i & 31)) & 1u), fr = occ && !nr;
         const unsigned long long nm = __ballot(nr), fm = __ballot(fr);
         int nb = 0, fb = 0;
         if ((tid & 63) == 0) {
@@ -500,17 +508,22 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
     }
     __syncthreads();
     const int n_near = sh.cell_count, n_far = sh.list_entries, n_cells = n_near + n_far;
-    const bool cells_lost = n_cells > Lcap;  // (more distinct cells than the list holds: every query of the chunk searches the map directly)
+    const bool cells_lost = n_cells > Lcap;  // (more distinct cells than the list holds)
     __syncthreads();
-    if (tid == 0) {
-        sh.cell_count = sh.list_entries = 0;  // (the caller's counters again)
-        if (cells_lost) sh.bulk_failed = kBulkFailMax + 1;
+    if (tid == 0) sh.cell_count = sh.list_entries = 0;  // (the caller's counters again)
+    if (cells_lost) {  // nothing has been entered: the queries are as they were, the caller comes again with fewer of them
+        if (mine) {
+            metas[tid].valid = 0;
+            metas[tid].list_state = 0;
+        }
+        __syncthreads();
+        return 2;
     }
     stamp(0);
     // ---- 2b: one map lookup per distinct cell, three in flight per thread; occupied voxels enter the table and file a fetch job
     constexpr int kBatch = 3;
     // (two segments with a barrier between them: every near cell has its room in the store before the first of the others asks)
-    for (int seg = 0; seg < 2 && !cells_lost; ++seg) {
+    for (int seg = 0; seg < 2; ++seg) {
     const int j_end = seg == 0 ? n_near : n_cells;
     for (int jb = seg == 0 ? 0 : n_near; jb < j_end; jb += kIcpThreads * kBatch) {  // (every thread takes every trip: the counters below are kept wave by wave)
         unsigned long long key[kBatch];
@@ -520,11 +533,11 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int j = jb + tid + u * kIcpThreads;  // near cells first: they take their room in the store before the others ask
-            rkey[u] = j < j_end ? (set[cells[j < n_near ? j : Lcap - 1 - (j - n_near)]] & ~kNearBit) : kTileEmpty;
+            rkey[u] = j < j_end ? set[cells[j < n_near ? j : Lcap - 1 - (j - n_near)]] : kTileEmpty;
             key[u] = 0;
             hs[u] = 0;
             if (rkey[u] != kTileEmpty) {
-                key[u] = pack_voxel(tile.ox + (int)(rkey[u] >> 20), tile.oy + (int)((rkey[u] >> 10) & 1023u), tile.oz + (int)(rkey[u] & 1023u));
+                key[u] = tile_unrel(tile, rkey[u]);
                 hs[u] = hash_key(key[u], m.mask);
             }
         }
@@ -738,10 +751,10 @@ __device__ __forceinline__ bool wide_fill_bulk(const MapView &m, const Tile &til
         meta->list_state = 0;
     }
     if (range_err) *range_err_out = 1;
-    if (tid == 0) sh.job_count = 0;  // (the caller's queue counter again)
+    if (tid == 0) sh.job_count = sh.bulk_failed = 0;  // (the caller's queue counters again)
     __syncthreads();
     stamp(3);
-    return true;
+    return 1;
 }
 
 }  // namespace kicp

@@ -197,7 +197,8 @@ struct IcpParams {
     unsigned long long *wts;  // one tagged granule per sorted position: the point's run weight, written by k_icp's prologue
                               // (runs of equal weight), or nullptr (runs of equal length)
     int weight_base, weight_quad;  // a point weighs base + c (+ c^2 / quad; quad < 0: when runs are short), c = population of its voxel,
-    int weight_long_base;                    //   (clouds of more than 64 points per workgroup: long_base + c + E)
+    int weight_long_base;                    //   (clouds of more than 64 points per workgroup: long_base + c + long_emul * E)
+    int weight_long_emul;
     int weight_dense_min, weight_dense_div;  //   + max(0, E - dense_min) / dense_div, E = population of its 27 voxels (dense_div 0: off)
     double *work;         // N x 3 transformed source, private to the launch
     const int *n_ptr;     // device count (pipeline) or nullptr
@@ -261,7 +262,8 @@ struct Options {
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
     long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
-    long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + E)
+    long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + emul * E)
+    long icp_weight_long_emul = 1;    // ... and the multiplier of E there
     long icp_weight_dense_min = 200;  // ... + (population of its 27 voxels - this) / icp_weight_dense_div when positive
     long icp_weight_dense_div = 1;    //     (0: off)
     long icp_weight_quad = -1;   // the weight also carries population^2 / this; 0: never; -1: when runs are short (kicp_sort.hip)

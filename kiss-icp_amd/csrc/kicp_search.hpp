@@ -347,10 +347,14 @@ constexpr unsigned kTileEmpty = 0xFFFFFFFFu;
 constexpr unsigned kTileReady = 0x80000000u;   // the entry is complete (LDS voxels: the points are in the store)
 constexpr unsigned kTileGlobal = 0x40000000u;  // the LDS store was full: the points are read from the map block in HBM / L2
 constexpr unsigned kTileOverflow = 0xFFFFFFFEu;  // block id beyond 24 bits: queries that need this voxel search HBM
-constexpr int kTileSpan = 1024;                  // relative voxel coordinates 0 .. 1023 per axis
+// relative voxel coordinates of a tile key: 11 bits for x and y, 10 for z -- with 0.1 m voxels 205 m x 205 m x 102 m, the
+// whole reach of a 100 m sensor (10 bits per axis until round 4: far-field runs of the 1M-point configuration, a few
+// hundred sparse points spread over more than 102 m, left the span and searched the map directly: 285 of 373 queries of
+// one workgroup, 45 us per iteration, profiles/r04_f_icp_probe_livox.txt).  x stays below 2047, so no key is kTileEmpty.
+constexpr int kTileSpanXY = 2048, kTileSpanZ = 1024;
 
 struct Tile {
-    unsigned *keys;  // [slots] relative voxel key (10 bits per axis) or kTileEmpty
+    unsigned *keys;  // [slots] relative voxel key (x 11 | y 11 | z 10 bits) or kTileEmpty
     unsigned *vals;  // [slots]
     int slots_mask;  // slots - 1 (2048 slots for runs of at most 64 points, else 4096)
     int hash_shift;  // 32 - log2(slots)
@@ -374,8 +378,11 @@ __device__ __forceinline__ int tile_ref(unsigned val) { return (int)(val & 0xFFF
 __device__ __forceinline__ int tile_cnt(unsigned val) { return (int)((val >> 24) & 63u); }
 __device__ __forceinline__ bool tile_rel(const Tile &t, int qx, int qy, int qz, unsigned &key) {
     const unsigned rx = (unsigned)(qx - t.ox), ry = (unsigned)(qy - t.oy), rz = (unsigned)(qz - t.oz);
-    key = (rx << 20) | (ry << 10) | rz;
-    return rx < (unsigned)kTileSpan && ry < (unsigned)kTileSpan && rz < (unsigned)kTileSpan;
+    key = (rx << 21) | (ry << 10) | rz;
+    return rx < (unsigned)(kTileSpanXY - 1) && ry < (unsigned)kTileSpanXY && rz < (unsigned)kTileSpanZ;
+}
+__device__ __forceinline__ unsigned long long tile_unrel(const Tile &t, unsigned key) {  // the map key of a relative key
+    return pack_voxel(t.ox + (int)(key >> 21), t.oy + (int)((key >> 10) & 2047u), t.oz + (int)(key & 1023u));
 }
 __device__ __forceinline__ unsigned tile_hash(const Tile &t, unsigned key) { return (key * 0x9E3779B1u) >> t.hash_shift; }
 static_assert(kIcpTileSlots == 4096, "hash_shift is derived from 4096 / 2048 slots");

@@ -50,6 +50,11 @@ if gp.size:
                 (vis & 255).mean(), (vis & 255).max(), (vis >> 8).mean(), (vis >> 8).max()))
             for nm, col in (('lookups', od[:, 4]), ('chains', od[:, 5]), ('walk', od[:, 1])):
                 print('   wave %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (nm, col.mean() / 100, np.percentile(col, 50) / 100, np.percentile(col, 99) / 100, col.max() / 100))
+            wgd, wgr, wgi, wgm, wgt = gw[:, 2, 4], gw[:, 2, 5], gw[:, 4, 4], gw[:, 4, 5], gw[:, :, 8].max(axis=1) / 100.0
+            print('   per workgroup: map-direct queries mean %.1f max %d; items served mean %.1f max %d (in the map mean %.1f max %d) in rounds mean %.2f max %d' % (
+                wgd.mean(), wgd.max(), wgi.mean(), wgi.max(), wgm.mean(), wgm.max(), wgr.mean(), wgr.max()))
+            for w in np.argsort(-wgt)[:10]:
+                print('      wg %3d: %6.2f us  run %3d  direct %3d  items %4d (map %4d)  rounds %d' % (w, wgt[w], gw[w, 0, 7], wgd[w], wgi[w], wgm[w], wgr[w]))
             slow = np.argsort(-od[:, 3])[:6]
             for w in slow:
                 print('   slow wave: scan %6.2f = lookups %6.2f + chains %6.2f + walk %6.2f us (+ queueing)' % (od[w, 3] / 100, od[w, 4] / 100, od[w, 5] / 100, od[w, 1] / 100))
