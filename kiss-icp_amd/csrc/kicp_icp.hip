@@ -858,9 +858,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                  meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
                     wq.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
                     if (wq.flag == 1) sh.any_fill = 1;
-                    if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
-                        sh.origin[0] = vx - kTileSpanXY / 2;
-                        sh.origin[1] = vy - kTileSpanXY / 2;
+                    if (it == 0 && j == 0) {
+                        // The tile's relative voxel coordinates: centred on the SENSOR when the map's reach fits the span (every
+                        // query is a scan point: within max_distance of it) -- a far-field run of a few hundred sparse points
+                        // may lie all around the sensor, farther apart than any span centred on one of them covers --, else on
+                        // the run's first point.
+                        const bool reach_fits = m.max_distance * inv_voxel < (double)(kTileSpanXY / 2 - 4);
+                        const int cx = reach_fits ? voxel_coord(guess.t[0], m.voxel_size) : vx, cy = reach_fits ? voxel_coord(guess.t[1], m.voxel_size) : vy;
+                        sh.origin[0] = cx - kTileSpanXY / 2;
+                        sh.origin[1] = cy - kTileSpanXY / 2;
                         sh.origin[2] = vz - kTileSpanZ / 2;
                     }
                 }

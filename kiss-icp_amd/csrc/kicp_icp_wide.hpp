@@ -23,13 +23,13 @@
 //      AlignPointsToMap): a converged query reads one voxel or two instead of fifteen.  The result (neighbour, distance,
 //      ties) is the reference's, bit for bit: reading fewer voxels only removes comparisons that are lost anyway, and
 //      the order among equals is kept by the key {shift position, index in the voxel} exactly as in tile_scan;
-//   3. the thread walks ONE voxel itself -- the first occupied one in shift order: its own voxel, else a face
-//      neighbour --, which gives it a distance to skip by.  Whatever survives that (in dense surroundings a query
-//      that floats beside a surface keeps ten voxels of twenty points; its 63 neighbours in the wave would wait for
-//      it: 52 us per iteration in such workgroups, profiles/r04_d_icp_probe_livox.txt) is filed as {query, voxel}
-//      items in a queue in LDS and served by the 32-lane groups: lane i point i, six voxels in flight, voxels in the
-//      LDS store and voxels the store had no room for (kTileGlobal: read from the map in HBM / L2) alike; the owners
-//      merge the answers.  The work is spread over all 512 lanes whatever the queries look like.
+//   3. the thread walks voxels itself while that is cheap: the first occupied one in shift order (its own voxel, else
+//      a face neighbour) always -- it gives a distance to skip by --, then at most four voxels / 24 points in all.  What
+//      survives beyond that (in dense surroundings a query that floats beside a surface keeps ten voxels of twenty
+//      points; its 63 neighbours in the wave would wait for it: 52 us per iteration in such workgroups,
+//      profiles/r04_d_icp_probe_livox.txt) is filed as {query, voxel} items in two queues in LDS and served by the
+//      32-lane groups: lane i point i, six voxels in flight -- voxels in the LDS store, and voxels the store had no room
+//      for (kTileGlobal: read from the map in HBM / L2); the owners merge the answers.
 // Queries the tile cannot serve (outside the key span, table full) and queries of runs longer than one chunk go
 // through a small queue served by the 32-lane groups with the map-direct search of the first form (closest_neighbor_any).
 // The partition of the cloud (runs), the order in which products are added (phase C) and the exchange are those of
@@ -113,6 +113,8 @@ constexpr int kWideItems = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + s
 // map (a trip is an HBM / L2 round trip) -- mixed, every trip of every group waited for a map voxel
 // (17 us per round of 486 items, profiles/r04_f_icp_probe_livox.txt).
 constexpr int kWideItemsLds = 320, kWideItemsMap = kWideItems - kWideItemsLds;
+// what a thread walks itself before it leaves the rest of its voxels to the queue (the first voxel is always walked)
+constexpr int kWideWalkVoxels = 4, kWideWalkPoints = 24;
 
 struct WideBest {  // a search in progress (between the LDS part and the map part)
     double best, bx, by, bz;
@@ -240,28 +242,12 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     if (bad) return;
     q.E = E;
     const unsigned tp2 = PROF ? ticks32() : 0u;
-    // ---- 2: the first occupied voxel in shift order (the query's own, else a face neighbour ...), walked by this thread ----
+    // ---- 2: this thread walks voxels itself, in shift order (its own voxel, the faces, ...), as long as that is cheap: the
+    // first one always, then up to kWideWalkVoxels / kWideWalkPoints in all -- after every walk the bounds of all 27
+    // cells (sums of three of the nine squared gaps, picked at compile time) are held against what is now in hand.
+    // What survives beyond the budget (dense surroundings) is left in b.m_lds for the queue.
     const WideGaps gaps = wide_gaps(q.s, q.v, m.voxel_size);
-    const unsigned first = m_lds ? (m_lds & (0u - m_lds)) : 0u;  // (lowest set bit)
-    if (first) {
-        const int j = __ffs(first) - 1;
-        const unsigned v = wide_entry(tile, vx, vy, vz, j);
-        const int ref = tile_ref(v), cnt = tile_cnt(v);
-        const double *P = tile.points + 3 * ref;
-        for (int k0 = 0; k0 < cnt; k0 += 2) {
-            const int k1 = k0 + 1 < cnt ? k0 + 1 : k0;
-            const double x0 = P[3 * k0], y0 = P[3 * k0 + 1], z0 = P[3 * k0 + 2];
-            const double x1 = P[3 * k1], y1 = P[3 * k1 + 1], z1 = P[3 * k1 + 2];
-            wide_take(b, sx, sy, sz, x0, y0, z0, (j << 5) | k0, true);
-            wide_take(b, sx, sy, sz, x1, y1, z1, (j << 5) | k1, k1 != k0);
-        }
-        b.limit = b.best < b.limit ? b.best : b.limit;
-        m_lds &= ~first;
-        if (PROF) ++ctr.visited_lds;
-    }
-    // ---- 3 (prepared): what can still matter after that -- the bounds of all 27 cells, unrolled (sums of three of the
-    // nine squared gaps picked at compile time) -------------------------------------------------------------------------
-    if (prune) {
+    auto keep_mask = [&]() {
         unsigned keep = 0u;
 #pragma unroll
         for (int j = 0; j < 27; ++j) {
@@ -271,9 +257,30 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
             if (!((bx + by) + bz > b.limit)) keep |= 1u << j;
         }
-        m_lds &= keep;
-        m_map &= keep;
+        return keep;
+    };
+    if (prune) m_lds &= keep_mask();
+    int walked_points = 0;
+    for (int visits = 0; m_lds != 0u && visits < kWideWalkVoxels; ++visits) {
+        const int j = __ffs(m_lds) - 1;
+        const unsigned v = wide_entry(tile, vx, vy, vz, j);
+        const int ref = tile_ref(v), cnt = tile_cnt(v);
+        if (visits > 0 && walked_points + cnt > kWideWalkPoints) break;
+        m_lds &= m_lds - 1u;
+        const double *P = tile.points + 3 * ref;
+        for (int k0 = 0; k0 < cnt; k0 += 2) {
+            const int k1 = k0 + 1 < cnt ? k0 + 1 : k0;
+            const double x0 = P[3 * k0], y0 = P[3 * k0 + 1], z0 = P[3 * k0 + 2];
+            const double x1 = P[3 * k1], y1 = P[3 * k1 + 1], z1 = P[3 * k1 + 2];
+            wide_take(b, sx, sy, sz, x0, y0, z0, (j << 5) | k0, true);
+            wide_take(b, sx, sy, sz, x1, y1, z1, (j << 5) | k1, k1 != k0);
+        }
+        walked_points += cnt;
+        b.limit = b.best < b.limit ? b.best : b.limit;
+        if (prune) m_lds &= keep_mask();
+        if (PROF) ++ctr.visited_lds;
     }
+    if (prune) m_map &= keep_mask();
     b.m_lds = m_lds;
     b.m_map = m_map;
     if (PROF) {
