@@ -549,9 +549,24 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     if (sh.run[0] < 0) {  // the workgroups are not all resident: give up like a failed exchange
         return false;
     }
-    if (tid == 0)
+    if (tid == 0) {
         for (int g = 0; g < G; ++g) x_pref[g + 1] += x_pref[g];  // (G <= 256 additions)
+        // Long runs: no run longer than kRunCap points (the thread-per-query form carries one chunk of 512 queries through
+        // the iterations in registers; a run is at most total weight / (G x smallest weight) points long).  Every weight
+        // is raised by the same delta -- E'[q] = E[q] + delta q -- just enough for that bound; integer arithmetic on
+        // data again.  (x_pref[G + 1]: the delta, for the scan of the boundary slices below.)
+        long long delta = 0;
+        constexpr long long kRunCap = 500;
+        if (long_runs && kRunCap * G > (long long)n) {
+            const long long W = x_pref[G], need = W - kRunCap * G * (long long)w_base, room = kRunCap * G - (long long)n;
+            if (need > 0) delta = (need + room - 1) / room;
+        }
+        if (delta > 0)
+            for (int g = 0; g <= G; ++g) x_pref[g] += delta * (long long)min(n, g * L);
+        x_pref[G + 1] = delta;
+    }
     __syncthreads();
+    const long long w_delta = x_pref[G + 1];
     if (tid < 128) {  // wave 0: where this run starts; wave 1: where the next one does
         const int which = tid >> 6, l = tid & 63;
         const long long W = x_pref[G];
@@ -586,7 +601,7 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
                             __builtin_amdgcn_s_sleep(1);
                             gq = granule_load(P.wts + q);
                         }
-                        w = (long long)(unsigned)gq;
+                        w = (long long)(unsigned)gq + w_delta;
                     }
                     wfail = __ballot(wfail) != 0ull;
                     long long incl = w;  // inclusive scan of the 64 weights
@@ -716,10 +731,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     Tile tile;
     {
         char *q = smem + head_bytes + (WIDE ? (((size_t)n_meta * sizeof(WideMeta) + 15) & ~(size_t)15) : (size_t)n_meta * sizeof(IcpQueryMeta));
-        const int slots = (!WIDE && n_local <= kIcpListRunMax) ? kIcpTileSlots / 2 : kIcpTileSlots;
+        // (WIDE with a few hundred queries: their windows hold 3 .. 5 k occupied voxels at the 1M-point configuration's steady
+        // state -- a 4096-slot table was full there, misses walked 32 slots (58 us per search in the slowest waves) and
+        // whole workgroups fell back to the map: profiles/r04_l_icp_probe_livox.txt -- so 8192 slots, at most 5/8 full)
+        const int slots = WIDE ? (n_local > 192 ? 2 * kIcpTileSlots : kIcpTileSlots) : (n_local <= kIcpListRunMax ? kIcpTileSlots / 2 : kIcpTileSlots);
         tile.slots_mask = slots - 1;
-        tile.hash_shift = slots == kIcpTileSlots ? 20 : 21;
-        tile.load_limit = (slots * 3) / 4;
+        tile.hash_shift = slots == 2 * kIcpTileSlots ? 19 : (slots == kIcpTileSlots ? 20 : 21);
+        tile.load_limit = WIDE ? (slots * 5) / 8 : (slots * 3) / 4;
         tile.keys = reinterpret_cast<unsigned *>(q);
         tile.vals = tile.keys + slots;
         q += (size_t)2 * slots * sizeof(unsigned);
@@ -1009,6 +1027,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 if (active && wq.flag == 2) sh.cell_count = 1;
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
                 int prof_items = 0, prof_map_items = 0, prof_rounds = 0, prof_direct = 0;
+                unsigned prof_file = 0, prof_serve = 0, prof_merge = 0, prof_c = 0;
                 auto file_items = [&](unsigned &pend, int *counter, int cap, WideItem *dst, int &base, int &n_filed) {
                     const int n_want = __popc(pend);
                     base = 0;
@@ -1024,8 +1043,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         it.s[1] = wq.s[1];
                         it.s[2] = wq.s[2];
                         it.d2 = DBL_MAX;
-                        it.blk_cnt = wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & ~(kTileReady | kTileGlobal);
-                        it.owner = (unsigned short)tid;
+                        unsigned slot = 0u;
+                        it.blk_cnt = wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj, &slot) & ~(kTileReady | kTileGlobal);
+                        it.slot = (unsigned short)slot;
                         it.j = (unsigned char)jj;
                         it.k = 0;
                     }
@@ -1037,11 +1057,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         wide_take(wb, wq.s[0], wq.s[1], wq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
                     }
                 };
-                for (;;) {
+                for (int round = 0;; ++round) {
+                    const unsigned tr0 = PROF ? ticks32() : 0u;
+                    if (round > 0 && pend_map) {  // a voxel may have been promoted into the store since this query classified it
+                        unsigned todo = pend_map;
+                        while (todo) {
+                            const int jj = __ffs(todo) - 1;
+                            todo &= todo - 1u;
+                            if (!(wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & kTileGlobal)) {
+                                pend_map &= ~(1u << jj);
+                                pend_lds |= 1u << jj;
+                            }
+                        }
+                    }
                     int base_l, nf_l, base_m, nf_m;
                     file_items(pend_lds, &sh.job_count, kWideItemsLds, items, base_l, nf_l);
                     file_items(pend_map, &sh.bulk_failed, kWideItemsMap, items + kWideItemsLds, base_m, nf_m);
                     __syncthreads();
+                    const unsigned tr1 = PROF ? ticks32() : 0u;
+                    if (PROF) prof_file += tr1 - tr0;
                     const int n_l = min(sh.job_count, kWideItemsLds), n_m = min(sh.bulk_failed, kWideItemsMap);  // (the whole workgroup)
                     if (n_l + n_m == 0) break;
                     if (PROF) {
@@ -1052,31 +1086,21 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane);
                     if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane);
                     __syncthreads();
+                    const unsigned tr2 = PROF ? ticks32() : 0u;
                     merge_items(items, base_l, nf_l);
                     merge_items(items + kWideItemsLds, base_m, nf_m);
                     if (tid == 0) sh.job_count = sh.bulk_failed = 0;
                     __syncthreads();  // (the queues' memory is the next round's, the slow paths' and phase C's)
+                    if (PROF) {
+                        prof_serve += tr2 - tr1;
+                        prof_merge += ticks32() - tr2;
+                    }
                 }
                 if (searching) wide_finish(wq, wb);
                 if (sh.cell_count) prof_direct = serve(2, &sh.list_entries);
                 if (PROF) t_group += ticks32() - tb0;
-                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0) {
-                    // this thread's record of the iteration (10 ns ticks); same layout as the first form's group records
-                    unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) + (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
-                    r[0] = (unsigned)(tb00 - ta) | (min(ctr.visited_lds, 255u) << 16) | (min(ctr.visited_map, 255u) << 24);  // phase A; voxels visited (LDS, map)
-                    if (it == 0 && P.bulk_fill && grp < 5) r[0] = (r[0] & 0xFFFFu) | (min(sh.bulk_ticks[grp], 0xFFFFu) << 16);  // groups 0..4: the window phase's parts instead
-                    r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)min(t_scan, 0xFFFFu) << 16);
-                    r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)min(wq.E, 0xFFFF) << 16);
-                    if (grp & 1) {  // the odd groups (same wave as the even one in front): where the search's time went instead
-                        r[0] = (r[0] & 0xFFFFu) | (min(ctr.t_walk, 0xFFFFu) << 16);
-                        r[2] = min(ctr.t_lookup, 0xFFFFu) | (min(ctr.t_chains, 0xFFFFu) << 16);
-                    }
-                    if (grp == 2) r[2] = (unsigned)min(prof_direct, 0xFFFF) | ((unsigned)min(prof_rounds, 0xFFFF) << 16);  // workgroup: map-direct queries, queue rounds
-                    if (grp == 4) r[2] = (unsigned)min(prof_items, 0xFFFF) | ((unsigned)min(prof_map_items, 0xFFFF) << 16);  // workgroup: items served, of them in the map
-                    r[3] = 4u;
-                    prof_path = 4u;
-                }
                 // ---- C: products of kWideTermRows points at a time, added in the first form's order ----------------
+                const unsigned tc0 = PROF ? ticks32() : 0u;
                 for (int sub = 0; sub < cn; sub += kWideTermRows) {
                     const int sn = min(kWideTermRows, cn - sub);
                     if (tid >= sub && tid < sub + sn) {
@@ -1113,6 +1137,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (cg < kIcpGroupsPerBlock)
                         for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += rows[i][ck];
                     __syncthreads();
+                }
+                if (PROF) prof_c = ticks32() - tc0;
+                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0) {
+                    // this thread's record of the iteration (10 ns ticks); same layout as the first form's group records
+                    unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) + (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+                    r[0] = (unsigned)(tb00 - ta) | (min(ctr.visited_lds, 255u) << 16) | (min(ctr.visited_map, 255u) << 24);  // phase A; voxels visited (LDS, map)
+                    if (it == 0 && P.bulk_fill && grp < 5) r[0] = (r[0] & 0xFFFFu) | (min(sh.bulk_ticks[grp], 0xFFFFu) << 16);  // groups 0..4: the window phase's parts instead
+                    r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)min(t_scan, 0xFFFFu) << 16);
+                    r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)min(wq.E, 0xFFFF) << 16);
+                    if (grp & 1) {  // the odd groups (same wave as the even one in front): where the search's time went instead
+                        r[0] = (r[0] & 0xFFFFu) | (min(ctr.t_walk, 0xFFFFu) << 16);
+                        r[2] = min(ctr.t_lookup, 0xFFFFu) | (min(ctr.t_chains, 0xFFFFu) << 16);
+                    }
+                    if (grp == 2) r[2] = (unsigned)min(prof_direct, 0xFFFF) | ((unsigned)min(prof_rounds, 0xFFFF) << 16);  // workgroup: map-direct queries, queue rounds
+                    if (grp == 6) r[2] = min(prof_file, 0xFFFFu) | (min(prof_serve, 0xFFFFu) << 16);  // workgroup: filing (+ wait), serving
+                    if (grp == 8) r[2] = min(prof_merge, 0xFFFFu) | (min(prof_c, 0xFFFFu) << 16);     // workgroup: merging, phase C
+                    if (grp == 4) r[2] = (unsigned)min(prof_items, 0xFFFF) | ((unsigned)min(prof_map_items, 0xFFFF) << 16);  // workgroup: items served, of them in the map
+                    r[3] = 4u;
+                    prof_path = 4u;
                 }
             }
         } else

@@ -104,15 +104,15 @@ struct WideItem {
     double s[3];       // in: the query; out: the voxel's point closest to it
     double d2;         // out: its squared distance
     unsigned blk_cnt;  // block id (LDS queue: position in the LDS store) | point count << 24
-    unsigned short owner;
-    unsigned char j, k;  // shift position of the voxel; out: index of the point in it
+    unsigned short slot;  // the voxel's slot in the tile's table
+    unsigned char j, k;   // shift position of the voxel; out: index of the point in it
 };
 static_assert(sizeof(WideItem) == 40, "WideItem layout");
 constexpr int kWideItems = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk) / sizeof(WideItem));
 // Two queues in that memory: voxels in the LDS store (a trip of the serving loop is an LDS round trip) and voxels in the
 // map (a trip is an HBM / L2 round trip) -- mixed, every trip of every group waited for a map voxel
 // (17 us per round of 486 items, profiles/r04_f_icp_probe_livox.txt).
-constexpr int kWideItemsLds = 320, kWideItemsMap = kWideItems - kWideItemsLds;
+constexpr int kWideItemsLds = 160, kWideItemsMap = kWideItems - kWideItemsLds;
 // what a thread walks itself before it leaves the rest of its voxels to the queue (the first voxel is always walked)
 constexpr int kWideWalkVoxels = 4, kWideWalkPoints = 24;
 
@@ -136,14 +136,17 @@ __device__ __forceinline__ void wide_take(WideBest &b, double sx, double sy, dou
 
 // the table entry of cell j of the 27 (any chain length); 0: not in the table.  (Plain loads here and in the search:
 // in this form nobody writes the table while it is searched -- fills and searches are separated by barriers.)
-__device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy, int vz, int j) {
+__device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy, int vz, int j, unsigned *slot_out = nullptr) {
     const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
     unsigned rkey;
     if (!tile_rel(tile, qx, qy, qz, rkey)) return 0u;
     unsigned s = tile_hash(tile, rkey);
     for (int probes = 0; probes < kTileMaxProbes; ++probes) {
         const unsigned k = tile.keys[s];
-        if (k == rkey) return tile.vals[s];
+        if (k == rkey) {
+            if (slot_out) *slot_out = s;
+            return tile.vals[s];
+        }
         if (k == kTileEmpty) return 0u;
         s = (s + 1u) & (unsigned)tile.slots_mask;
     }
@@ -350,6 +353,33 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
         }
 #pragma unroll
         for (int u = 0; u < kChunk; ++u) {
+            if (!LDS && valid[u]) {
+                // PROMOTION: a voxel that is read from the map is one some query really looks at -- and will look at again in
+                // the next iteration (the search is bounded by the last neighbour).  While the store has room the group leaves
+                // the points it has just read there and the table entry says so from now on: the store turns into a cache of
+                // the voxels that ARE visited, whatever the window phase guessed.  (Nobody searches during this phase; two
+                // groups promoting the same voxel in the same round leave two copies, one of them unused.)
+                WideItem &it = items[e0 + kIcpGroupsPerBlock * u];
+                const int cnt = (int)((it.blk_cnt >> 24) & 63u);
+                int off = -1;
+                if (lane == 0 && (tile.vals[it.slot] & kTileGlobal)) {
+                    const int o = atomicAdd(tile.count, cnt);
+                    if ((unsigned)(o + cnt) * 24u <= tile.region_bytes && o + cnt <= 0xFFFF) {
+                        atomicMax(tile.stored, o + cnt);
+                        off = o;
+                    }
+                }
+                off = __shfl(off, 0, 32);
+                if (off >= 0) {
+                    if (ld[u]) {
+                        double *q = tile.points + 3 * (off + lane);
+                        q[0] = xy[u].x;
+                        q[1] = xy[u].y;
+                        q[2] = zz[u];
+                    }
+                    if (lane == 0) tile.vals[it.slot] = (unsigned)off | ((unsigned)cnt << 24) | kTileReady;
+                }
+            }
             double d = DBL_MAX;
             if (ld[u]) {
                 const double ex = xy[u].x - qs[u][0], ey = xy[u].y - qs[u][1], ez = zz[u] - qs[u][2];
@@ -419,6 +449,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
     int range_err = 0;
     const int s0 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the store's end before this phase
     const unsigned free_top = tile.region_bytes & ~15u;  // (this form keeps no scan lists: the region is points only)
+    const unsigned prefill_top = max((unsigned)s0 * 24u, (free_top / 8u) * 5u);
     // the set of distinct cells (u32 relative keys), a bit per slot ("near"), and the list of the set's members (u16 slot
     // numbers: near cells from the bottom, the others from the top): the largest power of two of slots, 64 per query at
     // most, that leaves the list 3/4 of the slots (at least 1024 entries) above the points
@@ -625,8 +656,9 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
                 }
             }
             bool failed = occ && !won;  // table full
-            // (offsets only: the points arrive in phase 3, when the set is dead)
-            const bool fits = won && (unsigned)(off + cnt) * 24u <= free_top && off + cnt <= 0xFFFF;
+            // (offsets only: the points arrive in phase 3, when the set is dead.  The window phase fills 5/8 of the store at
+            // most: the rest is for the voxels the searches turn out to visit -- wide_serve_items)
+            const bool fits = won && (unsigned)(off + cnt) * 24u <= prefill_top && off + cnt <= 0xFFFF;
             const bool want = fits && (unsigned)blk < 0x1000000u;
             const unsigned long long jm = __ballot(want);
             int jbase = 0;
@@ -758,7 +790,11 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
         meta->list_state = 0;
     }
     if (range_err) *range_err_out = 1;
-    if (tid == 0) sh.job_count = sh.bulk_failed = 0;  // (the caller's queue counters again)
+    if (tid == 0) {
+        sh.job_count = sh.bulk_failed = 0;  // (the caller's queue counters again)
+        // the store's allocator goes on where the points end (it has counted every voxel that asked, also those without room)
+        *tile.count = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     __syncthreads();
     stamp(3);
     return 1;

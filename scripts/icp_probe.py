@@ -38,7 +38,8 @@ if gp.size:
         for j, nm in enumerate(names):
             print('   %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (
                 nm, g[:, j].mean() / 100, np.percentile(g[:, j], 50) / 100, np.percentile(g[:, j], 99) / 100, g[:, j].max() / 100))
-        print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (g[:, 4].mean(), g[:, 4].max(), g[:, 5].mean(), g[:, 5].max()))
+        gc = g.reshape(-1, 16, g.shape[1])[:, [0, 10, 12, 14], :].reshape(-1, g.shape[1]) if (g[:, 6] == 4).all() else g  # (thread-per-query form: the other groups' records carry counters)
+        print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (gc[:, 4].mean(), gc[:, 4].max(), gc[:, 5].mean(), gc[:, 5].max()))
         if (g[:, 6] == 4).all():
             # thread-per-query form: the 'xform' field of a record carries the voxels its thread visited {LDS | map << 8}
             # (the 'wait-in' field is phase A); in iteration 0 the records of groups 0..4 carry the window phase's parts instead
@@ -53,8 +54,13 @@ if gp.size:
             wgd, wgr, wgi, wgm, wgt = gw[:, 2, 4], gw[:, 2, 5], gw[:, 4, 4], gw[:, 4, 5], gw[:, :, 8].max(axis=1) / 100.0
             print('   per workgroup: map-direct queries mean %.1f max %d; items served mean %.1f max %d (in the map mean %.1f max %d) in rounds mean %.2f max %d' % (
                 wgd.mean(), wgd.max(), wgi.mean(), wgi.max(), wgm.mean(), wgm.max(), wgr.mean(), wgr.max()))
-            for w in np.argsort(-wgt)[:10]:
-                print('      wg %3d: %6.2f us  run %3d  direct %3d  items %4d (map %4d)  rounds %d' % (w, wgt[w], gw[w, 0, 7], wgd[w], wgi[w], wgm[w], wgr[w]))
+            tf, ts, tm, tc = gw[:, 6, 4] / 100.0, gw[:, 6, 5] / 100.0, gw[:, 8, 4] / 100.0, gw[:, 8, 5] / 100.0
+            print('   per workgroup (us): filing + wait mean %.2f max %.2f; serving mean %.2f max %.2f; merging mean %.2f max %.2f; phase C mean %.2f max %.2f' % (
+                tf.mean(), tf.max(), ts.mean(), ts.max(), tm.mean(), tm.max(), tc.mean(), tc.max()))
+            order = np.argsort(-wgt)
+            for w in list(order[:8]) + list(order[len(order) // 2: len(order) // 2 + 4]):
+                print('      wg %3d: %6.2f us  run %3d  direct %3d  items %4d (map %4d)  rounds %d   file %5.2f serve %5.2f merge %5.2f C %5.2f' % (
+                    w, wgt[w], gw[w, 0, 7], wgd[w], wgi[w], wgm[w], wgr[w], tf[w], ts[w], tm[w], tc[w]))
             slow = np.argsort(-od[:, 3])[:6]
             for w in slow:
                 print('   slow wave: scan %6.2f = lookups %6.2f + chains %6.2f + walk %6.2f us (+ queueing)' % (od[w, 3] / 100, od[w, 4] / 100, od[w, 5] / 100, od[w, 1] / 100))
@@ -79,8 +85,9 @@ if gp.size:
     g = gp[it].reshape(-1, 16, 9)
     wg_t = g[:, :, 8].max(axis=1) / 100.0
     wg_n = g[:, 0, 7]
-    wg_staged = g[:, :, 4].max(axis=1)
-    wg_ex = g[:, :, 5].mean(axis=1)
+    clean = [0, 10, 12, 14] if (gp[it][:, 6] == 4).all() else list(range(16))
+    wg_staged = g[:, clean, 4].max(axis=1)
+    wg_ex = g[:, clean, 5].mean(axis=1)
     used = wg_n > 0
     print('per workgroup, iteration %d: %d workgroups with points; search time of the slowest group: mean %.2f  p50 %.2f  p90 %.2f  max %.2f us' % (
         it, used.sum(), wg_t[used].mean(), np.percentile(wg_t[used], 50), np.percentile(wg_t[used], 90), wg_t[used].max()))
