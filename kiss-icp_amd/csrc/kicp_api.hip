@@ -198,6 +198,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     const long per_wg = (long)(n_hint / (size_t)(P.force_blocks > 0 ? P.force_blocks : grid));
     P.use_wide = options().icp_wide >= 0 ? (options().icp_wide != 0) : (per_wg > kIcpListRunMax);
     P.wide_prune = (int)options().icp_wide_prune;
+    P.wide_prefill = (int)options().icp_wide_prefill;
     return grid;
 }
 
@@ -2362,6 +2363,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide")) {
         if (value < -1 || value > 1) return KICP_ERR_INVALID_ARG;
         options().icp_wide = value;
+    } else if (!strcmp(name, "icp_wide_prefill")) {
+        if (value < 0 || value > 8) return KICP_ERR_INVALID_ARG;
+        options().icp_wide_prefill = value;
     } else if (!strcmp(name, "icp_wide_prune")) {
         if (value < 0 || value > 2) return KICP_ERR_INVALID_ARG;
         options().icp_wide_prune = value;

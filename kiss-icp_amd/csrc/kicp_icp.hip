@@ -972,7 +972,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (it == 0 && base == 0 && P.bulk_fill) {
                         int rerr = 0;
                         const bool mine = active && wq.flag == 1;
-                        int r = wide_fill_bulk(m, tile, &sh, 0, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF);
+                        int r = wide_fill_bulk(m, tile, &sh, 0, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF, P.wide_prefill);
                         bulk_done = r == 1;
                         if (bulk_done && mine) wq.flag = meta->valid > 0 ? 0 : 2;
                         if (r == 2) {
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                             for (int lo = 0; lo < cn; lo += 128) {
                                 const int hi = min(cn, lo + 128);
                                 const bool part = mine && tid >= lo && tid < hi;
-                                r = wide_fill_bulk(m, tile, &sh, lo, hi, wmetas, part, wq.s, wq.v, &rerr, false);
+                                r = wide_fill_bulk(m, tile, &sh, lo, hi, wmetas, part, wq.s, wq.v, &rerr, false, P.wide_prefill);
                                 if (r == 1) {
                                     if (part) wq.flag = meta->valid > 0 ? 0 : 2;
                                 } else {
@@ -1028,8 +1028,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
                 int prof_items = 0, prof_map_items = 0, prof_rounds = 0, prof_direct = 0;
                 unsigned prof_file = 0, prof_serve = 0, prof_merge = 0, prof_c = 0;
+                constexpr int kPerRound = 2;  // items a thread files per round and queue: the nearest first, the rest is held against what they bring back
                 auto file_items = [&](unsigned &pend, int *counter, int cap, WideItem *dst, int &base, int &n_filed) {
-                    const int n_want = __popc(pend);
+                    const int n_want = min(__popc(pend), kPerRound);
                     base = 0;
                     n_filed = 0;
                     if (n_want == 0) return;
@@ -1083,12 +1084,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         prof_map_items += n_m;
                         ++prof_rounds;
                     }
-                    if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane);
-                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane);
+                    if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane, it > 0 || P.wide_prefill > 0);
+                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false);
                     __syncthreads();
                     const unsigned tr2 = PROF ? ticks32() : 0u;
                     merge_items(items, base_l, nf_l);
                     merge_items(items + kWideItemsLds, base_m, nf_m);
+                    if ((pend_lds | pend_map) != 0u && P.wide_prune > 0) {  // what is left, against what the answers have brought
+                        wb.limit = wb.best < wb.limit ? wb.best : wb.limit;
+                        const unsigned keep = wide_keep_mask(wide_gaps(wq.s, wq.v, m.voxel_size), wb.limit);
+                        pend_lds &= keep;
+                        pend_map &= keep;
+                    }
                     if (tid == 0) sh.job_count = sh.bulk_failed = 0;
                     __syncthreads();  // (the queues' memory is the next round's, the slow paths' and phase C's)
                     if (PROF) {

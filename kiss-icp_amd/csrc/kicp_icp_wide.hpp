@@ -94,6 +94,20 @@ __device__ __forceinline__ WideGaps wide_gaps(const double s[3], const int v[3],
     }
     return g;
 }
+// which of the 27 cells can still matter: bound <= limit (sums of three of the nine squared gaps, picked at compile time)
+__device__ __forceinline__ unsigned wide_keep_mask(const WideGaps &gaps, double limit) {
+    unsigned keep = 0u;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const int cx = (int)((kShift.x >> (2 * j)) & 3), cy = (int)((kShift.y >> (2 * j)) & 3), cz = (int)((kShift.z >> (2 * j)) & 3);
+        const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
+        const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
+        const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
+        if (!((bx + by) + bz > limit)) keep |= 1u << j;
+    }
+    return keep;
+}
+
 struct WideCounters {  // profiling build
     unsigned visited_lds, visited_map;
     unsigned t_lookup, t_chains, t_walk;  // 10 ns ticks: the unrolled lookups, chains longer than two slots, the voxels in LDS
@@ -250,18 +264,7 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     // cells (sums of three of the nine squared gaps, picked at compile time) are held against what is now in hand.
     // What survives beyond the budget (dense surroundings) is left in b.m_lds for the queue.
     const WideGaps gaps = wide_gaps(q.s, q.v, m.voxel_size);
-    auto keep_mask = [&]() {
-        unsigned keep = 0u;
-#pragma unroll
-        for (int j = 0; j < 27; ++j) {
-            const int cx = (int)((kShift.x >> (2 * j)) & 3), cy = (int)((kShift.y >> (2 * j)) & 3), cz = (int)((kShift.z >> (2 * j)) & 3);
-            const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
-            const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
-            const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
-            if (!((bx + by) + bz > b.limit)) keep |= 1u << j;
-        }
-        return keep;
-    };
+    auto keep_mask = [&]() { return wide_keep_mask(gaps, b.limit); };
     if (prune) m_lds &= keep_mask();
     int walked_points = 0;
     for (int visits = 0; m_lds != 0u && visits < kWideWalkVoxels; ++visits) {
@@ -323,21 +326,18 @@ __device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &til
 // the voxel -- the smaller index among equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back
 // into the item
 template <bool LDS>
-__device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane) {
-    for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kChunk) {  // wave-uniform trip count
-        double2 xy[kChunk];
-        double zz[kChunk];
-        double qs[kChunk][3];
-        bool ld[kChunk], valid[kChunk];
+__device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane, bool promote) {
+    constexpr int kFly = LDS ? kChunk : 2 * kChunk;  // voxels of a group in flight (map voxels: twelve -- a trip is an HBM / L2 round trip)
+    for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kFly) {  // wave-uniform trip count
+        double2 xy[kFly];
+        double zz[kFly];
+        bool ld[kFly], valid[kFly];
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
+        for (int u = 0; u < kFly; ++u) {
             const int e = e0 + kIcpGroupsPerBlock * u;
             valid[u] = e < n_items;
             const WideItem &it = items[valid[u] ? e : 0];
             const int blk = (int)(it.blk_cnt & 0xFFFFFFu), cnt = (int)((it.blk_cnt >> 24) & 63u);
-            qs[u][0] = it.s[0];
-            qs[u][1] = it.s[1];
-            qs[u][2] = it.s[2];
             ld[u] = valid[u] && lane < cnt;
             if (ld[u]) {
                 if (LDS) {
@@ -352,8 +352,8 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
             }
         }
 #pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
-            if (!LDS && valid[u]) {
+        for (int u = 0; u < kFly; ++u) {
+            if (!LDS && promote && valid[u]) {
                 // PROMOTION: a voxel that is read from the map is one some query really looks at -- and will look at again in
                 // the next iteration (the search is bounded by the last neighbour).  While the store has room the group leaves
                 // the points it has just read there and the table entry says so from now on: the store turns into a cache of
@@ -382,7 +382,8 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
             }
             double d = DBL_MAX;
             if (ld[u]) {
-                const double ex = xy[u].x - qs[u][0], ey = xy[u].y - qs[u][1], ez = zz[u] - qs[u][2];
+                const WideItem &it = items[e0 + kIcpGroupsPerBlock * u];
+                const double ex = xy[u].x - it.s[0], ey = xy[u].y - it.s[1], ez = zz[u] - it.s[2];
                 d = (ex * ex + ey * ey) + ez * ez;
             }
             double gd = d;
@@ -432,8 +433,9 @@ __device__ __forceinline__ void wide_finish(WideQuery &q, const WideBest &b) {
 // ------------------------------------------------------------------------------------------
 // Returns 1 done, 0 no room for the scratch, 2 more distinct cells than the member list holds (nothing was entered; the
 // caller comes again with fewer queries: 128 queries have at most 8192 cells).  Queries q_lo <= q < q_hi take part.
+// prefill_eighths: how much of the store the window phase may fill with points (0: none -- the table only; 8: all of it).
 __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile, IcpShared *shp, int q_lo, int q_hi, WideMeta *metas, bool mine, const double s[3], const int v[3],
-                                              int *range_err_out, bool prof) {
+                                              int *range_err_out, bool prof, int prefill_eighths) {
     const int cn = q_hi - q_lo;
     IcpShared &sh = *shp;
     const int tid = threadIdx.x;
@@ -449,7 +451,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
     int range_err = 0;
     const int s0 = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the store's end before this phase
     const unsigned free_top = tile.region_bytes & ~15u;  // (this form keeps no scan lists: the region is points only)
-    const unsigned prefill_top = max((unsigned)s0 * 24u, (free_top / 8u) * 5u);
+    const unsigned prefill_top = prefill_eighths > 0 ? max((unsigned)s0 * 24u, (free_top / 8u) * (unsigned)prefill_eighths) : 0u;
     // the set of distinct cells (u32 relative keys), a bit per slot ("near"), and the list of the set's members (u16 slot
     // numbers: near cells from the bottom, the others from the top): the largest power of two of slots, 64 per query at
     // most, that leaves the list 3/4 of the slots (at least 1024 entries) above the points
