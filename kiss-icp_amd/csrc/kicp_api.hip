@@ -199,6 +199,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     P.use_wide = options().icp_wide >= 0 ? (options().icp_wide != 0) : (per_wg > kIcpListRunMax);
     P.wide_prune = (int)options().icp_wide_prune;
     P.wide_prefill = (int)options().icp_wide_prefill;
+    P.wide_per_round = (int)options().icp_wide_per_round;
     return grid;
 }
 
@@ -2363,6 +2364,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide")) {
         if (value < -1 || value > 1) return KICP_ERR_INVALID_ARG;
         options().icp_wide = value;
+    } else if (!strcmp(name, "icp_wide_per_round")) {
+        if (value < 1 || value > 27) return KICP_ERR_INVALID_ARG;
+        options().icp_wide_per_round = value;
     } else if (!strcmp(name, "icp_wide_prefill")) {
         if (value < 0 || value > 8) return KICP_ERR_INVALID_ARG;
         options().icp_wide_prefill = value;

@@ -805,6 +805,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     bool failed = false;
     WideQuery wq;  // (WIDE) this thread's query: kept in registers from iteration to iteration when the run is a single chunk
     wq.have_nn = false;
+    wq.occ_valid = false;
+    wq.occ = 0u;
+    wq.occ_E = 0;
+    wq.occ_v[0] = wq.occ_v[1] = wq.occ_v[2] = 0;
     wq.flag = 2;
     wq.E = 0;
     wq.d2 = DBL_MAX;
@@ -863,6 +867,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         P.work[3 * (size_t)(q0 + j) + 1] = wq.s[1];
                         P.work[3 * (size_t)(q0 + j) + 2] = wq.s[2];
                         wq.have_nn = false;
+                        wq.occ_valid = false;
                     }
                     const int vx = voxel_coord_fast(wq.s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(wq.s[1], m.voxel_size, inv_voxel),
                               vz = voxel_coord_fast(wq.s[2], m.voxel_size, inv_voxel);
@@ -1028,7 +1033,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
                 int prof_items = 0, prof_map_items = 0, prof_rounds = 0, prof_direct = 0;
                 unsigned prof_file = 0, prof_serve = 0, prof_merge = 0, prof_c = 0;
-                constexpr int kPerRound = 2;  // items a thread files per round and queue: the nearest first, the rest is held against what they bring back
+                const int kPerRound = P.wide_per_round;  // items a thread files per round and queue: the nearest first, the rest is held against what they bring back
                 auto file_items = [&](unsigned &pend, int *counter, int cap, WideItem *dst, int &base, int &n_filed) {
                     const int n_want = min(__popc(pend), kPerRound);
                     base = 0;

@@ -68,6 +68,13 @@ struct WideQuery {  // registers of the owning thread
     int E;         // map points the reference examines for this query
     int flag;      // 0 window valid, 1 window must be (re)established, 2 map-direct search
     bool have_nn;  // nn / pv come from a tile search of this launch
+    // which of the 27 cells around occ_v are occupied, and their population: what the table lookups of a search find
+    // out.  It stays true as long as the query stays in its voxel (the map does not change during AlignPointsToMap), so
+    // a query that has not left its voxel since the last search skips the lookups -- and a wave all of whose queries
+    // stayed (most waves, a few iterations in) skips that part of the code altogether.
+    unsigned occ;
+    int occ_v[3], occ_E;
+    bool occ_valid;
 };
 
 // ---- lower bounds of the distances to the neighbouring voxel layers --------------------------------------------------
@@ -187,6 +194,14 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     q.E = 0;
     q.d2 = DBL_MAX;
     q.have_nn = false;
+    const bool cached = q.occ_valid && q.occ_v[0] == vx && q.occ_v[1] == vy && q.occ_v[2] == vz;
+    unsigned m_lds = 0u, m_map = 0u, open = 0u;
+    int E = 0;
+    unsigned tp1 = tp0;
+    if (cached) {
+        m_lds = q.occ;  // (which of them are in the LDS store is found out when they are visited: voxels move there as they are used)
+        E = q.occ_E;
+    } else {
     {
         bool span_ok = true;
 #pragma unroll
@@ -199,8 +214,6 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             return;
         }
     }
-    unsigned m_lds = 0u, m_map = 0u, open = 0u;
-    int E = 0;
     auto classify = [&](unsigned v, int j) {
         if (v == 0u) return;
         if (v == kTileOverflow || !(v & kTileReady)) {
@@ -237,7 +250,7 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
 #pragma unroll
         for (int u = 0; u < 9; ++u) classify(val[u], jb + u);
     }
-    const unsigned tp1 = PROF ? ticks32() : 0u;
+    tp1 = PROF ? ticks32() : 0u;
     while (open) {  // chains longer than two slots
         const int j = __ffs(open) - 1;
         open &= open - 1u;
@@ -256,7 +269,15 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             s = (s + 1u) & (unsigned)tile.slots_mask;
         }
     }
+    q.occ_valid = false;
     if (bad) return;
+    q.occ = m_lds | m_map;
+    q.occ_v[0] = vx;
+    q.occ_v[1] = vy;
+    q.occ_v[2] = vz;
+    q.occ_E = E;
+    q.occ_valid = true;
+    }
     q.E = E;
     const unsigned tp2 = PROF ? ticks32() : 0u;
     // ---- 2: this thread walks voxels itself, in shift order (its own voxel, the faces, ...), as long as that is cheap: the
@@ -267,11 +288,17 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     auto keep_mask = [&]() { return wide_keep_mask(gaps, b.limit); };
     if (prune) m_lds &= keep_mask();
     int walked_points = 0;
-    for (int visits = 0; m_lds != 0u && visits < kWideWalkVoxels; ++visits) {
+    for (int visits = 0; m_lds != 0u && visits < kWideWalkVoxels;) {
         const int j = __ffs(m_lds) - 1;
         const unsigned v = wide_entry(tile, vx, vy, vz, j);
+        if (v & kTileGlobal) {  // (cached occupancy: this one is in the map)
+            m_lds &= m_lds - 1u;
+            m_map |= 1u << j;
+            continue;
+        }
         const int ref = tile_ref(v), cnt = tile_cnt(v);
         if (visits > 0 && walked_points + cnt > kWideWalkPoints) break;
+        ++visits;
         m_lds &= m_lds - 1u;
         const double *P = tile.points + 3 * ref;
         for (int k0 = 0; k0 < cnt; k0 += 2) {
@@ -285,6 +312,17 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
         b.limit = b.best < b.limit ? b.best : b.limit;
         if (prune) m_lds &= keep_mask();
         if (PROF) ++ctr.visited_lds;
+    }
+    if (cached) {  // what is left for the queues: which queue
+        unsigned todo = m_lds;
+        while (todo) {
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            if (wide_entry(tile, vx, vy, vz, j) & kTileGlobal) {
+                m_lds &= ~(1u << j);
+                m_map |= 1u << j;
+            }
+        }
     }
     if (prune) m_map &= keep_mask();
     b.m_lds = m_lds;
@@ -327,7 +365,7 @@ __device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &til
 // into the item
 template <bool LDS>
 __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane, bool promote) {
-    constexpr int kFly = LDS ? kChunk : 2 * kChunk;  // voxels of a group in flight (map voxels: twelve -- a trip is an HBM / L2 round trip)
+    constexpr int kFly = LDS ? kChunk : 8;  // voxels of a group in flight (map voxels: twelve -- a trip is an HBM / L2 round trip)
     for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kFly) {  // wave-uniform trip count
         double2 xy[kFly];
         double zz[kFly];
