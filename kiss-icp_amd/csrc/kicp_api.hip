@@ -200,6 +200,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     P.wide_prune = (int)options().icp_wide_prune;
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
+    P.wide_stable = (int)options().icp_wide_stable;
     return grid;
 }
 
@@ -2364,6 +2365,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide")) {
         if (value < -1 || value > 1) return KICP_ERR_INVALID_ARG;
         options().icp_wide = value;
+    } else if (!strcmp(name, "icp_wide_stable")) {
+        options().icp_wide_stable = value != 0;
     } else if (!strcmp(name, "icp_wide_per_round")) {
         if (value < 1 || value > 27) return KICP_ERR_INVALID_ARG;
         options().icp_wide_per_round = value;

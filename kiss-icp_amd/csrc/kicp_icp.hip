@@ -806,6 +806,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     WideQuery wq;  // (WIDE) this thread's query: kept in registers from iteration to iteration when the run is a single chunk
     wq.have_nn = false;
     wq.occ_valid = false;
+    wq.lr_valid = false;
+    wq.Lr = 0.0;
     wq.occ = 0u;
     wq.occ_E = 0;
     wq.occ_v[0] = wq.occ_v[1] = wq.occ_v[2] = 0;
@@ -844,6 +846,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const bool has_meta = active && j < n_meta;  // (n_meta <= kWideChunk: queries of the first chunk)
                 WideMeta *meta = wmetas + (has_meta ? j : 0);
                 const unsigned ta = PROF ? ticks32() : 0u;
+                double moved = 0.0;
                 // ---- A: s = est * s, its voxel, is the known window still good ------------------------------------
                 if (active) {
                     double pin[3];
@@ -862,12 +865,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         pin[2] = P.work[3 * (size_t)(q0 + j) + 2];
                     }
                     se3_act(est, pin, wq.s);
+                    if (single && it > 0) {  // how far the query has moved since the last iteration (for the stability test), rounded up
+                        const double mx = wq.s[0] - pin[0], my = wq.s[1] - pin[1], mz = wq.s[2] - pin[2];
+                        moved = sqrt((mx * mx + my * my) + mz * mz) * (1.0 + 0x1p-30) + DBL_MIN;
+                    }
                     if (!single) {
                         P.work[3 * (size_t)(q0 + j)] = wq.s[0];
                         P.work[3 * (size_t)(q0 + j) + 1] = wq.s[1];
                         P.work[3 * (size_t)(q0 + j) + 2] = wq.s[2];
                         wq.have_nn = false;
                         wq.occ_valid = false;
+                        wq.lr_valid = false;
                     }
                     const int vx = voxel_coord_fast(wq.s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(wq.s[1], m.voxel_size, inv_voxel),
                               vz = voxel_coord_fast(wq.s[2], m.voxel_size, inv_voxel);
@@ -962,6 +970,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                 wq.d2 = r.d2;
                                 wq.E = r.E;
                                 wq.have_nn = false;
+                                wq.lr_valid = false;
                             }
                             pending = false;
                         }
@@ -1006,30 +1015,92 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 WideCounters ctr;
                 ctr.visited_lds = ctr.visited_map = 0u;
                 ctr.t_lookup = ctr.t_chains = ctr.t_walk = 0u;
-                WideBest wb;
-                wb.m_map = 0u;
-                bool searching = active && wq.flag == 0;
-                if (searching) {
-                    // what can still matter: the correspondence threshold and -- its voxel still among the 27 -- last iteration's neighbour
-                    double limit0 = limit_corr;
-                    if (P.wide_prune > 1 && wq.have_nn && abs(wq.pv[0] - wq.v[0]) <= 1 && abs(wq.pv[1] - wq.v[1]) <= 1 && abs(wq.pv[2] - wq.v[2]) <= 1) {
+                // (1) who needs a full search.  A query that has stayed in its voxel, whose last neighbour is still closer than
+                // anything else can have come (WideQuery::Lr), needs nothing: its answer is nn again, from registers.
+                bool need_full = active && wq.flag == 0;
+                double limit0 = limit_corr;
+                if (need_full) {
+                    const bool same_voxel = wq.occ_valid && wq.occ_v[0] == wq.v[0] && wq.occ_v[1] == wq.v[1] && wq.occ_v[2] == wq.v[2];
+                    double dp = DBL_MAX;
+                    if (wq.have_nn) {
                         const double ex = wq.nn[0] - wq.s[0], ey = wq.nn[1] - wq.s[1], ez = wq.nn[2] - wq.s[2];
-                        const double dp = (ex * ex + ey * ey) + ez * ez;
+                        dp = (ex * ex + ey * ey) + ez * ez;  // (as the search computes it)
+                    }
+                    if (P.wide_stable && single && it > 0 && wq.lr_valid && same_voxel) {
+                        wq.Lr -= moved;
+                        bool ok;
+                        if (wq.have_nn)
+                            ok = sqrt(dp) * (1.0 + 0x1p-30) < wq.Lr;
+                        else  // (no neighbour last time: nothing within the correspondence threshold -- or nothing at all)
+                            ok = wq.occ == 0u || sqrt(limit_corr) * (1.0 + 0x1p-30) < wq.Lr;
+                        if (ok) {
+                            wq.d2 = dp;
+                            wq.E = wq.occ_E;
+                            need_full = false;
+                        }
+                    }
+                    // what can still matter in a full search: the correspondence threshold and -- its voxel still among the 27 -- last iteration's neighbour
+                    if (need_full && P.wide_prune > 1 && wq.have_nn && abs(wq.pv[0] - wq.v[0]) <= 1 && abs(wq.pv[1] - wq.v[1]) <= 1 && abs(wq.pv[2] - wq.v[2]) <= 1)
                         limit0 = dp < limit0 ? dp : limit0;
+                    if (need_full) wq.lr_valid = false;
+                }
+                // (2) the full searches run on the first lanes when there are few of them (a wave's search costs the same with
+                // one lane busy as with 64), in place when most queries need one (the first iterations)
+                int my_rank = -1;
+                if (need_full) my_rank = atomicAdd(&sh.next_point, 1);
+                __syncthreads();
+                const int n_full = sh.next_point;  // (the whole workgroup)
+                const bool compact = P.wide_stable && n_full > 0 && n_full <= kWideRecs;
+                WideRec *recs = reinterpret_cast<WideRec *>(sh.part);
+                if (compact) {
+                    if (need_full) {
+                        WideRec &r = recs[my_rank];
+                        r.s[0] = wq.s[0];
+                        r.s[1] = wq.s[1];
+                        r.s[2] = wq.s[2];
+                        r.limit = limit0;
+                        r.v[0] = wq.v[0];
+                        r.v[1] = wq.v[1];
+                        r.v[2] = wq.v[2];
+                        r.occ = wq.occ;
+                        r.occ_E = wq.occ_E;
+                        r.cached = (wq.occ_valid && wq.occ_v[0] == wq.v[0] && wq.occ_v[1] == wq.v[1] && wq.occ_v[2] == wq.v[2]) ? 1 : 0;
                     }
-                    int bad = 0;
-                    wide_search_lds<PROF>(m, tile, wq, limit0, P.wide_prune > 0, bad, ctr, wb);
-                    if (bad) {  // the tile cannot answer (a voxel outside the key span, an entry that did not fit): the map from now on
-                        meta->valid = -1;
-                        wq.flag = 2;
-                        searching = false;
-                    }
+                    __syncthreads();
+                }
+                bool searching = compact ? tid < n_full : need_full;  // this lane runs a full search, for the query cq
+                WideQuery cq = wq;
+                if (compact && searching) {
+                    const WideRec &r = recs[tid];
+                    cq.s[0] = r.s[0];
+                    cq.s[1] = r.s[1];
+                    cq.s[2] = r.s[2];
+                    cq.v[0] = r.v[0];
+                    cq.v[1] = r.v[1];
+                    cq.v[2] = r.v[2];
+                    limit0 = r.limit;
+                    cq.occ = r.occ;
+                    cq.occ_E = r.occ_E;
+                    cq.occ_valid = r.cached != 0;
+                    cq.occ_v[0] = r.v[0];
+                    cq.occ_v[1] = r.v[1];
+                    cq.occ_v[2] = r.v[2];
+                    cq.flag = 0;
+                }
+                WideBest wb;
+                wb.m_map = wb.m_lds = 0u;
+                wb.seen = 0u;
+                wb.sec = DBL_MAX;
+                int cq_bad = 0;
+                if (searching) {
+                    wide_search_lds<PROF>(m, tile, cq, limit0, P.wide_prune > 0, cq_bad, ctr, wb);
+                    if (cq_bad) searching = false;  // (the tile cannot answer: a voxel outside the key span, an entry that did not fit)
                 }
                 // Whatever this query still has to look at -- voxels in the LDS store beyond the first, voxels in the map -- goes
                 // into the two queues the groups serve; what does not fit waits for the next round.
                 WideItem *items = reinterpret_cast<WideItem *>(sh.terms);
                 unsigned pend_lds = searching ? wb.m_lds : 0u, pend_map = searching ? wb.m_map : 0u;
-                if (active && wq.flag == 2) sh.cell_count = 1;
+                if (active && wq.flag == 2) sh.cell_count = 1;  // (queries without a tile; those a search has just found unanswerable join below)
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
                 int prof_items = 0, prof_map_items = 0, prof_rounds = 0, prof_direct = 0;
                 unsigned prof_file = 0, prof_serve = 0, prof_merge = 0, prof_c = 0;
@@ -1045,12 +1116,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         const int jj = __ffs(pend) - 1;
                         pend &= pend - 1u;
                         WideItem &it = dst[base + r];
-                        it.s[0] = wq.s[0];
-                        it.s[1] = wq.s[1];
-                        it.s[2] = wq.s[2];
+                        it.s[0] = cq.s[0];
+                        it.s[1] = cq.s[1];
+                        it.s[2] = cq.s[2];
                         it.d2 = DBL_MAX;
                         unsigned slot = 0u;
-                        it.blk_cnt = wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj, &slot) & ~(kTileReady | kTileGlobal);
+                        it.blk_cnt = wide_entry(tile, cq.v[0], cq.v[1], cq.v[2], jj, &slot) & ~(kTileReady | kTileGlobal);
                         it.slot = (unsigned short)slot;
                         it.j = (unsigned char)jj;
                         it.k = 0;
@@ -1060,7 +1131,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 auto merge_items = [&](const WideItem *src, int base, int n_filed) {
                     for (int r = 0; r < n_filed; ++r) {
                         const WideItem &it = src[base + r];
-                        wide_take(wb, wq.s[0], wq.s[1], wq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
+                        wide_take(wb, cq.s[0], cq.s[1], cq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
+                        const double runner_up = (double)__uint_as_float(it.blk_cnt);  // (FLT_MAX: the voxel holds one point)
+                        if (it.d2 < DBL_MAX && runner_up < (double)FLT_MAX && runner_up < wb.sec) wb.sec = runner_up;
+                        wb.seen |= 1u << it.j;
                     }
                 };
                 for (int round = 0;; ++round) {
@@ -1070,7 +1144,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         while (todo) {
                             const int jj = __ffs(todo) - 1;
                             todo &= todo - 1u;
-                            if (!(wide_entry(tile, wq.v[0], wq.v[1], wq.v[2], jj) & kTileGlobal)) {
+                            if (!(wide_entry(tile, cq.v[0], cq.v[1], cq.v[2], jj) & kTileGlobal)) {
                                 pend_map &= ~(1u << jj);
                                 pend_lds |= 1u << jj;
                             }
@@ -1097,7 +1171,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     merge_items(items + kWideItemsLds, base_m, nf_m);
                     if ((pend_lds | pend_map) != 0u && P.wide_prune > 0) {  // what is left, against what the answers have brought
                         wb.limit = wb.best < wb.limit ? wb.best : wb.limit;
-                        const unsigned keep = wide_keep_mask(wide_gaps(wq.s, wq.v, m.voxel_size), wb.limit);
+                        const unsigned keep = wide_keep_mask(wide_gaps(cq.s, cq.v, m.voxel_size), wb.limit);
                         pend_lds &= keep;
                         pend_map &= keep;
                     }
@@ -1108,7 +1182,59 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         prof_merge += ticks32() - tr2;
                     }
                 }
-                if (searching) wide_finish(wq, wb);
+                // (3) the answers go home
+                if (searching) wide_finish(m, cq, wb);
+                if (compact) {
+                    if (tid < n_full) {
+                        WideRec &r = recs[tid];
+                        r.s[0] = cq.nn[0];
+                        r.s[1] = cq.nn[1];
+                        r.s[2] = cq.nn[2];
+                        r.limit = cq.d2;
+                        r.v[0] = wb.bkey;
+                        r.v[1] = cq.E;
+                        r.v[2] = cq_bad;
+                        r.occ = cq.occ;
+                        r.occ_E = cq.occ_E;
+                        r.cached = cq.occ_valid ? 1 : 0;
+                        r.Lr = cq.Lr;
+                    }
+                    __syncthreads();
+                    if (need_full) {
+                        const WideRec &r = recs[my_rank];
+                        cq_bad = r.v[2];
+                        wq.nn[0] = r.s[0];
+                        wq.nn[1] = r.s[1];
+                        wq.nn[2] = r.s[2];
+                        wq.d2 = r.limit;
+                        wq.E = r.v[1];
+                        wq.have_nn = !cq_bad && r.limit < DBL_MAX;
+                        if (wq.have_nn) {
+                            const int j = r.v[0] >> 5;
+                            wq.pv[0] = wq.v[0] + (int)((kShift.x >> (2 * j)) & 3) - 1;
+                            wq.pv[1] = wq.v[1] + (int)((kShift.y >> (2 * j)) & 3) - 1;
+                            wq.pv[2] = wq.v[2] + (int)((kShift.z >> (2 * j)) & 3) - 1;
+                        }
+                        wq.occ = r.occ;
+                        wq.occ_E = r.occ_E;
+                        wq.occ_valid = !cq_bad && r.cached != 0;
+                        wq.occ_v[0] = wq.v[0];
+                        wq.occ_v[1] = wq.v[1];
+                        wq.occ_v[2] = wq.v[2];
+                        wq.Lr = r.Lr;
+                        wq.lr_valid = wq.occ_valid;
+                    }
+                } else if (need_full) {
+                    wq = cq;
+                }
+                if (need_full && cq_bad) {  // the map from now on
+                    meta->valid = -1;
+                    wq.flag = 2;
+                    wq.have_nn = false;
+                    wq.occ_valid = wq.lr_valid = false;
+                    sh.cell_count = 1;
+                }
+                if (compact || n_full > 0) __syncthreads();  // (sh.cell_count; the records' memory is the exchange's)
                 if (sh.cell_count) prof_direct = serve(2, &sh.list_entries);
                 if (PROF) t_group += ticks32() - tb0;
                 // ---- C: products of kWideTermRows points at a time, added in the first form's order ----------------

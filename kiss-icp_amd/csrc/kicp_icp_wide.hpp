@@ -75,7 +75,31 @@ struct WideQuery {  // registers of the owning thread
     unsigned occ;
     int occ_v[3], occ_E;
     bool occ_valid;
+    // STABILITY.  Lr: a lower bound (a distance, not squared, shaved by 2^-30) of the distance from the query to every map
+    // point of its 27 cells EXCEPT nn -- the second smallest distance the last full search computed, or the smallest
+    // box bound of a cell it did not read.  The query moves by |s' - s| per iteration, so every one of those points stays
+    // at least Lr - |s' - s| away (triangle inequality); as long as the query stays in its voxel (same 27 cells) and nn's
+    // new distance is strictly below that, nn is still the unique minimum the reference's strict '<' loops would find
+    // (VoxelHashMap.cpp:55-63) and E is unchanged: the iteration needs no lookup and no point -- registers only.
+    // Anything else (voxel left, margin used up, no neighbour yet) takes the full search, which renews Lr.
+    double Lr;
+    bool lr_valid;
 };
+
+// a query on its way to / from the lanes that run the full searches of an iteration (compaction: a few per cent of a
+// workgroup's queries need one, a few iterations in; gathered into the first lanes they cost one wave instead of all)
+struct WideRec {
+    double s[3];    // in: the query;            out: nn
+    double limit;   // in: limit0;               out: d2
+    int v[3];       // in: its voxel;            out: {bkey, E, bad}
+    unsigned occ;   // in / out: occupancy of the 27 cells (in: when `cached`)
+    int occ_E;
+    int cached;     // in: occ / occ_E are valid for v
+    double Lr;      // out
+};
+static_assert(sizeof(WideRec) == 64, "WideRec layout");
+static_assert(offsetof(IcpShared, range_sum) == offsetof(IcpShared, part) + sizeof(double) * kIcpGroupsPerBlock * kIcpSums, "the records use part and range_sum as one array");
+constexpr int kWideRecs = (int)((sizeof(double) * kIcpGroupsPerBlock * kIcpSums + sizeof(double) * kIcpMaxMembers * kIcpSums) / sizeof(WideRec));  // 114
 
 // ---- lower bounds of the distances to the neighbouring voxel layers --------------------------------------------------
 // A point p stored in voxel c satisfies floor(fl(p / vs)) == c (PointToVoxel, VoxelUtils.hpp:33-37), hence
@@ -124,7 +148,8 @@ struct WideCounters {  // profiling build
 struct WideItem {
     double s[3];       // in: the query; out: the voxel's point closest to it
     double d2;         // out: its squared distance
-    unsigned blk_cnt;  // block id (LDS queue: position in the LDS store) | point count << 24
+    unsigned blk_cnt;  // in: block id (LDS queue: position in the LDS store) | point count << 24; out: the voxel's SECOND smallest squared
+                       // distance as float bits, rounded down (FLT_MAX: the voxel has one point) -- a bound, for the stability test
     unsigned short slot;  // the voxel's slot in the tile's table
     unsigned char j, k;   // shift position of the voxel; out: index of the point in it
 };
@@ -142,16 +167,23 @@ struct WideBest {  // a search in progress (between the LDS part and the map par
     double limit;  // nothing at a distance above this can be, or tie with, the answer
     int bkey;
     unsigned m_lds, m_map;  // occupied cells that can still matter and have not been read: points in the LDS store / in the map only
+    double sec;     // the smallest squared distance computed for any point other than the best one (DBL_MAX: none)
+    unsigned seen;  // cells whose points have been read
 };
 __device__ __forceinline__ void wide_take(WideBest &b, double sx, double sy, double sz, double x, double y, double z, int key, bool valid) {
     const double ex = x - sx, ey = y - sy, ez = z - sz;
     const double d = (ex * ex + ey * ey) + ez * ez;
-    if (valid && (d < b.best || (d == b.best && key < b.bkey))) {
-        b.best = d;
-        b.bkey = key;
-        b.bx = x;
-        b.by = y;
-        b.bz = z;
+    if (valid) {
+        if (d < b.best || (d == b.best && key < b.bkey)) {
+            b.sec = b.best;  // (the best so far is not above anything seen before)
+            b.best = d;
+            b.bkey = key;
+            b.bx = x;
+            b.by = y;
+            b.bz = z;
+        } else {
+            b.sec = d < b.sec ? d : b.sec;
+        }
     }
 }
 
@@ -186,6 +218,8 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     b.bkey = 0x7FFFFFFF;
     b.limit = limit0;
     b.m_map = 0u;
+    b.sec = DBL_MAX;
+    b.seen = 0u;
     const unsigned tp0 = PROF ? ticks32() : 0u;
     const int vx = q.v[0], vy = q.v[1], vz = q.v[2];
     const double sx = q.s[0], sy = q.s[1], sz = q.s[2];
@@ -300,6 +334,7 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
         if (visits > 0 && walked_points + cnt > kWideWalkPoints) break;
         ++visits;
         m_lds &= m_lds - 1u;
+        b.seen |= 1u << j;
         const double *P = tile.points + 3 * ref;
         for (int k0 = 0; k0 < cnt; k0 += 2) {
             const int k1 = k0 + 1 < cnt ? k0 + 1 : k0;
@@ -427,6 +462,12 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
             double gd = d;
             int gk = ld[u] ? lane : 0x7FFFFFFF;
             group_min_dist_key(gd, gk);
+            double g2 = (ld[u] && gk != lane) ? d : DBL_MAX;  // the runner-up of the voxel
+            group_fmin_step<0>(g2);
+            group_fmin_step<1>(g2);
+            group_fmin_step<2>(g2);
+            group_fmin_step<3>(g2);
+            group_fmin_step<4>(g2);
             if (valid[u] && ld[u] && gk == lane) {
                 WideItem &it = items[e0 + kIcpGroupsPerBlock * u];
                 it.s[0] = xy[u].x;
@@ -434,13 +475,15 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
                 it.s[2] = zz[u];
                 it.d2 = gd;
                 it.k = (unsigned char)lane;
+                it.blk_cnt = __float_as_uint(g2 < (double)FLT_MAX ? __double2float_rd(g2) : FLT_MAX);
             }
         }
     }
 }
 
-// the search's result into the query's registers
-__device__ __forceinline__ void wide_finish(WideQuery &q, const WideBest &b) {
+// the search's result into the query's registers, and the bound that lets the next iterations do without a search
+// (WideQuery::Lr): the second smallest distance computed, or the smallest box bound of an occupied cell that was not read
+__device__ __forceinline__ void wide_finish(const MapView &m, WideQuery &q, const WideBest &b) {
     q.d2 = b.best;
     q.have_nn = false;
     if (b.best < DBL_MAX) {
@@ -453,6 +496,22 @@ __device__ __forceinline__ void wide_finish(WideQuery &q, const WideBest &b) {
         q.pv[2] = q.v[2] + (int)((kShift.z >> (2 * j)) & 3) - 1;
         q.have_nn = true;
     }
+    double L = b.sec;
+    const unsigned unread = q.occ & ~b.seen;
+    if (unread) {
+        const WideGaps gaps = wide_gaps(q.s, q.v, m.voxel_size);
+#pragma unroll
+        for (int j = 0; j < 27; ++j) {
+            const int cx = (int)((kShift.x >> (2 * j)) & 3), cy = (int)((kShift.y >> (2 * j)) & 3), cz = (int)((kShift.z >> (2 * j)) & 3);
+            const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
+            const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
+            const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
+            const double bd = (bx + by) + bz;
+            if (((unread >> j) & 1u) && bd < L) L = bd;
+        }
+    }
+    q.Lr = sqrt(L) * (1.0 - 0x1p-30);
+    q.lr_valid = q.occ_valid;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -219,6 +219,8 @@ struct IcpParams {
     int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
+    int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
+                           // are searched on the first lanes (0: every query is searched in place, every iteration)
     int wide_per_round;    // thread-per-query form: items a thread files per round and queue
     int wide_prefill;      // thread-per-query form: eighths of the LDS store the window phase fills with points (0: the table only; the
                            // store is then filled by the searches themselves, from the second iteration on)
@@ -255,7 +257,8 @@ struct Options {
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
-    long icp_wide_per_round = 2; // thread-per-query form: items a thread files per round and queue (1 .. 27)
+    long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
+    long icp_wide_per_round = 4; // thread-per-query form: items a thread files per round and queue (1 .. 27)
     long icp_wide_prefill = 0;   // thread-per-query form: eighths of the LDS store filled by the window phase (0 .. 8)
     long icp_wide_prune = 2;     // thread-per-query form: 0 visit every occupied voxel, 1 skip by box distance, 2 + bound from the last neighbour
     long icp_profile = 0;        // 1: launch the ICP kernel variant that records phase timers
