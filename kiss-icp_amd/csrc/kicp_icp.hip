@@ -809,15 +809,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     wq.lr_valid = false;
     wq.Lr = 0.0;
     wq.occ = 0u;
-    wq.occ_E = 0;
-    wq.occ_v[0] = wq.occ_v[1] = wq.occ_v[2] = 0;
     wq.flag = 2;
     wq.E = 0;
     wq.d2 = DBL_MAX;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         wq.s[a] = wq.nn[a] = 0.0;
-        wq.v[a] = wq.pv[a] = 0;
+        wq.v[a] = 0;
     }
 
     const int max_iters = map_empty ? 0 : P.max_iters;
@@ -864,7 +862,20 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         pin[1] = P.work[3 * (size_t)(q0 + j) + 1];
                         pin[2] = P.work[3 * (size_t)(q0 + j) + 2];
                     }
-                    se3_act(est, pin, wq.s);
+                    // (the transform comes from LDS -- the initial guess, then every solve's result -- instead of staying in
+                    // fourteen registers per thread through the whole iteration: this form's registers are all taken)
+                    SE3 step;
+                    {
+                        const double *e = it == 0 ? sh.guess : sh.est;
+                        step.q[0] = e[0];
+                        step.q[1] = e[1];
+                        step.q[2] = e[2];
+                        step.q[3] = e[3];
+                        step.t[0] = e[4];
+                        step.t[1] = e[5];
+                        step.t[2] = e[6];
+                    }
+                    se3_act(step, pin, wq.s);
                     if (single && it > 0) {  // how far the query has moved since the last iteration (for the stability test), rounded up
                         const double mx = wq.s[0] - pin[0], my = wq.s[1] - pin[1], mz = wq.s[2] - pin[2];
                         moved = sqrt((mx * mx + my * my) + mz * mz) * (1.0 + 0x1p-30) + DBL_MIN;
@@ -879,6 +890,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                     const int vx = voxel_coord_fast(wq.s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(wq.s[1], m.voxel_size, inv_voxel),
                               vz = voxel_coord_fast(wq.s[2], m.voxel_size, inv_voxel);
+                    if (vx != wq.v[0] || vy != wq.v[1] || vz != wq.v[2]) {  // another voxel: another 27 cells -- nothing that was found out carries over
+                        wq.occ_valid = false;
+                        wq.lr_valid = false;
+                        wq.have_nn = false;
+                    }
                     wq.v[0] = vx;
                     wq.v[1] = vy;
                     wq.v[2] = vz;
@@ -895,7 +911,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         // may lie all around the sensor, farther apart than any span centred on one of them covers --, else on
                         // the run's first point.
                         const bool reach_fits = m.max_distance * inv_voxel < (double)(kTileSpanXY / 2 - 4);
-                        const int cx = reach_fits ? voxel_coord(guess.t[0], m.voxel_size) : vx, cy = reach_fits ? voxel_coord(guess.t[1], m.voxel_size) : vy;
+                        const int cx = reach_fits ? voxel_coord(sh.guess[4], m.voxel_size) : vx, cy = reach_fits ? voxel_coord(sh.guess[5], m.voxel_size) : vy;
                         sh.origin[0] = cx - kTileSpanXY / 2;
                         sh.origin[1] = cy - kTileSpanXY / 2;
                         sh.origin[2] = vz - kTileSpanZ / 2;
@@ -971,6 +987,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                 wq.E = r.E;
                                 wq.have_nn = false;
                                 wq.lr_valid = false;
+                                wq.occ_valid = false;
                             }
                             pending = false;
                         }
@@ -1020,13 +1037,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 bool need_full = active && wq.flag == 0;
                 double limit0 = limit_corr;
                 if (need_full) {
-                    const bool same_voxel = wq.occ_valid && wq.occ_v[0] == wq.v[0] && wq.occ_v[1] == wq.v[1] && wq.occ_v[2] == wq.v[2];
                     double dp = DBL_MAX;
-                    if (wq.have_nn) {
+                    if (wq.have_nn) {  // (found from this very voxel: the point is among the 27 cells)
                         const double ex = wq.nn[0] - wq.s[0], ey = wq.nn[1] - wq.s[1], ez = wq.nn[2] - wq.s[2];
                         dp = (ex * ex + ey * ey) + ez * ez;  // (as the search computes it)
                     }
-                    if (P.wide_stable && single && it > 0 && wq.lr_valid && same_voxel) {
+                    if (P.wide_stable && single && it > 0 && wq.lr_valid && wq.occ_valid) {
                         wq.Lr -= moved;
                         bool ok;
                         if (wq.have_nn)
@@ -1034,14 +1050,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         else  // (no neighbour last time: nothing within the correspondence threshold -- or nothing at all)
                             ok = wq.occ == 0u || sqrt(limit_corr) * (1.0 + 0x1p-30) < wq.Lr;
                         if (ok) {
-                            wq.d2 = dp;
-                            wq.E = wq.occ_E;
+                            wq.d2 = dp;  // (E stays)
                             need_full = false;
                         }
                     }
-                    // what can still matter in a full search: the correspondence threshold and -- its voxel still among the 27 -- last iteration's neighbour
-                    if (need_full && P.wide_prune > 1 && wq.have_nn && abs(wq.pv[0] - wq.v[0]) <= 1 && abs(wq.pv[1] - wq.v[1]) <= 1 && abs(wq.pv[2] - wq.v[2]) <= 1)
-                        limit0 = dp < limit0 ? dp : limit0;
+                    // what can still matter in a full search: the correspondence threshold and the last neighbour
+                    if (need_full && P.wide_prune > 1 && wq.have_nn) limit0 = dp < limit0 ? dp : limit0;
                     if (need_full) wq.lr_valid = false;
                 }
                 // (2) the full searches run on the first lanes when there are few of them (a wave's search costs the same with
@@ -1063,38 +1077,50 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         r.v[1] = wq.v[1];
                         r.v[2] = wq.v[2];
                         r.occ = wq.occ;
-                        r.occ_E = wq.occ_E;
-                        r.cached = (wq.occ_valid && wq.occ_v[0] == wq.v[0] && wq.occ_v[1] == wq.v[1] && wq.occ_v[2] == wq.v[2]) ? 1 : 0;
+                        r.E = wq.E;
+                        r.cached = wq.occ_valid ? 1 : 0;
                     }
                     __syncthreads();
                 }
-                bool searching = compact ? tid < n_full : need_full;  // this lane runs a full search, for the query cq
-                WideQuery cq = wq;
+                bool searching = compact ? tid < n_full : need_full;  // this lane runs a full search, for the query `job`
+                WideJob job;
+                job.s[0] = wq.s[0];
+                job.s[1] = wq.s[1];
+                job.s[2] = wq.s[2];
+                job.v[0] = wq.v[0];
+                job.v[1] = wq.v[1];
+                job.v[2] = wq.v[2];
+                job.occ = wq.occ;
+                job.E = wq.E;
+                job.cached = wq.occ_valid;
+                job.d2 = DBL_MAX;
+                job.Lr = 0.0;
+                job.bkey = 0x7FFFFFFF;
                 if (compact && searching) {
                     const WideRec &r = recs[tid];
-                    cq.s[0] = r.s[0];
-                    cq.s[1] = r.s[1];
-                    cq.s[2] = r.s[2];
-                    cq.v[0] = r.v[0];
-                    cq.v[1] = r.v[1];
-                    cq.v[2] = r.v[2];
+                    job.s[0] = r.s[0];
+                    job.s[1] = r.s[1];
+                    job.s[2] = r.s[2];
+                    job.v[0] = r.v[0];
+                    job.v[1] = r.v[1];
+                    job.v[2] = r.v[2];
                     limit0 = r.limit;
-                    cq.occ = r.occ;
-                    cq.occ_E = r.occ_E;
-                    cq.occ_valid = r.cached != 0;
-                    cq.occ_v[0] = r.v[0];
-                    cq.occ_v[1] = r.v[1];
-                    cq.occ_v[2] = r.v[2];
-                    cq.flag = 0;
+                    job.occ = r.occ;
+                    job.E = r.E;
+                    job.cached = r.cached != 0;
                 }
                 WideBest wb;
+                wb.best = DBL_MAX;
+                wb.bx = wb.by = wb.bz = 0.0;
+                wb.bkey = 0x7FFFFFFF;
+                wb.limit = limit0;
                 wb.m_map = wb.m_lds = 0u;
                 wb.seen = 0u;
                 wb.sec = DBL_MAX;
-                int cq_bad = 0;
+                int job_bad = 0;
                 if (searching) {
-                    wide_search_lds<PROF>(m, tile, cq, limit0, P.wide_prune > 0, cq_bad, ctr, wb);
-                    if (cq_bad) searching = false;  // (the tile cannot answer: a voxel outside the key span, an entry that did not fit)
+                    wide_search_lds<PROF>(m, tile, job, limit0, P.wide_prune > 0, job_bad, ctr, wb);
+                    if (job_bad) searching = false;  // (the tile cannot answer: a voxel outside the key span, an entry that did not fit)
                 }
                 // Whatever this query still has to look at -- voxels in the LDS store beyond the first, voxels in the map -- goes
                 // into the two queues the groups serve; what does not fit waits for the next round.
@@ -1116,12 +1142,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         const int jj = __ffs(pend) - 1;
                         pend &= pend - 1u;
                         WideItem &it = dst[base + r];
-                        it.s[0] = cq.s[0];
-                        it.s[1] = cq.s[1];
-                        it.s[2] = cq.s[2];
+                        it.s[0] = job.s[0];
+                        it.s[1] = job.s[1];
+                        it.s[2] = job.s[2];
                         it.d2 = DBL_MAX;
                         unsigned slot = 0u;
-                        it.blk_cnt = wide_entry(tile, cq.v[0], cq.v[1], cq.v[2], jj, &slot) & ~(kTileReady | kTileGlobal);
+                        it.blk_cnt = wide_entry(tile, job.v[0], job.v[1], job.v[2], jj, &slot) & ~(kTileReady | kTileGlobal);
                         it.slot = (unsigned short)slot;
                         it.j = (unsigned char)jj;
                         it.k = 0;
@@ -1131,7 +1157,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 auto merge_items = [&](const WideItem *src, int base, int n_filed) {
                     for (int r = 0; r < n_filed; ++r) {
                         const WideItem &it = src[base + r];
-                        wide_take(wb, cq.s[0], cq.s[1], cq.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
+                        wide_take(wb, job.s[0], job.s[1], job.s[2], it.s[0], it.s[1], it.s[2], ((int)it.j << 5) | (int)it.k, it.d2 < DBL_MAX);
                         const double runner_up = (double)__uint_as_float(it.blk_cnt);  // (FLT_MAX: the voxel holds one point)
                         if (it.d2 < DBL_MAX && runner_up < (double)FLT_MAX && runner_up < wb.sec) wb.sec = runner_up;
                         wb.seen |= 1u << it.j;
@@ -1144,7 +1170,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         while (todo) {
                             const int jj = __ffs(todo) - 1;
                             todo &= todo - 1u;
-                            if (!(wide_entry(tile, cq.v[0], cq.v[1], cq.v[2], jj) & kTileGlobal)) {
+                            if (!(wide_entry(tile, job.v[0], job.v[1], job.v[2], jj) & kTileGlobal)) {
                                 pend_map &= ~(1u << jj);
                                 pend_lds |= 1u << jj;
                             }
@@ -1171,7 +1197,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     merge_items(items + kWideItemsLds, base_m, nf_m);
                     if ((pend_lds | pend_map) != 0u && P.wide_prune > 0) {  // what is left, against what the answers have brought
                         wb.limit = wb.best < wb.limit ? wb.best : wb.limit;
-                        const unsigned keep = wide_keep_mask(wide_gaps(cq.s, cq.v, m.voxel_size), wb.limit);
+                        const unsigned keep = wide_keep_mask(wide_gaps(job.s, job.v, m.voxel_size), wb.limit);
                         pend_lds &= keep;
                         pend_map &= keep;
                     }
@@ -1183,56 +1209,58 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                 }
                 // (3) the answers go home
-                if (searching) wide_finish(m, cq, wb);
+                if (searching) wide_finish(m, job, wb);
+                bool got = false;  // this thread's query has had its full search
                 if (compact) {
                     if (tid < n_full) {
                         WideRec &r = recs[tid];
-                        r.s[0] = cq.nn[0];
-                        r.s[1] = cq.nn[1];
-                        r.s[2] = cq.nn[2];
-                        r.limit = cq.d2;
-                        r.v[0] = wb.bkey;
-                        r.v[1] = cq.E;
-                        r.v[2] = cq_bad;
-                        r.occ = cq.occ;
-                        r.occ_E = cq.occ_E;
-                        r.cached = cq.occ_valid ? 1 : 0;
-                        r.Lr = cq.Lr;
+                        r.s[0] = wb.bx;
+                        r.s[1] = wb.by;
+                        r.s[2] = wb.bz;
+                        r.limit = job.d2;
+                        r.v[0] = job.bkey;
+                        r.v[2] = job_bad;
+                        r.occ = job.occ;
+                        r.E = job.E;
+                        r.Lr = job.Lr;
                     }
                     __syncthreads();
                     if (need_full) {
                         const WideRec &r = recs[my_rank];
-                        cq_bad = r.v[2];
-                        wq.nn[0] = r.s[0];
-                        wq.nn[1] = r.s[1];
-                        wq.nn[2] = r.s[2];
-                        wq.d2 = r.limit;
-                        wq.E = r.v[1];
-                        wq.have_nn = !cq_bad && r.limit < DBL_MAX;
-                        if (wq.have_nn) {
-                            const int j = r.v[0] >> 5;
-                            wq.pv[0] = wq.v[0] + (int)((kShift.x >> (2 * j)) & 3) - 1;
-                            wq.pv[1] = wq.v[1] + (int)((kShift.y >> (2 * j)) & 3) - 1;
-                            wq.pv[2] = wq.v[2] + (int)((kShift.z >> (2 * j)) & 3) - 1;
-                        }
-                        wq.occ = r.occ;
-                        wq.occ_E = r.occ_E;
-                        wq.occ_valid = !cq_bad && r.cached != 0;
-                        wq.occ_v[0] = wq.v[0];
-                        wq.occ_v[1] = wq.v[1];
-                        wq.occ_v[2] = wq.v[2];
-                        wq.Lr = r.Lr;
-                        wq.lr_valid = wq.occ_valid;
+                        job_bad = r.v[2];
+                        wb.bx = r.s[0];
+                        wb.by = r.s[1];
+                        wb.bz = r.s[2];
+                        job.d2 = r.limit;
+                        job.occ = r.occ;
+                        job.E = r.E;
+                        job.Lr = r.Lr;
+                        got = true;
                     }
-                } else if (need_full) {
-                    wq = cq;
+                } else {
+                    got = need_full;
                 }
-                if (need_full && cq_bad) {  // the map from now on
-                    meta->valid = -1;
-                    wq.flag = 2;
-                    wq.have_nn = false;
-                    wq.occ_valid = wq.lr_valid = false;
-                    sh.cell_count = 1;
+                if (got) {
+                    if (job_bad) {  // the map from now on
+                        meta->valid = -1;
+                        wq.flag = 2;
+                        wq.have_nn = false;
+                        wq.occ_valid = wq.lr_valid = false;
+                        sh.cell_count = 1;
+                    } else {
+                        wq.d2 = job.d2;
+                        wq.E = job.E;
+                        wq.occ = job.occ;
+                        wq.occ_valid = true;
+                        wq.Lr = job.Lr;
+                        wq.lr_valid = true;
+                        wq.have_nn = job.d2 < DBL_MAX;
+                        if (wq.have_nn) {
+                            wq.nn[0] = wb.bx;
+                            wq.nn[1] = wb.by;
+                            wq.nn[2] = wb.bz;
+                        }
+                    }
                 }
                 if (compact || n_full > 0) __syncthreads();  // (sh.cell_count; the records' memory is the exchange's)
                 if (sh.cell_count) prof_direct = serve(2, &sh.list_entries);

@@ -59,21 +59,19 @@ struct WideMeta {
 };
 static_assert(sizeof(WideMeta) == 20, "WideMeta layout");
 
-struct WideQuery {  // registers of the owning thread
+struct WideQuery {  // registers of the owning thread, from iteration to iteration
     double s[3];   // transformed source point
-    double nn[3];  // closest map point (valid when d2 < DBL_MAX)
-    double d2;
+    double nn[3];  // closest map point (have_nn)
+    double d2;     // its squared distance (DBL_MAX: no neighbour)
     int v[3];      // voxel of s
-    int pv[3];     // voxel nn was found in (have_nn)
     int E;         // map points the reference examines for this query
     int flag;      // 0 window valid, 1 window must be (re)established, 2 map-direct search
-    bool have_nn;  // nn / pv come from a tile search of this launch
-    // which of the 27 cells around occ_v are occupied, and their population: what the table lookups of a search find
-    // out.  It stays true as long as the query stays in its voxel (the map does not change during AlignPointsToMap), so
-    // a query that has not left its voxel since the last search skips the lookups -- and a wave all of whose queries
-    // stayed (most waves, a few iterations in) skips that part of the code altogether.
+    bool have_nn;  // nn comes from a tile search of this launch, made while the query was in voxel v
+    // OCCUPANCY: which of the 27 cells around v are occupied (and E, their population): what the table lookups of a search
+    // find out.  It stays true as long as the query stays in its voxel (the map does not change during
+    // AlignPointsToMap), so a query that has not left its voxel since its last search skips the lookups -- and a wave
+    // all of whose queries stayed skips that part of the code altogether.  occ_valid: occ / E / nn belong to voxel v.
     unsigned occ;
-    int occ_v[3], occ_E;
     bool occ_valid;
     // STABILITY.  Lr: a lower bound (a distance, not squared, shaved by 2^-30) of the distance from the query to every map
     // point of its 27 cells EXCEPT nn -- the second smallest distance the last full search computed, or the smallest
@@ -86,15 +84,26 @@ struct WideQuery {  // registers of the owning thread
     bool lr_valid;
 };
 
+// one full search: what goes in, what comes out (the neighbour itself comes back in WideBest)
+struct WideJob {
+    double s[3];
+    int v[3];
+    unsigned occ;  // in (cached) / out
+    int E;         // in (cached) / out
+    bool cached;   // in: occ / E are valid for v
+    double d2, Lr; // out
+    int bkey;      // out: {shift position, index} of the neighbour
+};
+
 // a query on its way to / from the lanes that run the full searches of an iteration (compaction: a few per cent of a
 // workgroup's queries need one, a few iterations in; gathered into the first lanes they cost one wave instead of all)
 struct WideRec {
     double s[3];    // in: the query;            out: nn
     double limit;   // in: limit0;               out: d2
-    int v[3];       // in: its voxel;            out: {bkey, E, bad}
+    int v[3];       // in: its voxel;            out: {bkey, -, bad}
     unsigned occ;   // in / out: occupancy of the 27 cells (in: when `cached`)
-    int occ_E;
-    int cached;     // in: occ / occ_E are valid for v
+    int E;          // in / out: their population
+    int cached;     // in: occ / E are valid for v
     double Lr;      // out
 };
 static_assert(sizeof(WideRec) == 64, "WideRec layout");
@@ -212,7 +221,7 @@ __device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy,
 // the key span or one the table has no entry for): the caller sends the query to the map-direct search.
 // (first part: the table lookups and the voxels in LDS; the voxels in the map are left in b.m_map)
 template <bool PROF>
-__device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &tile, WideQuery &q, double limit0, bool prune, int &bad, WideCounters &ctr, WideBest &b) {
+__device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &tile, WideJob &q, double limit0, bool prune, int &bad, WideCounters &ctr, WideBest &b) {
     b.best = DBL_MAX;
     b.bx = b.by = b.bz = 0.0;
     b.bkey = 0x7FFFFFFF;
@@ -225,16 +234,14 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     const double sx = q.s[0], sy = q.s[1], sz = q.s[2];
     // ---- 1: which of the 27 cells are occupied (three batches of nine: 18 + 9 loads in flight, ~45 registers) -----------
     bad = 0;
-    q.E = 0;
     q.d2 = DBL_MAX;
-    q.have_nn = false;
-    const bool cached = q.occ_valid && q.occ_v[0] == vx && q.occ_v[1] == vy && q.occ_v[2] == vz;
+    const bool cached = q.cached;
     unsigned m_lds = 0u, m_map = 0u, open = 0u;
     int E = 0;
     unsigned tp1 = tp0;
     if (cached) {
         m_lds = q.occ;  // (which of them are in the LDS store is found out when they are visited: voxels move there as they are used)
-        E = q.occ_E;
+        E = q.E;
     } else {
     {
         bool span_ok = true;
@@ -303,14 +310,9 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
             s = (s + 1u) & (unsigned)tile.slots_mask;
         }
     }
-    q.occ_valid = false;
     if (bad) return;
     q.occ = m_lds | m_map;
-    q.occ_v[0] = vx;
-    q.occ_v[1] = vy;
-    q.occ_v[2] = vz;
-    q.occ_E = E;
-    q.occ_valid = true;
+    q.cached = true;
     }
     q.E = E;
     const unsigned tp2 = PROF ? ticks32() : 0u;
@@ -369,38 +371,13 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
     }
 }
 
-// one voxel read by the thread itself (not used while the queue has rounds; kept for a caller that cannot wait)
-__device__ __forceinline__ void wide_visit_map(const MapView &m, const Tile &tile, const WideQuery &q, int j, WideBest &b) {
-    const unsigned v = wide_entry(tile, q.v[0], q.v[1], q.v[2], j);
-    const int blk = tile_ref(v), cnt = tile_cnt(v);
-    if (!(v & kTileGlobal)) {
-        const double *P = tile.points + 3 * blk;
-        for (int k = 0; k < cnt; ++k) wide_take(b, q.s[0], q.s[1], q.s[2], P[3 * k], P[3 * k + 1], P[3 * k + 2], (j << 5) | k, true);
-        return;
-    }
-    const double2 *XY = block_xy(m, blk);
-    const double *Z = block_z(m, blk);
-    for (int k0 = 0; k0 < cnt; k0 += 4) {
-        double2 xy[4];
-        double zz[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u < cnt ? k0 + u : k0;
-            xy[u] = XY[k];
-            zz[u] = Z[k];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wide_take(b, q.s[0], q.s[1], q.s[2], xy[u].x, xy[u].y, zz[u], (j << 5) | (k0 + u), k0 + u < cnt);
-    }
-}
-
 // the queue of {query, voxel} items, served by the 32-lane groups: lane i reads point i of the voxel (from the LDS store,
 // or from the map: one 16-byte and one 8-byte load, coalesced), kChunk voxels of a group in flight; the closest point of
 // the voxel -- the smaller index among equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back
 // into the item
 template <bool LDS>
 __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane, bool promote) {
-    constexpr int kFly = LDS ? kChunk : 8;  // voxels of a group in flight (map voxels: twelve -- a trip is an HBM / L2 round trip)
+    constexpr int kFly = LDS ? kChunk : 6;  // voxels of a group in flight (map voxels: twelve -- a trip is an HBM / L2 round trip)
     for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kFly) {  // wave-uniform trip count
         double2 xy[kFly];
         double zz[kFly];
@@ -481,21 +458,11 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
     }
 }
 
-// the search's result into the query's registers, and the bound that lets the next iterations do without a search
-// (WideQuery::Lr): the second smallest distance computed, or the smallest box bound of an occupied cell that was not read
-__device__ __forceinline__ void wide_finish(const MapView &m, WideQuery &q, const WideBest &b) {
+// the end of a full search: its distance, and the bound that lets the next iterations do without a search (WideQuery::Lr)
+// -- the second smallest distance computed, or the smallest box bound of an occupied cell that was not read
+__device__ __forceinline__ void wide_finish(const MapView &m, WideJob &q, const WideBest &b) {
     q.d2 = b.best;
-    q.have_nn = false;
-    if (b.best < DBL_MAX) {
-        const int j = b.bkey >> 5;
-        q.nn[0] = b.bx;
-        q.nn[1] = b.by;
-        q.nn[2] = b.bz;
-        q.pv[0] = q.v[0] + (int)((kShift.x >> (2 * j)) & 3) - 1;
-        q.pv[1] = q.v[1] + (int)((kShift.y >> (2 * j)) & 3) - 1;
-        q.pv[2] = q.v[2] + (int)((kShift.z >> (2 * j)) & 3) - 1;
-        q.have_nn = true;
-    }
+    q.bkey = b.bkey;
     double L = b.sec;
     const unsigned unread = q.occ & ~b.seen;
     if (unread) {
@@ -511,7 +478,6 @@ __device__ __forceinline__ void wide_finish(const MapView &m, WideQuery &q, cons
         }
     }
     q.Lr = sqrt(L) * (1.0 - 0x1p-30);
-    q.lr_valid = q.occ_valid;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -658,7 +624,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
     }
     stamp(0);
     // ---- 2b: one map lookup per distinct cell, three in flight per thread; occupied voxels enter the table and file a fetch job
-    constexpr int kBatch = 3;
+    constexpr int kBatch = 2;
     // (two segments with a barrier between them: every near cell has its room in the store before the first of the others asks)
     for (int seg = 0; seg < 2; ++seg) {
     const int j_end = seg == 0 ? n_near : n_cells;
@@ -806,7 +772,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
             for (int i = 0; i < cnt; ++i) owner[off + i] = (unsigned short)j;
         }
         __syncthreads();
-        constexpr int kPerThread = 6;  // points a thread keeps in flight: 3072 per trip
+        constexpr int kPerThread = 4;  // points a thread keeps in flight: 2048 per trip
         for (int p0 = s0 + tid; p0 < s1; p0 += kIcpThreads * kPerThread) {
             double2 xy[kPerThread];
             double zz[kPerThread];
@@ -836,7 +802,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
                 }
         }
     } else {
-        constexpr int kFly = 12;  // voxels a 32-lane group keeps in flight (lane i fetches point i: one 16-byte and one 8-byte load)
+        constexpr int kFly = 4;   // voxels a 32-lane group keeps in flight (lane i fetches point i: one 16-byte and one 8-byte load)
         const int lane = tid & (kIcpGroup - 1), grp = tid / kIcpGroup;
         for (int j0 = grp; j0 < n_jobs; j0 += kIcpGroupsPerBlock * kFly) {  // job j0 + 16 u: the groups share every trip evenly
             double2 xy[kFly];
