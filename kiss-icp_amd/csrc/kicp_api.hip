@@ -201,6 +201,8 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
     P.wide_stable = (int)options().icp_wide_stable;
+    P.wide_promote_from = (int)options().icp_wide_promote_from;
+    P.wide_load_eighths = (int)options().icp_wide_load_eighths;
     return grid;
 }
 
@@ -2365,6 +2367,12 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide")) {
         if (value < -1 || value > 1) return KICP_ERR_INVALID_ARG;
         options().icp_wide = value;
+    } else if (!strcmp(name, "icp_wide_promote_from")) {
+        if (value < 0 || value > 1000) return KICP_ERR_INVALID_ARG;
+        options().icp_wide_promote_from = value;
+    } else if (!strcmp(name, "icp_wide_load_eighths")) {
+        if (value < 2 || value > 7) return KICP_ERR_INVALID_ARG;
+        options().icp_wide_load_eighths = value;
     } else if (!strcmp(name, "icp_wide_stable")) {
         options().icp_wide_stable = value != 0;
     } else if (!strcmp(name, "icp_wide_per_round")) {

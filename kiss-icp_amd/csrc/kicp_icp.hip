@@ -493,9 +493,56 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     const int dense_min = long_runs ? 0 : P.dense_min, dense_div = long_runs ? 1 : P.dense_div;
     long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
     long long my_sum = 0;
-    // one 32-lane group per point: lane j looks up the j-th voxel of the point's 27-neighbourhood (all in flight together)
     const int lane = tid & (kIcpGroup - 1);
-    for (int q = s0 + tid / kIcpGroup; q < s1; q += kIcpGroupsPerBlock) {
+    // Long runs (hundreds of points per slice): a THREAD per point, its 27 lookups three at a time -- served 16 points at a
+    // time by the groups below, 420 points were 26 dependent rounds of lookups, ~100 us of every launch of the 1M-point
+    // configuration (profiles/r04_r_icp_probe_livox100.txt).  Same c, same E, same weight.
+    if (long_runs) {
+        for (int q = s0 + tid; q < s1; q += kIcpThreads) {
+            const int p = min((int)(P.order[q] & 0xFFFFFFull), n - 1);
+            const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
+            double sp[3];
+            se3_act(guess, pin, sp);
+            const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
+            int c = 0, E = 0;
+#pragma unroll
+            for (int jb = 0; jb < 27; jb += 3) {
+                unsigned long long key[3];
+                uint32_t hs[3];
+                bool ok[3];
+                Slot a[3][kProbeAhead];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int j = jb + u;
+                    const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
+                    ok[u] = voxel_in_range(qx, qy, qz);
+                    key[u] = pack_voxel(qx, qy, qz);
+                    hs[u] = hash_key(key[u], m.mask);
+#pragma unroll
+                    for (int i = 0; i < kProbeAhead; ++i) {
+                        a[u][i].key = kKeyEmpty;
+                        a[u][i].block = -1;
+                        a[u][i].count = 0;
+                        if (ok[u]) a[u][i] = load_slot(m.slots + ((hs[u] + i) & m.mask));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    int blk, cnt;
+                    if (!probe_resolve(a[u], key[u], blk, cnt)) probe_tail(m, (hs[u] + kProbeAhead) & m.mask, key[u], blk, cnt);
+                    if (blk < 0) cnt = 0;
+                    E += cnt;
+                    if (jb + u == 0) c = cnt;  // the point's own voxel (shift 0 of the table)
+                }
+            }
+            const int dense = (dense_div > 0 ? max(0, E - dense_min) / dense_div : 0) * P.weight_long_emul;
+            const int w = w_base + c + (quad > 0 ? (c * c) / quad : 0) + dense;
+            granule_store(P.wts + q, epoch_base, (unsigned)w);
+            my_sum += w;
+        }
+    }
+    // (short runs) one 32-lane group per point: lane j looks up the j-th voxel of the point's 27-neighbourhood (all in flight together)
+    for (int q = s0 + tid / kIcpGroup; !long_runs && q < s1; q += kIcpGroupsPerBlock) {
         // (The clamp never changes a value -- checked on the device: every key read here has index < n -- yet without it
         // this loop raised a memory fault (ROCm 7.2, gfx950): the point load evidently also executes, at some index
         // made of a stale key, for lanes the loop condition excludes.  With the clamp any such load stays inside the cloud.)
@@ -737,7 +784,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         const int slots = WIDE ? (n_local > 192 ? 2 * kIcpTileSlots : kIcpTileSlots) : (n_local <= kIcpListRunMax ? kIcpTileSlots / 2 : kIcpTileSlots);
         tile.slots_mask = slots - 1;
         tile.hash_shift = slots == 2 * kIcpTileSlots ? 19 : (slots == kIcpTileSlots ? 20 : 21);
-        tile.load_limit = WIDE ? (slots * 5) / 8 : (slots * 3) / 4;
+        tile.load_limit = WIDE ? (slots * P.wide_load_eighths) / 8 : (slots * 3) / 4;
         tile.keys = reinterpret_cast<unsigned *>(q);
         tile.vals = tile.keys + slots;
         q += (size_t)2 * slots * sizeof(unsigned);
@@ -1003,9 +1050,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (it == 0 && base == 0 && P.bulk_fill) {
                         int rerr = 0;
                         const bool mine = active && wq.flag == 1;
+                        if (tid == 0) sh.bulk_ticks[7] = 0u;  // (set by a query the workgroup-wide phase leaves unsettled)
                         int r = wide_fill_bulk(m, tile, &sh, 0, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF, P.wide_prefill);
                         bulk_done = r == 1;
-                        if (bulk_done && mine) wq.flag = meta->valid > 0 ? 0 : 2;
+                        if (bulk_done && mine) wq.flag = meta->valid > 0 ? 0 : (meta->valid == 0 ? 1 : 2);
                         if (r == 2) {
                             // more distinct cells than the scratch holds (sparse surroundings: nobody shares a cell): 128 queries at a
                             // time, whose windows have 8192 cells at most
@@ -1015,13 +1063,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                                 const bool part = mine && tid >= lo && tid < hi;
                                 r = wide_fill_bulk(m, tile, &sh, lo, hi, wmetas, part, wq.s, wq.v, &rerr, false, P.wide_prefill);
                                 if (r == 1) {
-                                    if (part) wq.flag = meta->valid > 0 ? 0 : 2;
+                                    if (part) wq.flag = meta->valid > 0 ? 0 : (meta->valid == 0 ? 1 : 2);
                                 } else {
                                     bulk_done = false;  // (the rest one by one, below)
                                 }
                             }
                         }
                         if (rerr) range_err = 1;
+                        if (sh.bulk_ticks[7]) bulk_done = false;  // (a barrier has passed since it was written; some windows are left: one by one, below)
                     }
                     if (!bulk_done) serve(1, &sh.next_point);
                     if (tid == 0) sh.any_fill = 0;  // (barriers inside both routes: everybody has read it)
@@ -1189,7 +1238,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         prof_map_items += n_m;
                         ++prof_rounds;
                     }
-                    if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane, it > 0 || P.wide_prefill > 0);
+                    if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane, it >= P.wide_promote_from);
                     if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false);
                     __syncthreads();
                     const unsigned tr2 = PROF ? ticks32() : 0u;

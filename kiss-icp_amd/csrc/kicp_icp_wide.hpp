@@ -167,7 +167,7 @@ constexpr int kWideItems = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + s
 // Two queues in that memory: voxels in the LDS store (a trip of the serving loop is an LDS round trip) and voxels in the
 // map (a trip is an HBM / L2 round trip) -- mixed, every trip of every group waited for a map voxel
 // (17 us per round of 486 items, profiles/r04_f_icp_probe_livox.txt).
-constexpr int kWideItemsLds = 160, kWideItemsMap = kWideItems - kWideItemsLds;
+constexpr int kWideItemsLds = 120, kWideItemsMap = kWideItems - kWideItemsLds;
 // what a thread walks itself before it leaves the rest of its voxels to the queue (the first voxel is always walked)
 constexpr int kWideWalkVoxels = 4, kWideWalkPoints = 24;
 
@@ -589,7 +589,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
             }
             si = (si + 1u) & set_mask;
         }
-        if (!done) metas[qt].valid = -1;  // (a set this crowded: the query looks the map up itself, one by one)
+        if (!done) metas[qt].list_state = 3;  // (a set this crowded: this query's window is established on its own afterwards)
     });
     __syncthreads();
     // the members: near cells from the bottom of the list, the others from its top (one LDS atomic per wave and class)
@@ -849,9 +849,10 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
         });
         __syncthreads();
     }
-    if (mine) {
+    if (mine) {  // 1: the window is in the tile; -1: it cannot be; 0: not settled here (the caller establishes it on its own)
         WideMeta *meta = metas + tid;
-        meta->valid = meta->valid != -1 ? 1 : -1;
+        meta->valid = meta->valid == -1 ? -1 : (meta->list_state == 3 ? 0 : 1);
+        if (meta->valid == 0) sh.bulk_ticks[7] = 1u;
         meta->list_state = 0;
     }
     if (range_err) *range_err_out = 1;

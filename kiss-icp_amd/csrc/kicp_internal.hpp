@@ -221,6 +221,8 @@ struct IcpParams {
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
+    int wide_promote_from; // thread-per-query form: first iteration whose map reads leave their voxels in the LDS store
+    int wide_load_eighths; // thread-per-query form: the tile's table is at most this many eighths full
     int wide_per_round;    // thread-per-query form: items a thread files per round and queue
     int wide_prefill;      // thread-per-query form: eighths of the LDS store the window phase fills with points (0: the table only; the
                            // store is then filled by the searches themselves, from the second iteration on)
@@ -258,6 +260,8 @@ struct Options {
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
+    long icp_wide_promote_from = 1;
+    long icp_wide_load_eighths = 5;
     long icp_wide_per_round = 4; // thread-per-query form: items a thread files per round and queue (1 .. 27)
     long icp_wide_prefill = 0;   // thread-per-query form: eighths of the LDS store filled by the window phase (0 .. 8)
     long icp_wide_prune = 2;     // thread-per-query form: 0 visit every occupied voxel, 1 skip by box distance, 2 + bound from the last neighbour
