@@ -1051,22 +1051,29 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         int rerr = 0;
                         const bool mine = active && wq.flag == 1;
                         if (tid == 0) sh.bulk_ticks[7] = 0u;  // (set by a query the workgroup-wide phase leaves unsettled)
-                        int r = wide_fill_bulk(m, tile, &sh, 0, cn, wmetas, mine, wq.s, wq.v, &rerr, PROF, P.wide_prefill);
-                        bulk_done = r == 1;
-                        if (bulk_done && mine) wq.flag = meta->valid > 0 ? 0 : (meta->valid == 0 ? 1 : 2);
-                        if (r == 2) {
-                            // more distinct cells than the scratch holds (sparse surroundings: nobody shares a cell): 128 queries at a
-                            // time, whose windows have 8192 cells at most
-                            bulk_done = true;
-                            for (int lo = 0; lo < cn; lo += 128) {
-                                const int hi = min(cn, lo + 128);
-                                const bool part = mine && tid >= lo && tid < hi;
-                                r = wide_fill_bulk(m, tile, &sh, lo, hi, wmetas, part, wq.s, wq.v, &rerr, false, P.wide_prefill);
-                                if (r == 1) {
-                                    if (part) wq.flag = meta->valid > 0 ? 0 : (meta->valid == 0 ? 1 : 2);
-                                } else {
-                                    bulk_done = false;  // (the rest one by one, below)
+                        // 256 queries at a time (their windows have 16384 cell instances at most, a few thousand distinct cells:
+                        // what the scratch beside an 8192-slot table holds); a batch with more distinct cells than the member
+                        // list holds (sparse surroundings: nobody shares a cell) comes again in halves
+                        bulk_done = true;
+                        for (int lo = 0; lo < cn; lo += 256) {
+                            const int hi = min(cn, lo + 256);
+                            const bool part = mine && tid >= lo && tid < hi;
+                            int r = wide_fill_bulk(m, tile, &sh, lo, hi, wmetas, part, wq.s, wq.v, &rerr, PROF && lo == 0, P.wide_prefill);
+                            if (r == 1) {
+                                if (part) wq.flag = meta->valid > 0 ? 0 : (meta->valid == 0 ? 1 : 2);
+                            } else if (r == 2) {
+                                for (int l2 = lo; l2 < hi; l2 += 128) {
+                                    const int h2 = min(hi, l2 + 128);
+                                    const bool part2 = mine && tid >= l2 && tid < h2;
+                                    r = wide_fill_bulk(m, tile, &sh, l2, h2, wmetas, part2, wq.s, wq.v, &rerr, false, P.wide_prefill);
+                                    if (r == 1) {
+                                        if (part2) wq.flag = meta->valid > 0 ? 0 : (meta->valid == 0 ? 1 : 2);
+                                    } else {
+                                        bulk_done = false;  // (the rest one by one, below)
+                                    }
                                 }
+                            } else {
+                                bulk_done = false;
                             }
                         }
                         if (rerr) range_err = 1;
@@ -1179,7 +1186,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const unsigned t_scan = PROF ? ticks32() - tb0 : 0u;
                 int prof_items = 0, prof_map_items = 0, prof_rounds = 0, prof_direct = 0;
                 unsigned prof_file = 0, prof_serve = 0, prof_merge = 0, prof_c = 0;
-                const int kPerRound = P.wide_per_round;  // items a thread files per round and queue: the nearest first, the rest is held against what they bring back
+                // items a thread files per round and queue: the nearest first, the rest is held against what they bring back -- all at
+                // once when only the few compacted searches are filing (everything fits one round)
+                const int kPerRound = compact ? 27 : P.wide_per_round;
+                const int cap_l = (it == 0 && P.wide_prefill == 0) ? 0 : kWideItemsLds, cap_m = kWideItems - cap_l;  // (nothing is in the store yet: the whole queue for the map)
                 auto file_items = [&](unsigned &pend, int *counter, int cap, WideItem *dst, int &base, int &n_filed) {
                     const int n_want = min(__popc(pend), kPerRound);
                     base = 0;
@@ -1226,24 +1236,24 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         }
                     }
                     int base_l, nf_l, base_m, nf_m;
-                    file_items(pend_lds, &sh.job_count, kWideItemsLds, items, base_l, nf_l);
-                    file_items(pend_map, &sh.bulk_failed, kWideItemsMap, items + kWideItemsLds, base_m, nf_m);
+                    file_items(pend_lds, &sh.job_count, cap_l, items, base_l, nf_l);
+                    file_items(pend_map, &sh.bulk_failed, cap_m, items + cap_l, base_m, nf_m);
                     __syncthreads();
                     const unsigned tr1 = PROF ? ticks32() : 0u;
                     if (PROF) prof_file += tr1 - tr0;
-                    const int n_l = min(sh.job_count, kWideItemsLds), n_m = min(sh.bulk_failed, kWideItemsMap);  // (the whole workgroup)
+                    const int n_l = min(sh.job_count, cap_l), n_m = min(sh.bulk_failed, cap_m);  // (the whole workgroup)
                     if (n_l + n_m == 0) break;
                     if (PROF) {
                         prof_items += n_l + n_m;
                         prof_map_items += n_m;
                         ++prof_rounds;
                     }
-                    if (n_m) wide_serve_items<false>(m, tile, items + kWideItemsLds, n_m, grp, lane, it >= P.wide_promote_from);
+                    if (n_m) wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from);
                     if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false);
                     __syncthreads();
                     const unsigned tr2 = PROF ? ticks32() : 0u;
                     merge_items(items, base_l, nf_l);
-                    merge_items(items + kWideItemsLds, base_m, nf_m);
+                    merge_items(items + cap_l, base_m, nf_m);
                     if ((pend_lds | pend_map) != 0u && P.wide_prune > 0) {  // what is left, against what the answers have brought
                         wb.limit = wb.best < wb.limit ? wb.best : wb.limit;
                         const unsigned keep = wide_keep_mask(wide_gaps(job.s, job.v, m.voxel_size), wb.limit);
