@@ -1138,7 +1138,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                     __syncthreads();
                 }
-                bool searching = compact ? tid < n_full : need_full;  // this lane runs a full search, for the query `job`
+                // (compacted: record r goes to lane r % 16 of wave r / 16 -- the first four waves sit on different SIMDs, and a
+                // search's data-dependent loops end with the slowest of 16 lanes instead of 64)
+                const int my_rec = (tid >> 6) * 16 + (tid & 63);
+                const bool rec_worker = compact && (tid & 63) < 16 && my_rec < n_full;
+                bool searching = compact ? rec_worker : need_full;  // this lane runs a full search, for the query `job`
                 WideJob job;
                 job.s[0] = wq.s[0];
                 job.s[1] = wq.s[1];
@@ -1152,8 +1156,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 job.d2 = DBL_MAX;
                 job.Lr = 0.0;
                 job.bkey = 0x7FFFFFFF;
-                if (compact && searching) {
-                    const WideRec &r = recs[tid];
+                if (rec_worker) {
+                    const WideRec &r = recs[my_rec];
                     job.s[0] = r.s[0];
                     job.s[1] = r.s[1];
                     job.s[2] = r.s[2];
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 };
                 for (int round = 0;; ++round) {
                     const unsigned tr0 = PROF ? ticks32() : 0u;
-                    if (round > 0 && pend_map) {  // a voxel may have been promoted into the store since this query classified it
+                    if (round > 0 && pend_map && it >= P.wide_promote_from) {  // a voxel may have been promoted into the store since this query classified it
                         unsigned todo = pend_map;
                         while (todo) {
                             const int jj = __ffs(todo) - 1;
@@ -1248,8 +1252,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         prof_map_items += n_m;
                         ++prof_rounds;
                     }
-                    if (n_m) wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from);
-                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false);
+                    if (n_m) wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from, it > 0);
+                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false, it > 0);
                     __syncthreads();
                     const unsigned tr2 = PROF ? ticks32() : 0u;
                     merge_items(items, base_l, nf_l);
@@ -1271,8 +1275,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 if (searching) wide_finish(m, job, wb);
                 bool got = false;  // this thread's query has had its full search
                 if (compact) {
-                    if (tid < n_full) {
-                        WideRec &r = recs[tid];
+                    if (rec_worker) {
+                        WideRec &r = recs[my_rec];
                         r.s[0] = wb.bx;
                         r.s[1] = wb.by;
                         r.s[2] = wb.bz;

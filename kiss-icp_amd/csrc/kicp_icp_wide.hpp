@@ -376,7 +376,9 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
 // the voxel -- the smaller index among equals, std::min_element's first minimum (VoxelHashMap.cpp:58-61) -- goes back
 // into the item
 template <bool LDS>
-__device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane, bool promote) {
+// runner_up: also find the voxel's second smallest distance (the stability test's margin); without it the item reports the
+// smallest again, i.e. no margin -- right for the first iteration, after which nearly every query is searched again anyway.
+__device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &tile, WideItem *items, int n_items, int grp, int lane, bool promote, bool runner_up) {
     constexpr int kFly = LDS ? kChunk : 6;  // voxels of a group in flight (map voxels: twelve -- a trip is an HBM / L2 round trip)
     for (int e0 = grp; __ballot(e0 < n_items) != 0ull; e0 += kIcpGroupsPerBlock * kFly) {  // wave-uniform trip count
         double2 xy[kFly];
@@ -439,12 +441,15 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
             double gd = d;
             int gk = ld[u] ? lane : 0x7FFFFFFF;
             group_min_dist_key(gd, gk);
-            double g2 = (ld[u] && gk != lane) ? d : DBL_MAX;  // the runner-up of the voxel
-            group_fmin_step<0>(g2);
-            group_fmin_step<1>(g2);
-            group_fmin_step<2>(g2);
-            group_fmin_step<3>(g2);
-            group_fmin_step<4>(g2);
+            double g2 = gd;
+            if (runner_up) {  // (the whole workgroup alike)
+                g2 = (ld[u] && gk != lane) ? d : DBL_MAX;
+                group_fmin_step<0>(g2);
+                group_fmin_step<1>(g2);
+                group_fmin_step<2>(g2);
+                group_fmin_step<3>(g2);
+                group_fmin_step<4>(g2);
+            }
             if (valid[u] && ld[u] && gk == lane) {
                 WideItem &it = items[e0 + kIcpGroupsPerBlock * u];
                 it.s[0] = xy[u].x;
