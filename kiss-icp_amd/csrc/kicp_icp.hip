@@ -1252,8 +1252,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         prof_map_items += n_m;
                         ++prof_rounds;
                     }
-                    if (n_m) wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from, it > 0);
-                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false, it > 0);
+                    // (the runner-up also in the first iteration: with its margin a good half of the queries need no search in the second)
+                    if (n_m) wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from, true);
+                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false, true);
                     __syncthreads();
                     const unsigned tr2 = PROF ? ticks32() : 0u;
                     merge_items(items, base_l, nf_l);
