@@ -468,6 +468,9 @@ struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter 
     int weight_base, weight_long_base, weight_long_emul, weight_quad, dense_min, dense_div;
     unsigned spin_limit;
 };
+// THREAD_PER_POINT: long runs are weighed by a thread per point (the thread-per-query form of the kernel; the group form
+// keeps its registers as they were)
+template <bool THREAD_PER_POINT>
 __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, SE3 guess, unsigned epoch_base, int n, int G) {
     IcpShared &sh = *shp;
     const int tid = threadIdx.x;
@@ -494,10 +497,10 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
     long long my_sum = 0;
     const int lane = tid & (kIcpGroup - 1);
-    // Long runs (hundreds of points per slice): a THREAD per point, its 27 lookups three at a time -- served 16 points at a
+    // Long runs (hundreds of points per slice): a THREAD per point, its 27 lookups nine at a time (the registers are there: the kernel's allocation is the iterations') -- served 16 points at a
     // time by the groups below, 420 points were 26 dependent rounds of lookups, ~100 us of every launch of the 1M-point
     // configuration (profiles/r04_r_icp_probe_livox100.txt).  Same c, same E, same weight.
-    if (long_runs) {
+    if (THREAD_PER_POINT && long_runs) {
         for (int q = s0 + tid; q < s1; q += kIcpThreads) {
             const int p = min((int)(P.order[q] & 0xFFFFFFull), n - 1);
             const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
@@ -506,13 +509,13 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
             const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
             int c = 0, E = 0;
 #pragma unroll
-            for (int jb = 0; jb < 27; jb += 3) {
-                unsigned long long key[3];
-                uint32_t hs[3];
-                bool ok[3];
-                Slot a[3][kProbeAhead];
+            for (int jb = 0; jb < 27; jb += 9) {
+                unsigned long long key[9];
+                uint32_t hs[9];
+                bool ok[9];
+                Slot a[9][kProbeAhead];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < 9; ++u) {
                     const int j = jb + u;
                     const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
                     ok[u] = voxel_in_range(qx, qy, qz);
@@ -527,7 +530,7 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < 9; ++u) {
                     int blk, cnt;
                     if (!probe_resolve(a[u], key[u], blk, cnt)) probe_tail(m, (hs[u] + kProbeAhead) & m.mask, key[u], blk, cnt);
                     if (blk < 0) cnt = 0;
@@ -542,7 +545,7 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
         }
     }
     // (short runs) one 32-lane group per point: lane j looks up the j-th voxel of the point's 27-neighbourhood (all in flight together)
-    for (int q = s0 + tid / kIcpGroup; !long_runs && q < s1; q += kIcpGroupsPerBlock) {
+    for (int q = s0 + tid / kIcpGroup; !(THREAD_PER_POINT && long_runs) && q < s1; q += kIcpGroupsPerBlock) {
         // (The clamp never changes a value -- checked on the device: every key read here has index < n -- yet without it
         // this loop raised a memory fault (ROCm 7.2, gfx950): the point load evidently also executes, at some index
         // made of a stale key, for lanes the loop condition excludes.  With the clamp any such load stays inside the cloud.)
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         R.dense_min = P.weight_dense_min;
         R.dense_div = P.weight_dense_div;
         R.spin_limit = P.spin_limit;
-        if (!icp_weighted_run(R, &sh, guess, epoch_base, n, G)) {
+        if (!icp_weighted_run<WIDE>(R, &sh, guess, epoch_base, n, G)) {
             if (tid == 0) {
                 atomicOr(&st->err, E_TIMEOUT);
                 if (blockIdx.x == 0) st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
