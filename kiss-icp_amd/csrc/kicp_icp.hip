@@ -1196,7 +1196,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 // items a thread files per round and queue: the nearest first, the rest is held against what they bring back -- all at
                 // once when only the few compacted searches are filing (everything fits one round)
                 const int kPerRound = compact ? 27 : P.wide_per_round;
-                const int cap_l = (it == 0 && P.wide_prefill == 0) ? 0 : kWideItemsLds, cap_m = kWideItems - cap_l;  // (nothing is in the store yet: the whole queue for the map)
                 auto file_items = [&](unsigned &pend, int *counter, int cap, WideItem *dst, int &base, int &n_filed) {
                     const int n_want = min(__popc(pend), kPerRound);
                     base = 0;
@@ -1231,6 +1230,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 };
                 for (int round = 0;; ++round) {
                     const unsigned tr0 = PROF ? ticks32() : 0u;
+                    // (while the store is empty -- the first iteration, as a rule -- the whole queue is the map's.  The store only
+                    // changes between barriers of this loop and in the window phases: every thread reads the same value here.)
+                    const int cap_l = __hip_atomic_load(tile.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 ? 0 : kWideItemsLds, cap_m = kWideItems - cap_l;
                     if (round > 0 && pend_map && it >= P.wide_promote_from) {  // a voxel may have been promoted into the store since this query classified it
                         unsigned todo = pend_map;
                         while (todo) {
