@@ -340,6 +340,12 @@ def main():
             "icp_workgroups": pipe.icp_profile()["workgroups"],
         },
         "ms_per_icp_iter": icp["total_ms"] / max(1, icp["iterations"]),
+        # how many ranks the pose exchange of this run really spanned, and through what: a driver can tell from the line alone
+        # whether RCCL saw N ranks (backend "nccl" IS RCCL on ROCm), a plumbing backend did, or there was nothing to exchange
+        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+        "exchange": {"ranks": world, "backend": args.backend if world > 1 else None,
+                     "collective": "all_gather of the new poses, once per batch of frames" if world > 1 else None,
+                     "launcher": "torch.distributed.run, one rank per GPU" if "WORLD_SIZE" in os.environ else "single process"},
         # what the host side of the K timed calls did (kicp_pipeline_host_stats): waits must be zero in steady state
         "host_side": host_side,
         "scan_generation_s": t_gen,

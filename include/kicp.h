@@ -66,6 +66,10 @@ typedef struct kicp_map kicp_map;
 int kicp_map_create(double voxel_size, double max_distance, unsigned max_points_per_voxel,
                     int device_id, kicp_map **out);
 int kicp_map_destroy(kicp_map *map);
+/* the implicit copy constructor of the reference's VoxelHashMap (a struct of scalars and a tsl::robin_map: copyable,
+ * VoxelHashMap.hpp:38-57): a second map with the same voxels, points and parameters on the same device, from then on
+ * independent of `src` (also when `src` is the map a pipeline owns).  Waits for the work queued on `src`. */
+int kicp_map_clone(const kicp_map *src, kicp_map **out);
 int kicp_map_clear(kicp_map *map);                          /* Clear()   VoxelHashMap.hpp:44 */
 int kicp_map_empty(const kicp_map *map, int *empty);        /* Empty()   VoxelHashMap.hpp:45 */
 int kicp_map_size(const kicp_map *map, size_t *n_voxels, size_t *n_points);
@@ -413,6 +417,15 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_wide_prune"  thread-per-point form: 0 = visit every occupied voxel of the 27; 1 = skip voxels whose box lies farther
  *                     than the best candidate / the correspondence threshold; 2 (default) = also bounded by the previous
  *                     iteration's neighbour.  Exact: skipped voxels lose every comparison of VoxelHashMap.cpp:58-63 anyway.
+ *   "icp_wide_stable"  thread-per-point form: 1 (default) = a source point that has stayed in its voxel and whose last neighbour is
+ *                     still provably closer than any other map point (a bound kept from its last search, minus how far the
+ *                     point has moved) keeps that neighbour without a search, and the searches that remain run on a few lanes;
+ *                     0 = every point is searched in every iteration.  Exact either way (kicp_icp_wide.hpp, WideQuery::Lr).
+ *   "icp_wide_prefill"  thread-per-point form: eighths (0 .. 8, default 0) of the workgroup's LDS point store that the first
+ *                     iteration's window phase fills; the rest is filled by the searches with the voxels they really read
+ *   "icp_wide_promote_from"  ... from this iteration on (default 1: the first iteration's reads are the widest, not the lasting ones)
+ *   "icp_wide_per_round"  ... items a thread files per round of the voxel queue (default 4; the rest is held against the answers)
+ *   "icp_wide_load_eighths"  ... eighths of the workgroup's voxel table that may fill (2 .. 7, default 5)
  *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if
  *                     their workgroups never became co-resident (exercises the replay path)
  *   "icp_inject_timeout_skip"  ... after leaving its first M registrations alone

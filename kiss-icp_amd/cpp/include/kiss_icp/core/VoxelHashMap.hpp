@@ -19,8 +19,11 @@ struct VoxelHashMap {
     explicit VoxelHashMap(double voxel_size, double max_distance, unsigned int max_points_per_voxel);
     VoxelHashMap(double voxel_size, double max_distance, unsigned int max_points_per_voxel, int device_id);
     ~VoxelHashMap();
-    VoxelHashMap(const VoxelHashMap &) = delete;  // one owner per device map
-    VoxelHashMap &operator=(const VoxelHashMap &) = delete;
+    // value semantics as in the reference (its VoxelHashMap is implicitly copyable, VoxelHashMap.hpp:38-57): a copy is a
+    // second, independent device map with the same content (kicp_map_clone) -- also a copy of the view that
+    // pipeline::KissICP::VoxelMap() returns, which is how a caller snapshots a running pipeline's local map
+    VoxelHashMap(const VoxelHashMap &other);
+    VoxelHashMap &operator=(const VoxelHashMap &other);
     VoxelHashMap(VoxelHashMap &&other) noexcept;
 
     void Clear();

@@ -22,8 +22,9 @@ inline Voxel PointToVoxel(const Eigen::Vector3d &point, const double voxel_size)
                  static_cast<int>(std::floor(point.z() / voxel_size)));
 }
 
-/// Voxelize a point cloud keeping the original coordinates (first point of every voxel; output in
-/// ascending input order -- the reference's order is its hash map's bucket order, unspecified)
+/// Voxelize a point cloud keeping the original coordinates: the first point of every voxel, emitted in the REFERENCE's
+/// order -- the bucket order of the tsl::robin_map it collects them in (VoxelUtils.cpp:7-21; option "downsample_order"
+/// = 0 gives ascending input order instead)
 /// A view of N packed points (N x 3 float64, row-major): what a numpy array, a DLPack tensor or a
 /// std::vector<Eigen::Vector3d> all are.  Every entry that takes a point vector also takes a span, so callers
 /// holding their points in another container reach the device without building a vector first (not in the

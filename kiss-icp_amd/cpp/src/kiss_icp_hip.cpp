@@ -78,6 +78,24 @@ VoxelHashMap::VoxelHashMap(VoxelHashMap &&o) noexcept
     o.handle_ = nullptr;
 }
 
+VoxelHashMap::VoxelHashMap(const VoxelHashMap &o)
+    : voxel_size_(o.voxel_size_), max_distance_(o.max_distance_), max_points_per_voxel_(o.max_points_per_voxel_) {
+    if (o.handle_) check(kicp_map_clone(o.handle_, &handle_), "VoxelHashMap(const VoxelHashMap &)");
+}
+
+VoxelHashMap &VoxelHashMap::operator=(const VoxelHashMap &o) {
+    if (this == &o) return *this;
+    kicp_map *fresh = nullptr;
+    if (o.handle_) check(kicp_map_clone(o.handle_, &fresh), "VoxelHashMap::operator=");
+    if (handle_ && owned_) kicp_map_destroy(handle_);
+    handle_ = fresh;
+    owned_ = true;
+    voxel_size_ = o.voxel_size_;
+    max_distance_ = o.max_distance_;
+    max_points_per_voxel_ = o.max_points_per_voxel_;
+    return *this;
+}
+
 VoxelHashMap::~VoxelHashMap() {
     if (handle_ && owned_) kicp_map_destroy(handle_);
 }

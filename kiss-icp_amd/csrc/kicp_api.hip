@@ -564,6 +564,46 @@ int kicp_map_destroy(kicp_map *m) {
     return KICP_OK;
 }
 
+int kicp_map_clone(const kicp_map *csrc, kicp_map **out) {
+    kicp_map *src = const_cast<kicp_map *>(csrc);
+    if (!src || !out) return KICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    KICP_HIP(hipSetDevice(src->device));
+    KICP_HIP(hipStreamSynchronize(src->stream));  // everything queued on the source has happened
+    kicp_map *m = nullptr;
+    KICP_TRY(map_create_on_stream(src->voxel_size, src->max_distance, src->max_points, src->device, nullptr, &m));
+    int s = KICP_OK;
+    auto copy = [&](DevBuf &dst, const DevBuf &from) {
+        if (s != KICP_OK || !from.p) return;
+        dst.release();
+        s = dst.reserve(from.bytes);
+        if (s == KICP_OK && hipMemcpyAsync(dst.p, from.p, from.bytes, hipMemcpyDeviceToDevice, m->stream) != hipSuccess) {
+            set_error("kicp_map_clone: device copy failed");
+            s = KICP_ERR_HIP;
+        }
+    };
+    copy(m->slots, src->slots);
+    copy(m->heads, src->heads);
+    copy(m->blocks, src->blocks);
+    copy(m->free_ids, src->free_ids);
+    copy(m->ctr, src->ctr);
+    if (s == KICP_OK && hipStreamSynchronize(m->stream) != hipSuccess) s = KICP_ERR_HIP;
+    if (s != KICP_OK) {
+        kicp_map_destroy(m);
+        return s;
+    }
+    m->stride = src->stride;
+    m->slot_cap = src->slot_cap;
+    m->blocks_cap = src->blocks_cap;
+    m->used_ub = src->used_ub;
+    m->bump_ub = src->bump_ub;
+    m->live_ub = src->live_ub;
+    memcpy(m->h_ctr, src->h_ctr, sizeof m->h_ctr);
+    m->insert_seq = src->insert_seq;
+    *out = m;
+    return KICP_OK;
+}
+
 int kicp_map_clear(kicp_map *m) {
     if (!m) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(m->device));
@@ -2405,7 +2445,7 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "staging_zero_copy")) {
         options().staging_zero_copy = value;
     } else if (!strcmp(name, "icp_weight_base")) {
-        if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (the prefix sums are 32-bit)
+        if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (a weight is a 32-bit granule; the prefix sums are 64-bit)
         options().icp_weight_base = value;
     } else if (!strcmp(name, "icp_weight_long_base")) {
         if (value < 1 || value > 4096) return KICP_ERR_INVALID_ARG;

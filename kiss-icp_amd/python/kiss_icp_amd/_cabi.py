@@ -81,6 +81,7 @@ SIGNATURES = {
     "kicp_set_option": [C.c_char_p, C.c_long],
     "kicp_map_create": [_d, _d, C.c_uint, _i, C.POINTER(_vp)],
     "kicp_map_destroy": [_vp],
+    "kicp_map_clone": [_vp, C.POINTER(_vp)],
     "kicp_map_clear": [_vp],
     "kicp_map_empty": [_vp, C.POINTER(_i)],
     "kicp_map_size": [_vp, _szp, _szp],

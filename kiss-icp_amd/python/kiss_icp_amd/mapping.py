@@ -33,6 +33,19 @@ class VoxelHashMap:
             _cabi.lib().kicp_map_destroy(self._internal_map)
             self._internal_map = None
 
+    def copy(self):
+        """an independent map with the same content (the reference's VoxelHashMap is a copyable value type)"""
+        h = C.c_void_p()
+        _cabi.check(_cabi.lib().kicp_map_clone(self._internal_map, C.byref(h)))
+        m = VoxelHashMap.__new__(VoxelHashMap)
+        m._owned, m._owner, m._internal_map = True, None, h
+        return m
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        return self.copy()
+
     def clear(self):
         _cabi.check(_cabi.lib().kicp_map_clear(self._internal_map))
 

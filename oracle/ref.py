@@ -74,8 +74,51 @@ def lib():
         L.kr_pipeline_output_size.argtypes = [vp, i]
         L.kr_pipeline_output.restype = sz
         L.kr_pipeline_output.argtypes = [vp, i, vp]
+        L.kr_build_mode.restype = C.c_char_p
+        L.kr_build_mode.argtypes = []
+        for name in ("kr_se3_exp", "kr_se3_log"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [vp, vp]
+        L.kr_se3_mul.restype = None
+        L.kr_se3_mul.argtypes = [vp, vp, vp]
+        L.kr_ldlt6_solve.restype = None
+        L.kr_ldlt6_solve.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
+
+
+def build_mode():
+    """"shim": Eigen / Sophus / tsl / TBB are oracle/ref_build/shim (their arithmetic is the oracle's restatement);
+    "thirdparty": the library was built against the real headers (make -C oracle/ref_build THIRDPARTY=...)"""
+    return lib().kr_build_mode().decode()
+
+
+def se3_exp(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    M = np.empty((4, 4))
+    lib().kr_se3_exp(a.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p))
+    return M
+
+
+def se3_log(M):
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    a = np.empty(6)
+    lib().kr_se3_log(M.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p))
+    return a
+
+
+def se3_mul(A, B):
+    A, B = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(B, dtype=np.float64)
+    M = np.empty((4, 4))
+    lib().kr_se3_mul(A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p))
+    return M
+
+
+def ldlt6_solve(A, b):
+    A, b = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    x = np.empty(6)
+    lib().kr_ldlt6_solve(A.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+    return x
 
 
 def _pts(a):

@@ -30,12 +30,27 @@ size_t from_cloud(const Cloud &c, double *out) {
     }
     return c.size();
 }
+#if KICP_REF_THIRDPARTY
+// built against the REAL Eigen / Sophus / tsl / oneTBB headers (make THIRDPARTY=...): nothing of the oracle is linked
+Sophus::SE3d to_se3(const double M[16]) {
+    Eigen::Matrix4d m;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) m(r, c) = M[4 * r + c];
+    return Sophus::SE3d(m);  // Sophus::SE3d(Matrix4d), as the pybind layer does (kiss_icp_pybind.cpp:68,84,99)
+}
+void from_se3(const Sophus::SE3d &T, double M[16]) {
+    const Eigen::Matrix4d m = T.matrix();
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) M[4 * r + c] = m(r, c);
+}
+#else
 Sophus::SE3d to_se3(const double M[16]) {
     ko_se3 T;
     ko_se3_from_matrix(M, &T);  // Sophus::SE3d(Matrix4d), as the pybind layer does (kiss_icp_pybind.cpp:68,84,99)
     return Sophus::SE3d(T);
 }
 void from_se3(const Sophus::SE3d &T, double M[16]) { ko_se3_matrix(&T.T, M); }
+#endif
 
 struct RefPipeline {
     kiss_icp::pipeline::KissICP odom;
@@ -45,6 +60,38 @@ struct RefPipeline {
 }  // namespace
 
 extern "C" {
+// which third-party code this library was built against: "shim" (oracle/ref_build/shim: Eigen's LDLT, Sophus' exp / log /
+// product and tsl::robin_map's bucket order are the oracle's restatements -- the reference's own code is pinned, the
+// libraries' arithmetic is not) or "thirdparty" (the real headers: everything is pinned)
+const char *kr_build_mode(void) {
+#if KICP_REF_THIRDPARTY
+    return "thirdparty";
+#else
+    return "shim";
+#endif
+}
+// the arithmetic the reference takes from its libraries, exposed so that the oracle's restatements can be held against
+// the real thing where the real headers are present (tests/test_ref_pins_oracle.py::test_third_party_arithmetic)
+void kr_se3_exp(const double a[6], double M[16]) {
+    Eigen::Matrix<double, 6, 1> x;
+    for (int i = 0; i < 6; ++i) x(i) = a[i];
+    from_se3(Sophus::SE3d::exp(x), M);
+}
+void kr_se3_log(const double M[16], double a[6]) {
+    const Eigen::Matrix<double, 6, 1> x = to_se3(M).log();
+    for (int i = 0; i < 6; ++i) a[i] = x(i);
+}
+void kr_se3_mul(const double A[16], const double B[16], double M[16]) { from_se3(to_se3(A) * to_se3(B), M); }
+void kr_ldlt6_solve(const double A[36], const double b[6], double x[6]) {
+    Eigen::Matrix<double, 6, 6> m;
+    Eigen::Matrix<double, 6, 1> r;
+    for (int i = 0; i < 6; ++i) {
+        r(i) = b[i];
+        for (int j = 0; j < 6; ++j) m(i, j) = A[6 * i + j];
+    }
+    const Eigen::Matrix<double, 6, 1> s = m.ldlt().solve(r);
+    for (int i = 0; i < 6; ++i) x[i] = s(i);
+}
 // ---- VoxelDownsample / Preprocess
 size_t kr_voxel_downsample(const double *xyz, size_t n, double voxel_size, double *out) {
     return from_cloud(kiss_icp::VoxelDownsample(to_cloud(xyz, n), voxel_size), out);

@@ -100,6 +100,27 @@ int main() {
         const auto [p1, d1] = map.GetClosestNeighbor(Eigen::Vector3d(500, 500, 500));
         CHECK(d1 == 1.7976931348623157e308 && p1[0] == 0.0);
     }
+    {
+        // value semantics (the reference's VoxelHashMap is copyable, VoxelHashMap.hpp:38-57): a snapshot is a second,
+        // independent map -- same content now, untouched by what happens to the original afterwards
+        kiss_icp::VoxelHashMap snapshot = map;
+        CHECK(snapshot.NumVoxels() == map.NumVoxels());
+        CHECK(snapshot.Pointcloud().size() == map.Pointcloud().size());
+        const Eigen::Vector3d probe(3.3, -2.1, 0.4);
+        const auto [pa, da] = map.GetClosestNeighbor(probe);
+        const auto [pb, db] = snapshot.GetClosestNeighbor(probe);
+        CHECK(da == db && pa[0] == pb[0] && pa[1] == pb[1] && pa[2] == pb[2]);
+        const std::size_t before = snapshot.NumVoxels();
+        kiss_icp::VoxelHashMap assigned(2.0, 50.0, 5);
+        assigned = map;  // copy assignment replaces parameters and content
+        CHECK(assigned.voxel_size_ == map.voxel_size_ && assigned.NumVoxels() == map.NumVoxels());
+        Points far;
+        for (int i = 0; i < 300; ++i) far.emplace_back(200.0 + uni(0, 20), uni(-5, 5), uni(0, 2));
+        snapshot.AddPoints(far);
+        CHECK(snapshot.NumVoxels() > before && map.NumVoxels() == before && assigned.NumVoxels() == before);
+        snapshot.Clear();
+        CHECK(snapshot.Empty() && !map.Empty());
+    }
 
     // ---- Registration::AlignPointsToMap ---------------------------------------------------------------
     {

@@ -186,6 +186,51 @@ def test_map_update_and_prune(gpu, O):
     assert g.empty() and len(g.point_cloud()) == 0
 
 
+def test_map_copy_is_an_independent_map(gpu, O):
+    """the reference's VoxelHashMap is a copyable value type (VoxelHashMap.hpp:38-57): kicp_map_clone / VoxelHashMap.copy()
+    give a second device map with the same voxels and points, which neither follows nor disturbs the original -- also
+    when the original is the local map a running pipeline owns"""
+    import copy
+
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.kiss_icp import KissICP
+
+    rng = np.random.default_rng(14)
+    g, o = _maps(O)
+    pts = random_cloud(rng, 20000, extent=30.0, z_extent=3.0)
+    g.add_points(pts)
+    o.add_points(pts)
+    c = g.copy()
+    assert c.num_voxels() == g.num_voxels() == o.num_voxels()
+    assert np.array_equal(sort_rows(c.point_cloud()), sort_rows(o.point_cloud()))
+    q = random_cloud(rng, 500, extent=32.0, z_extent=4.0)
+    (na, da), (nb, db) = g.closest_neighbor(q), c.closest_neighbor(q)
+    assert np.array_equal(na, nb) and np.array_equal(da, db)
+    more = random_cloud(rng, 5000, extent=30.0, z_extent=3.0) + np.array([80.0, 0.0, 0.0])
+    c.add_points(more)  # the copy grows (tables rehash, pools grow) ...
+    o2 = O.VoxelHashMap(1.0, 100.0, 20)
+    o2.add_points(pts)
+    o2.add_points(more)
+    assert c.num_voxels() == o2.num_voxels() > g.num_voxels() == o.num_voxels()  # ... the original does not
+    assert np.array_equal(sort_rows(c.point_cloud()), sort_rows(o2.point_cloud()))
+    g.clear()
+    assert g.empty() and not c.empty()
+    d = copy.deepcopy(c)
+    assert d.num_voxels() == c.num_voxels()
+    # a snapshot of a pipeline's local map, taken between two frames
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=4, n_frames=3, beams=32, azimuth_steps=512)
+    k = KissICP(load_config(deskew=False))
+    k.register_frame(*ds[0])
+    k.register_frame(*ds[1])
+    snap = k.local_map.copy()
+    n_then = snap.num_voxels()
+    assert n_then == k.local_map.num_voxels()
+    k.register_frame(*ds[2])
+    assert snap.num_voxels() == n_then
+
+
 def test_closest_neighbor_exact(gpu, O):
     rng = np.random.default_rng(14)
     g, o = _maps(O)

@@ -35,6 +35,44 @@ def O():
     return oracle
 
 
+def test_third_party_arithmetic(R, O, record_property, capsys):
+    """Eigen's pivoted LDLT (Registration.cpp:156), Sophus' exp / log / product (Registration.cpp:157,161,166,
+    Preprocessing.cpp:68,78, Threshold.cpp:40-42) as THE LIBRARY THE REFERENCE IS BUILT AGAINST computes them, against the
+    oracle's restatements, bit for bit.  What this proves depends on how oracle/_ref was built, and the test says so:
+    in "shim" mode the library's Eigen / Sophus ARE the oracle's restatements (the comparison is circular and only
+    checks the plumbing); built with `make -C oracle/ref_build THIRDPARTY=...` it is the pin DESIGN.md section 2 calls
+    open.  Independent anchors that need no third-party code: tests/test_thirdparty_anchors.py."""
+    mode = R.build_mode()
+    record_property("ref_build_mode", mode)
+    with capsys.disabled():
+        print("\n[oracle/_ref built in %r mode: third-party arithmetic %s]" % (
+            mode, "PINNED against the real headers" if mode == "thirdparty" else "NOT pinned (stand-in headers forward to the oracle)"))
+    assert mode in ("shim", "thirdparty")
+    rng = np.random.default_rng(17)
+    for scale in (1e-12, 9e-11, 1.1e-10, 1e-6, 1e-2, 1.0, 3.1):
+        for _ in range(25):
+            a = rng.normal(size=6)
+            a[3:] *= scale / np.linalg.norm(a[3:])
+            T = R.se3_exp(a)
+            assert np.array_equal(T, O.se3_exp(a)), (scale, a)
+            assert np.array_equal(R.se3_log(T), O.se3_log(T)), (scale, a)
+    for _ in range(50):
+        A = make_pose(rng.uniform(-50, 50, 3), rng.uniform(-3, 3, 3))
+        B = make_pose(rng.uniform(-50, 50, 3), rng.uniform(-3, 3, 3))
+        assert np.array_equal(R.se3_mul(A, B), O.se3_mul(A, B))
+    for k in range(200):
+        J = rng.normal(size=(40, 6)) * rng.uniform(0.1, 30, size=6)
+        A = J.T @ J
+        if k % 4 == 1:  # tied diagonal entries: which one is the pivot
+            A[2, 2] = A[4, 4] = max(A[2, 2], A[4, 4])
+        if k % 4 == 2:  # a rank-deficient system: zero pivots
+            A[:, 5] = A[5, :] = 0.0
+        if k % 4 == 3:  # tiny but nonzero pivots
+            A *= 1e-300
+        b = rng.normal(size=6)
+        assert np.array_equal(R.ldlt6_solve(A, b), O.ldlt6_solve(A, b)), k
+
+
 def test_voxel_downsample_same_points_same_order(R, O):
     rng = np.random.default_rng(1)
     for n, v in ((0, 0.5), (1, 0.5), (5000, 0.5), (40000, 1.5), (40000, 0.05)):
