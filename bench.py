@@ -376,6 +376,7 @@ def main():
                 k.register_frame_async(*f)
             k.sync()
             items = prepare() if prepare else host[W:W + K]
+            k.host_stats(reset=True)
             torch.cuda.synchronize()
             t = time.perf_counter()
             for it in items:
@@ -391,8 +392,13 @@ def main():
         frames = [(d.data_ptr(), d.shape[0], t.data_ptr() if t is not None else None, t.shape[0] if t is not None else 0)
                   for d, t in zip(dev_pts, dev_ts)]
         kd, rate_dev = drive(lambda k, f: k.register_frame_device(*f), lambda: frames)
+        hs_dev = kd.host_stats()
         out["device_resident"] = {"scans_per_s": rate_dev, "ms_per_frame": 1e3 / rate_dev, "icp_workgroups": kd.icp_profile()["workgroups"],
-                                  "same_trajectory_as_host_input": bool((kd.last_pose == local_poses[-1]).all())}
+                                  "same_trajectory_as_host_input": bool((kd.last_pose == local_poses[-1]).all()),
+                                  # where its time went: device time between registrations (mean / worst single gap), host-side waits
+                                  "device_gap_ms_per_frame": hs_dev["device_gap_ms"] / K, "max_device_gap_ms": hs_dev["max_device_gap_ms"],
+                                  "map_grows": hs_dev["map_grows"], "map_rehashes": hs_dev["map_rehashes"], "buffer_grows": hs_dev["buffer_grows"],
+                                  "counter_refreshes": hs_dev["counter_refreshes"], "wait_ms": hs_dev["wait_ms"]}
         del dev_pts, dev_ts
         # (b) the sensor's native float32 points in host memory (no widening, no narrowing)
         host32 = [(p.astype(np.float32), t) for p, t in host[W:W + K]]

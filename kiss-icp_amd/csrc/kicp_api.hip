@@ -1760,8 +1760,16 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     p->inject_skip = (int)options().icp_inject_timeout_skip;
     p->ds_order = options().downsample_order != 0 ? 1 : 0;
     int s = KICP_OK;
-    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking) != hipSuccess ||
+    // The two streams of a pipeline must sit on DIFFERENT hardware queues: the registration is one persistent launch, and a
+    // front-stage kernel queued behind it on the same queue waits for it to end.  The runtime hands streams of one priority
+    // to a few hardware queues in turn, so two streams of a pipeline could share one -- measured: whichever pipeline was
+    // created second in a process lost the overlap, +87 us between its registrations, 2140 instead of 2585 scans/s
+    // (profiles/r04_aa_bench_200_10.json, r04_ac_bench_swapped.json: it is the position, not the input path).  Streams of
+    // different priorities never share a queue: the registration's stream gets the higher one.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&p->prep_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_prep_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_prep_done[1], hipEventDisableTiming) != hipSuccess)
         s = KICP_ERR_HIP;
