@@ -424,6 +424,33 @@ def main():
         for f in host[W:W + K]:
             ko.register_frame(*f)  # returns (preprocessed frame, source) as numpy arrays
         rate_out = K / (time.perf_counter() - t)
+        # (d) batch mode folded onto this ONE GPU (BASELINE configs[3]; option "icp_device_streams"): S streams, each with
+        #     1 / S of the persistent registration grid, registering side by side; driven through the C-ABI's batch entry
+        #     (a worker thread per stream inside libkicp.so; a host communicator, since RCCL refuses two ranks on a device).
+        #     Every stream runs the same K frames.  The headline `value` stays the single stream's.
+        out["batch_on_one_gpu"] = {}
+        for S in (2, 4):
+            try:
+                comm = host_communicator(S, local_rank)
+                batch = multistream.StreamBatch(load_config(**cfg_over), [local_rank] * S, comm=comm)
+                for f in host[:W]:
+                    batch.register_frames([f[0]] * S, [f[1]] * S)
+                batch.sync()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for f in host[W:W + K]:
+                    batch.register_frames([f[0]] * S, [f[1]] * S)
+                batch.sync()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t
+                pb = [batch.poses(r)[-1] for r in range(S)]
+                out["batch_on_one_gpu"][f"streams{S}"] = {
+                    "aggregate_scans_per_s": S * K / dt, "per_stream_scans_per_s": K / dt, "vs_single_stream": S * K / dt / out["value"],
+                    "streams_agree": bool(all((q == pb[0]).all() for q in pb)),
+                    "note": "every stream registers with 1/%d of the workgroups: its poses are those of a lone pipeline with that share, not bitwise the headline's" % S}
+                batch.close()
+            except Exception as e:  # noqa: BLE001 -- a secondary measurement must not cost the line
+                out["batch_on_one_gpu"][f"streams{S}"] = {"error": repr(e)}
         out["sync_per_frame"] = {"scans_per_s": rate_sync, "ms_per_frame": 1e3 / rate_sync,
                                  "same_trajectory_as_host_input": bool((ks.last_pose == local_poses[-1]).all())}
         out["sync_with_outputs"] = {"scans_per_s": rate_out, "ms_per_frame": 1e3 / rate_out,

@@ -426,6 +426,12 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_wide_promote_from"  ... from this iteration on (default 1: the first iteration's reads are the widest, not the lasting ones)
  *   "icp_wide_per_round"  ... items a thread files per round of the voxel queue (default 4; the rest is held against the answers)
  *   "icp_wide_load_eighths"  ... eighths of the workgroup's voxel table that may fill (2 .. 7, default 5)
+ *   "icp_device_streams"  batch mode on ONE GPU (default 1): pipelines created afterwards share their device with this many
+ *                     streams in all -- each registers with 1 / n of the co-resident workgroups, and up to n registrations
+ *                     of different pipelines run side by side instead of one behind the other.  A single stream gets slower
+ *                     (fewer workgroups), the device as a whole faster; kicp_batch_create sets it by itself when a device
+ *                     appears more than once in its list.  A pipeline's trajectory depends on its share (the summation
+ *                     tree follows the number of workgroups), not on what runs beside it.
  *   "icp_inject_timeout"  test hook: the first N registrations of a pipeline created afterwards behave as if
  *                     their workgroups never became co-resident (exercises the replay path)
  *   "icp_inject_timeout_skip"  ... after leaving its first M registrations alone

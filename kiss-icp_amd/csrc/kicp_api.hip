@@ -113,14 +113,24 @@ static int err_bits_to_status(int bits) {
 
 // ---- the persistent ICP kernel and the device it shares -------------------------------------------
 // k_icp's workgroups exchange partial sums inside the launch, so all of them must be resident at the
-// same time.  Two things guarantee that: (1) the grid never exceeds what the device can hold
-// (occupancy query x CU count of THIS device or partition, at the launch's LDS size); (2) launches of
-// k_icp on one device are ordered behind each other across handles and streams -- two half-resident
-// grids would wait for each other until their bounded spins give up.
+// same time.  Two things guarantee that: (1) the grids that can be in flight together never exceed what the device can
+// hold (occupancy query x CU count of THIS device or partition, at the launch's LDS size, divided among the streams that
+// share the device: option "icp_device_streams"); (2) launches of k_icp on one device pass a gate of as many LANES as
+// there are shares.  A stream keeps its lane from launch to launch; a stream without one takes a free lane, or queues
+// behind the last launch of the lane it takes over (hipStreamWaitEvent) -- so at most `lanes` registrations run at
+// once, each with 1 / lanes of the grid, whatever the number of handles.  One share (the default): the launches of all
+// handles are ordered behind each other, each with the whole grid -- two half-resident grids would wait for each other
+// until their bounded spins give up.
+constexpr int kIcpMaxLanes = 8;
 struct IcpDeviceGate {
     std::mutex mu;
-    hipStream_t last_stream = nullptr;  // stream of the most recent k_icp launch on this device
-    hipEvent_t ev = nullptr;            // scratch event (a wait captures the record it was issued behind)
+    int lanes = 1;  // the largest share count a handle of this device was created with
+    struct Lane {
+        hipStream_t stream = nullptr;  // stream of the most recent k_icp launch through this lane
+        unsigned long stamp = 0;       // (least recently used lane is taken over first)
+    } lane[kIcpMaxLanes];
+    unsigned long clock = 0;
+    hipEvent_t ev = nullptr;  // scratch event (a wait captures the record it was issued behind)
     // co-resident workgroups per dynamic-LDS size of the launch (the occupancy query is per size: a cache keyed on
     // anything coarser would hand a grid sized for one LDS setting to a launch with another)
     struct Entry {
@@ -151,30 +161,47 @@ static int icp_max_blocks(int device_id, int lds_bytes) {
     g.max_blocks[free_slot].blocks = (int)(b < kIcpMaxBlocks ? b : kIcpMaxBlocks);
     return g.max_blocks[free_slot].blocks;
 }
-// launch k_icp on `s`, behind any k_icp another stream of this device still has in flight
+// a handle that shares its device with share - 1 others is being created
+static void icp_gate_declare_share(int device_id, int share) {
+    IcpDeviceGate &g = icp_gate(device_id);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (share > g.lanes) g.lanes = share < kIcpMaxLanes ? share : kIcpMaxLanes;
+}
+// launch k_icp on `s` through the device's gate
 static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s) {
     IcpDeviceGate &g = icp_gate(device_id);
     std::lock_guard<std::mutex> lk(g.mu);
-    if (g.last_stream && g.last_stream != s) {
-        if (!g.ev) KICP_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
-        KICP_HIP(hipEventRecord(g.ev, g.last_stream));
-        KICP_HIP(hipStreamWaitEvent(s, g.ev, 0));
+    int mine = -1, pick = 0;
+    for (int i = 0; i < g.lanes; ++i) {
+        if (g.lane[i].stream == s) mine = i;
+        if (g.lane[i].stream == nullptr && g.lane[pick].stream != nullptr) pick = i;
+        if (g.lane[i].stream != nullptr && g.lane[pick].stream != nullptr && g.lane[i].stamp < g.lane[pick].stamp) pick = i;
+    }
+    if (mine < 0) {
+        mine = pick;
+        if (g.lane[mine].stream) {  // behind whatever that lane's last launch (and the work queued after it) is
+            if (!g.ev) KICP_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+            KICP_HIP(hipEventRecord(g.ev, g.lane[mine].stream));
+            KICP_HIP(hipStreamWaitEvent(s, g.ev, 0));
+        }
     }
     launch_icp(P, grid, profile, P.use_wide != 0, s);
-    g.last_stream = s;
+    g.lane[mine].stream = s;
+    g.lane[mine].stamp = ++g.clock;
     return KICP_OK;
 }
 // a stream is about to be destroyed: nobody may record on it any more
 static void icp_forget_stream(int device_id, hipStream_t s) {
     IcpDeviceGate &g = icp_gate(device_id);
     std::lock_guard<std::mutex> lk(g.mu);
-    if (g.last_stream == s) g.last_stream = nullptr;
+    for (int i = 0; i < kIcpMaxLanes; ++i)
+        if (g.lane[i].stream == s) g.lane[i].stream = nullptr;
 }
 
 // The grid is launched at the device's co-resident maximum; the kernel itself picks how many of the
 // workgroups take part from the actual N_src (surplus workgroups exit at once).  `cap` > 0 lowers the
 // maximum (replay after a timeout).
-static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) {
+static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, int share = 1) {
     P.force_blocks = (int)options().icp_blocks;
     P.points_per_group = (int)(options().icp_points_per_group > 0 ? options().icp_points_per_group : 1);
     P.use_lds = options().icp_use_lds != 0;
@@ -190,6 +217,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap) 
     int grid = icp_max_blocks(device_id, P.lds_bytes);
     const int reserve = (int)options().icp_reserve_cus;
     if (grid > 4 * reserve) grid -= reserve;
+    if (share > 1) grid = grid / share > 0 ? grid / share : 1;  // this handle's part of the device (see the gate)
     if (cap > 0 && cap < grid) grid = cap;
     if (P.force_blocks > grid) P.force_blocks = grid;
     // Which form of the association: a 32-lane group per source point (few points per workgroup, neighbourhoods of
@@ -1208,6 +1236,7 @@ struct kicp_pipeline {
     size_t out_stage_bytes = 0;
     // registration replay (timeout): co-residency cap for the ICP grid, the last frame's inputs
     int icp_cap = 0;
+    int icp_share = 1;  // streams this device's persistent grid is divided among (option "icp_device_streams" when the pipeline was created)
     int inject_timeouts = 0;  // test hook ("icp_inject_timeout" option, read at create)
     int inject_skip = 0;      // ... after this many untouched registrations ("icp_inject_timeout_skip")
     FrameInput last_in;
@@ -1521,7 +1550,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // the source cloud is at most the scan; in practice ~1/60 of it (two voxel downsamples): the LDS policy
     // goes by the previous frame's count when there is one
     const size_t n_src_hint = p->have_last ? (size_t)p->last.st.n_src : n / 32;
-    const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap);
+    const int G = icp_fill_policy(p->device, I, n_src_hint, p->icp_cap, p->icp_share);
     I.frame = p->src[par].as<double>();
     I.order = sorted ? p->sort_out[par].as<unsigned long long>() : nullptr;
     if (sorted && n) {  // runs of equal weight, settled by the kernel's own prologue
@@ -1759,6 +1788,8 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     p->inject_timeouts = (int)options().icp_inject_timeout;
     p->inject_skip = (int)options().icp_inject_timeout_skip;
     p->ds_order = options().downsample_order != 0 ? 1 : 0;
+    p->icp_share = (int)(options().icp_device_streams > 1 ? options().icp_device_streams : 1);
+    icp_gate_declare_share(device_id, p->icp_share);
     int s = KICP_OK;
     // The two streams of a pipeline must sit on DIFFERENT hardware queues: the registration is one persistent launch, and a
     // front-stage kernel queued behind it on the same queue waits for it to end.  The runtime hands streams of one priority
@@ -1945,7 +1976,7 @@ static int pipe_sync_impl(kicp_pipeline *p) {
             // next time with half as many workgroups
             IcpParams probe;
             memset(&probe, 0, sizeof probe);
-            const int grid = icp_fill_policy(p->device, probe, p->have_last ? (size_t)p->last.st.n_src : 0, p->icp_cap);
+            const int grid = icp_fill_policy(p->device, probe, p->have_last ? (size_t)p->last.st.n_src : 0, p->icp_cap, p->icp_share);
             p->icp_cap = grid > 1 ? grid / 2 : 1;
             p->frames_enqueued -= (uint64_t)(queued - good);
             if (queued - good == 1 && p->last_in.valid && attempt < 3 && !(err_bits & ~E_TIMEOUT)) {
@@ -2415,6 +2446,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide")) {
         if (value < -1 || value > 1) return KICP_ERR_INVALID_ARG;
         options().icp_wide = value;
+    } else if (!strcmp(name, "icp_device_streams")) {
+        if (value < 1 || value > kIcpMaxLanes) return KICP_ERR_INVALID_ARG;
+        options().icp_device_streams = value;
     } else if (!strcmp(name, "icp_wide_promote_from")) {
         if (value < 0 || value > 1000) return KICP_ERR_INVALID_ARG;
         options().icp_wide_promote_from = value;

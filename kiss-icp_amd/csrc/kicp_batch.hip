@@ -258,11 +258,22 @@ int kicp_batch_create(const kicp_config *cfg, const int *devices, int n_local, i
     b->frames.resize(n_local);
     b->driver.reset(new kicp_mstream::Driver<HipPipe>(n_local, first_rank, n_total, frames_per_gather, table));
     const kicp_config c = *cfg;
+    // streams that share a GPU share its persistent registration grid: each pipeline is created with 1 / n of it, and
+    // the device's gate lets n registrations run side by side (option "icp_device_streams", kicp_api.hip)
+    int share = 1;
+    for (int i = 0; i < n_local; ++i) {
+        int same = 0;
+        for (int j = 0; j < n_local; ++j) same += devices[j] == devices[i];
+        share = same > share ? same : share;
+    }
+    const long share_before = options().icp_device_streams;
+    if (share > share_before) options().icp_device_streams = share < 8 ? share : 8;
     int rc = b->driver->start(devices, [&](int) {
         auto p = std::make_unique<HipPipe>();
         p->cfg = c;
         return p;
     });
+    options().icp_device_streams = share_before;  // (start() returns when every stream's pipeline exists)
     if (rc != KICP_OK) {
         set_error("%s", b->driver->last_error().c_str());
         delete b;

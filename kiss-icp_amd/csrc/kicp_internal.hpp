@@ -269,6 +269,8 @@ struct Options {
     long icp_timing = 1;
     long map_apply_threads = 512;  // workgroup size of k_map_apply (256 / 512 / 1024)
     long icp_lds_kib = 0;        // dynamic LDS per ICP workgroup in KiB (0: all 160)
+    long icp_device_streams = 1; // pipelines created from now on share their GPU with this many streams in all: each registers with 1 / n
+                                 // of the persistent grid, and up to n registrations run side by side (kicp_api.hip, the gate)
     long icp_reserve_cus = 32;   // CUs left out of the ICP grid (one per shader engine) for the front stages of the next frame
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless

@@ -719,10 +719,11 @@ def test_batch_entry_direct_rccl_single_rank(gpu, O):
 
 
 def test_batch_entry_two_streams_host_communicator(gpu, O):
-    """two streams on the one GPU (two worker threads inside the library, two pipelines, the persistent ICP
-    kernels serialised by the device gate) with a communicator supplied by the host through kicp_batch_comm --
-    the hook an MPI host would use; here it moves the blocks with the C-ABI's own device copies.  Each stream's
-    trajectory is bit for bit what it is alone; both ranks' blocks arrive in rank order."""
+    """two streams on the one GPU (two worker threads inside the library, two pipelines, each registering with half of
+    the persistent grid, side by side through the two lanes of the device's gate) with a communicator supplied by the
+    host through kicp_batch_comm -- the hook an MPI host would use; here it moves the blocks with the C-ABI's own device
+    copies.  Each stream's trajectory is bit for bit what a pipeline with the same share of the device computes alone;
+    both ranks' blocks arrive in rank order."""
     import ctypes as C
 
     from kiss_icp_amd import _cabi
@@ -757,12 +758,16 @@ def test_batch_entry_two_streams_host_communicator(gpu, O):
     comm = _cabi.BatchComm(None, _cabi.BatchComm.INIT(0), _cabi.BatchComm.ALL_GATHER(all_gather), _cabi.BatchComm.FINALIZE(0))
     seqs = [kitti_like(seed=21 + r, n_frames=8, beams=32, azimuth_steps=500) for r in range(n_ranks)]
     want = []
-    for r in range(n_ranks):
-        k = _pipe(deskew=False)
-        for i in range(8):
-            k.register_frame(seqs[r][i][0])
-        want.append(k.last_pose.copy())
-        del k
+    _cabi.set_option("icp_device_streams", 2)  # (the share a batch gives its pipelines when two of them are on one device)
+    try:
+        for r in range(n_ranks):
+            k = _pipe(deskew=False)
+            for i in range(8):
+                k.register_frame(seqs[r][i][0])
+            want.append(k.last_pose.copy())
+            del k
+    finally:
+        _cabi.set_option("icp_device_streams", 1)
     b = StreamBatch(load_config(deskew=False), [0, 0], comm=comm)
     traj = [[], []]
     for lo, hi in ((0, 3), (3, 8)):
@@ -774,8 +779,60 @@ def test_batch_entry_two_streams_host_communicator(gpu, O):
             traj[r].extend(b.poses(r))
     assert len(traj[0]) == 8 and len(traj[1]) == 8
     assert np.array_equal(traj[0][-1], want[0])
+    assert np.array_equal(traj[1][-1], want[1])
     assert sorted(calls) == [0, 0, 1, 1]
     b.close()
+
+
+@pytest.mark.parametrize("streams", [2, 4])
+def test_streams_sharing_one_gpu_register_side_by_side(gpu, O, streams):
+    """batch mode on ONE GPU (BASELINE configs[3] folded onto a device: option "icp_device_streams"): n pipelines, each
+    with 1 / n of the persistent grid, driven from n host threads with full-size scans so that their registrations
+    really overlap.  Every trajectory is bit for bit what the same pipeline computes when it runs alone with the same
+    share -- what runs beside a registration has no say in its result -- and within the usual tolerance of the oracle's."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like_vegetated
+
+    n_frames = 8
+    data = [[kitti_like_vegetated(seed=30 + s, n_frames=n_frames)[i][0] for i in range(n_frames)] for s in range(streams)]
+    _cabi.set_option("icp_device_streams", streams)
+    try:
+        alone = []
+        for scans in data:
+            k = _pipe(deskew=False)
+            for s in scans:
+                k.register_frame_async(s)
+            k.sync()
+            alone.append(k.synced_poses())
+            assert k.icp_profile()["workgroups"] <= 224 // streams
+            del k
+        pipes = [_pipe(deskew=False) for _ in range(streams)]
+        results, errors = [None] * streams, []
+
+        def drive(j):
+            try:
+                for s in data[j]:
+                    pipes[j].register_frame_async(s)
+                pipes[j].sync()
+                results[j] = pipes[j].synced_poses()
+            except Exception as e:  # noqa: BLE001
+                errors.append((j, repr(e)))
+
+        threads = [threading.Thread(target=drive, args=(j,)) for j in range(streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        _cabi.set_option("icp_device_streams", 1)
+    assert not errors, errors
+    for j in range(streams):
+        assert np.array_equal(results[j], alone[j]), j
+    ko = O.KissICP(deskew=0)
+    for s in data[0]:
+        ko.register_frame(s)
+    dt, dr = pose_error(ko.last_pose, results[0][-1])
+    assert dt < TIGHT and dr < TIGHT
 
 
 @pytest.mark.parametrize("cfg", [
