@@ -1557,14 +1557,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         tile_list_build(tile, vx, vy, vz, lane, meta);
                     if (meta->list_state == 1) {
                         E = meta->list_n;
-                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, second);
+                        d2 = use_stable ? tile_scan_list<true>(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, second)
+                                        : tile_scan_list<false>(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, second);
                         listed = true;
                         path = 1;
                     }
                 }
                 if (flag == 0 && !listed) {
                     int bad;
-                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, second);
+                    d2 = use_stable ? tile_scan<true>(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, second)
+                                    : tile_scan<false>(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, second);
                     if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is
                                 // being fetched by another group this very moment -> HBM this once
                         if (bad == 2 && lane == 0) meta->valid = -1;

@@ -631,7 +631,9 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 // Returns the squared distance (DBL_MAX: no candidate), the neighbour, the number of points examined;
 // bad = the tile cannot answer: 1 a voxel is still being fetched by a concurrent fill, 2 one did not fit.
 // second: the smallest squared distance of any candidate OTHER than the returned one (DBL_MAX: there is none) -- the margin
-// by which the neighbour won, which lets later iterations keep it without a search (kicp_icp.hip, IcpStable).
+// by which the neighbour won, which lets later iterations keep it without a search (kicp_icp.hip, IcpStable).  Tracked only
+// when RUNNER is set: it costs two selects and a compare per candidate, a fifth of the scan (profiles/r04_ah_group_stable_ab.txt).
+template <bool RUNNER>
 __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz,
                                             int lane, double nn[3], int &examined, int &bad, double &second) {
     constexpr int U = 4;
@@ -689,8 +691,10 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
                 const double d = (ex * ex + ey * ey) + ez * ez;
                 const bool valid = k0 + u < c;
                 const bool take = valid & (d < best);
-                const double loser = take ? best : d;  // whichever of the two is not the best any more / yet
-                sec = (valid & (loser < sec)) ? loser : sec;
+                if (RUNNER) {
+                    const double loser = take ? best : d;  // whichever of the two is not the best any more / yet
+                    sec = (valid & (loser < sec)) ? loser : sec;
+                }
                 best = take ? d : best;
                 bk = take ? k0 + u : bk;
             }
@@ -732,13 +736,13 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
                 const double d = (ex * ex + ey * ey) + ez * ez;
                 const int k = (kj[u] << 5) | lane;  // {shift position of the voxel, index inside it}
                 if (d < best || (d == best && k < key)) {
-                    sec = best < sec ? best : sec;
+                    if (RUNNER) sec = best < sec ? best : sec;
                     best = d;
                     key = k;
                     bx = xy[u].x;
                     by = xy[u].y;
                     bz = zz[u];
-                } else {
+                } else if (RUNNER) {
                     sec = d < sec ? d : sec;
                 }
             }
@@ -749,7 +753,8 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
     const double mybest = best;
     group_min_dist_key(best, key);
     const bool found = key != 0x7FFFFFFF;
-    {  // the group's runner-up: every lane's own, and the best of every lane but the winner's
+    second = DBL_MAX;
+    if (RUNNER) {  // the group's runner-up: every lane's own, and the best of every lane but the winner's
         double g2 = (found && mykey == key) ? sec : (mybest < sec ? mybest : sec);
         group_fmin_step<0>(g2);
         group_fmin_step<1>(g2);
@@ -845,6 +850,7 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
 
 // GetClosestNeighbor over a scan list: 32 lanes stride over it, four candidates per lane in flight per trip,
 // no divergent control flow.  Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
+template <bool RUNNER>
 __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigned short *I, int n, double sx, double sy, double sz,
                                                  int lane, double nn[3], double &second) {
     constexpr int U = 4;
@@ -873,8 +879,10 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
             const double d = (ex * ex + ey * ey) + ez * ez;
             const bool valid = i < n;
             const bool take = valid & (d < best);
-            const double loser = take ? best : d;
-            sec = (valid & (loser < sec)) ? loser : sec;
+            if (RUNNER) {
+                const double loser = take ? best : d;
+                sec = (valid & (loser < sec)) ? loser : sec;
+            }
             best = take ? d : best;
             bi = take ? i : bi;
         }
@@ -883,7 +891,8 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
     const double mybest = best;
     group_min_dist_key(best, bi);
     const bool found = bi != 0x7FFFFFFF;
-    {
+    second = DBL_MAX;
+    if (RUNNER) {
         double g2 = (found && mybi == bi) ? sec : (mybest < sec ? mybest : sec);
         group_fmin_step<0>(g2);
         group_fmin_step<1>(g2);

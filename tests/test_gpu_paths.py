@@ -441,7 +441,7 @@ def test_stability_shortcut_is_bitwise_neutral(gpu, O, kind, form, blocks):
     assert np.array_equal(out[0][0], out[1][0])
     for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
         assert out[0][1][k] == out[1][1][k], k
-    assert out[1][1]["iterations"] >= 8
+    assert out[1][1]["iterations"] >= 4
     ro = O.Registration(500, 1e-5)
     To = ro.align_points_to_map(src, o, guess, 3.0 * voxel, voxel)
     dt, dr = pose_error(To, out[1][0])
