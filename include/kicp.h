@@ -417,9 +417,6 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_wide_prune"  thread-per-point form: 0 = visit every occupied voxel of the 27; 1 = skip voxels whose box lies farther
  *                     than the best candidate / the correspondence threshold; 2 (default) = also bounded by the previous
  *                     iteration's neighbour.  Exact: skipped voxels lose every comparison of VoxelHashMap.cpp:58-63 anyway.
- *   "icp_group_stable"  group-per-point form, runs of at most 64 points: the same shortcut as "icp_wide_stable" (default 0: it
- *                     does not pay there -- a workgroup's search phase lasts one search as soon as one of its ~20 points
- *                     needs one, and keeping the runner-up slows every scan)
  *   "icp_wide_stable"  thread-per-point form: 1 (default) = a source point that has stayed in its voxel and whose last neighbour is
  *                     still provably closer than any other map point (a bound kept from its last search, minus how far the
  *                     point has moved) keeps that neighbour without a search, and the searches that remain run on a few lanes;

@@ -229,7 +229,6 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
     P.wide_stable = (int)options().icp_wide_stable;
-    P.group_stable = (int)options().icp_group_stable;
     P.wide_promote_from = (int)options().icp_wide_promote_from;
     P.wide_load_eighths = (int)options().icp_wide_load_eighths;
     return grid;
@@ -2456,8 +2455,6 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide_load_eighths")) {
         if (value < 2 || value > 7) return KICP_ERR_INVALID_ARG;
         options().icp_wide_load_eighths = value;
-    } else if (!strcmp(name, "icp_group_stable")) {
-        options().icp_group_stable = value != 0;
     } else if (!strcmp(name, "icp_wide_stable")) {
         options().icp_wide_stable = value != 0;
     } else if (!strcmp(name, "icp_wide_per_round")) {

@@ -49,22 +49,6 @@ struct IcpPoint {
 };
 static_assert(sizeof(IcpPoint) == 80, "IcpPoint layout");
 
-// What lets a source point keep its neighbour without a search (the group form's copy of WideQuery's stability state,
-// kicp_icp_wide.hpp; kept for runs of at most kIcpListRunMax points -- the full-size-voxel configurations -- in LDS):
-// nn, the voxel sv the point was in when nn was found, E (the population of the 27 cells around sv) and Lr, a lower bound
-// (a distance, shaved by 2^-30) of the distance to every OTHER map point of those cells: the runner-up of the last
-// search, minus everything the point has moved since.  While the point stays in sv and nn's new distance is strictly
-// below Lr, nn is still the unique minimum of VoxelHashMap.cpp:55-63's strict '<' loops and E is what it was.
-struct IcpStable {
-    double nn[3];
-    double Lr;
-    int sv[3];
-    int E;
-    int valid;    // the record belongs to a tile search of this launch
-    int have_nn;  // 0: the 27 cells were empty (nothing to find, as long as the point stays in sv)
-};
-static_assert(sizeof(IcpStable) == 56, "IcpStable layout");
-
 constexpr int kBulkFailMax = 30;  // failed cells remembered one by one; more: every query of the chunk searches the map directly
 struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records and the candidate pool follow
     double part[kIcpGroupsPerBlock][kIcpSums];
@@ -793,16 +777,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // (WIDE: all of sh.pts stays -- the slow-path queue and, with sh.terms, phase C's rows; 20-byte query records)
     const size_t head_bytes = WIDE ? sizeof(IcpShared) : offsetof(IcpShared, pts) + (size_t)min(kIcpChunk, max(n_local, 1)) * sizeof(IcpPoint);
     IcpQueryMeta *metas = reinterpret_cast<IcpQueryMeta *>(smem + head_bytes);
-    const bool use_stable = !WIDE && use_lists && P.group_stable != 0;  // (group form, short runs)
-    IcpStable *stab = nullptr;
     WideMeta *wmetas = reinterpret_cast<WideMeta *>(smem + head_bytes);
     Tile tile;
     {
         char *q = smem + head_bytes + (WIDE ? (((size_t)n_meta * sizeof(WideMeta) + 15) & ~(size_t)15) : (size_t)n_meta * sizeof(IcpQueryMeta));
-        if (use_stable) {
-            stab = reinterpret_cast<IcpStable *>(q);
-            q += ((size_t)n_meta * sizeof(IcpStable) + 15) & ~(size_t)15;
-        }
         // (WIDE with a few hundred queries: their windows hold 3 .. 5 k occupied voxels at the 1M-point configuration's steady
         // state -- a 4096-slot table was full there, misses walked 32 slots (58 us per search in the slowest waves) and
         // whole workgroups fell back to the map: profiles/r04_l_icp_probe_livox.txt -- so 8192 slots, at most 5/8 full)
@@ -862,7 +840,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             metas[i].list_state = 0;
             metas[i].list_base = 0;
             metas[i].list_n = metas[i].list_cap = 0;
-            if (use_stable) stab[i].valid = 0;
         }
     }
     if (n_meta > 0)
@@ -1462,33 +1439,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 pt.v[1] = vy;
                 pt.v[2] = vz;
                 pt.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
-                if (use_stable && has_meta && it > 0) {
-                    // does the last neighbour provably stay the neighbour?  (see IcpStable)
-                    IcpStable &sb = stab[j];
-                    if (sb.valid && sb.sv[0] == vx && sb.sv[1] == vy && sb.sv[2] == vz) {
-                        const double mx = s[0] - pin[0], my = s[1] - pin[1], mz = s[2] - pin[2];
-                        sb.Lr -= sqrt((mx * mx + my * my) + mz * mz) * (1.0 + 0x1p-30) + DBL_MIN;  // how far the point has moved, rounded up
-                        double dp = DBL_MAX;
-                        bool ok = true;  // (an empty neighbourhood stays empty)
-                        if (sb.have_nn) {
-                            const double ex = sb.nn[0] - s[0], ey = sb.nn[1] - s[1], ez = sb.nn[2] - s[2];
-                            dp = (ex * ex + ey * ey) + ez * ez;  // (as the scans compute it)
-                            ok = sqrt(dp) * (1.0 + 0x1p-30) < sb.Lr;
-                        }
-                        if (ok) {
-                            pt.nn[0] = sb.nn[0];
-                            pt.nn[1] = sb.nn[1];
-                            pt.nn[2] = sb.nn[2];
-                            pt.d2 = dp;
-                            pt.E = sb.E;
-                            pt.flag = 3;  // answered: phase B passes it by
-                        } else {
-                            sb.valid = 0;
-                        }
-                    } else {
-                        sb.valid = 0;
-                    }
-                }
                 if (pt.flag == 1) sh.any_fill = 1;
                 if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
                     sh.origin[0] = vx - kTileSpanXY / 2;
@@ -1533,16 +1483,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             const unsigned tb0 = PROF ? ticks32() : 0u;
             for (int t = grp; t < cn;) {
                 IcpPoint &pt = sh.pts[t];
-                if (pt.flag == 3) {  // its neighbour stayed (phase A): nothing to search
-                    int nt = 0;
-                    if (lane == 0) nt = atomicAdd(&sh.next_point, 1);
-                    t = __shfl(nt, 0, 32);
-                    continue;
-                }
                 const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
                 const int vx = pt.v[0], vy = pt.v[1], vz = pt.v[2];
                 int flag = pt.flag;
-                double second = DBL_MAX;
                 IcpQueryMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
                 int path = flag == 0 ? 0 : 3;  // profiling: 0 tile (lane per voxel), 1 tile (scan list), 3 HBM search
                 const unsigned tb = PROF ? ticks32() : 0u;
@@ -1557,16 +1500,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         tile_list_build(tile, vx, vy, vz, lane, meta);
                     if (meta->list_state == 1) {
                         E = meta->list_n;
-                        d2 = use_stable ? tile_scan_list<true>(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, second)
-                                        : tile_scan_list<false>(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, second);
+                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn);
                         listed = true;
                         path = 1;
                     }
                 }
                 if (flag == 0 && !listed) {
                     int bad;
-                    d2 = use_stable ? tile_scan<true>(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, second)
-                                    : tile_scan<false>(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, second);
+                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad);
                     if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is
                                 // being fetched by another group this very moment -> HBM this once
                         if (bad == 2 && lane == 0) meta->valid = -1;
@@ -1586,21 +1527,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     pt.nn[2] = nn[2];
                     pt.d2 = d2;
                     pt.E = E;
-                    if (use_stable && base + t < n_meta) {
-                        IcpStable &sb = stab[base + t];
-                        sb.valid = flag == 0 ? 1 : 0;  // (a tile search: every candidate of the 27 cells was looked at)
-                        if (flag == 0) {
-                            sb.nn[0] = nn[0];
-                            sb.nn[1] = nn[1];
-                            sb.nn[2] = nn[2];
-                            sb.Lr = sqrt(second) * (1.0 - 0x1p-30);
-                            sb.sv[0] = vx;
-                            sb.sv[1] = vy;
-                            sb.sv[2] = vz;
-                            sb.E = E;
-                            sb.have_nn = d2 < DBL_MAX ? 1 : 0;
-                        }
-                    }
                 }
                 const unsigned td = PROF ? ticks32() : 0u;
                 if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && t == grp) {

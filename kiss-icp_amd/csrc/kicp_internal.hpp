@@ -219,7 +219,6 @@ struct IcpParams {
     int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
-    int group_stable;      // group form, short runs: source points whose neighbour cannot have changed skip the search (IcpStable)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
     int wide_promote_from; // thread-per-query form: first iteration whose map reads leave their voxels in the LDS store
@@ -260,10 +259,6 @@ struct Options {
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
-    long icp_group_stable = 0;   // group form: skip the search of source points whose neighbour provably stays (runs of at most 64 points).
-                                 // Off: a workgroup's search phase is as long as ONE search whenever any of its ~20 points needs one,
-                                 // and tracking the runner-up slows every scan by a fifth -- measured 3 % slower on the bench scene
-                                 // (profiles/r04_ah_group_stable_ab.txt); it pays in the thread-per-query form only
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
     long icp_wide_promote_from = 1;
     long icp_wide_load_eighths = 5;

@@ -630,12 +630,8 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 // voxel (max_points_per_voxel steps), not by the size of the neighbourhood.
 // Returns the squared distance (DBL_MAX: no candidate), the neighbour, the number of points examined;
 // bad = the tile cannot answer: 1 a voxel is still being fetched by a concurrent fill, 2 one did not fit.
-// second: the smallest squared distance of any candidate OTHER than the returned one (DBL_MAX: there is none) -- the margin
-// by which the neighbour won, which lets later iterations keep it without a search (kicp_icp.hip, IcpStable).  Tracked only
-// when RUNNER is set: it costs two selects and a compare per candidate, a fifth of the scan (profiles/r04_ah_group_stable_ab.txt).
-template <bool RUNNER>
 __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz,
-                                            int lane, double nn[3], int &examined, int &bad, double &second) {
+                                            int lane, double nn[3], int &examined, int &bad) {
     constexpr int U = 4;
     int ref = 0, cnt = 0;
     int mybad = 0;
@@ -671,7 +667,7 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
     for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
     examined = tot;
     // ---- voxels held in LDS: every lane walks its own voxel
-    double best = DBL_MAX, sec = DBL_MAX;  // (sec: this lane's runner-up)
+    double best = DBL_MAX;
     int bk = 0;
     {
         const double *P = tile.points + 3 * (glob ? 0 : ref);
@@ -689,12 +685,7 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
             for (int u = 0; u < U; ++u) {
                 const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
                 const double d = (ex * ex + ey * ey) + ez * ez;
-                const bool valid = k0 + u < c;
-                const bool take = valid & (d < best);
-                if (RUNNER) {
-                    const double loser = take ? best : d;  // whichever of the two is not the best any more / yet
-                    sec = (valid & (loser < sec)) ? loser : sec;
-                }
+                const bool take = (k0 + u < c) & (d < best);
                 best = take ? d : best;
                 bk = take ? k0 + u : bk;
             }
@@ -736,33 +727,19 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
                 const double d = (ex * ex + ey * ey) + ez * ez;
                 const int k = (kj[u] << 5) | lane;  // {shift position of the voxel, index inside it}
                 if (d < best || (d == best && k < key)) {
-                    if (RUNNER) sec = best < sec ? best : sec;
                     best = d;
                     key = k;
                     bx = xy[u].x;
                     by = xy[u].y;
                     bz = zz[u];
-                } else if (RUNNER) {
-                    sec = d < sec ? d : sec;
                 }
             }
         }
     }
     if (best == DBL_MAX) key = 0x7FFFFFFF;
     const int mykey = key;
-    const double mybest = best;
     group_min_dist_key(best, key);
     const bool found = key != 0x7FFFFFFF;
-    second = DBL_MAX;
-    if (RUNNER) {  // the group's runner-up: every lane's own, and the best of every lane but the winner's
-        double g2 = (found && mykey == key) ? sec : (mybest < sec ? mybest : sec);
-        group_fmin_step<0>(g2);
-        group_fmin_step<1>(g2);
-        group_fmin_step<2>(g2);
-        group_fmin_step<3>(g2);
-        group_fmin_step<4>(g2);
-        second = g2;
-    }
     // the lane that holds the winner hands its coordinates to the group
     const unsigned who = (unsigned)(__ballot(found && mykey == key) >> half_shift);
     const int wl = who ? (__ffs(who) - 1) : 0;
@@ -850,12 +827,11 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
 
 // GetClosestNeighbor over a scan list: 32 lanes stride over it, four candidates per lane in flight per trip,
 // no divergent control flow.  Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
-template <bool RUNNER>
 __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigned short *I, int n, double sx, double sy, double sz,
-                                                 int lane, double nn[3], double &second) {
+                                                 int lane, double nn[3]) {
     constexpr int U = 4;
     const double *P = tile.points;
-    double best = DBL_MAX, sec = DBL_MAX;
+    double best = DBL_MAX;
     int bi = 0x7FFFFFFF;
     for (int i0 = lane; __ballot(i0 < n) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
         int pos[U];
@@ -877,30 +853,13 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
             const int i = i0 + 32 * u;
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
             const double d = (ex * ex + ey * ey) + ez * ez;
-            const bool valid = i < n;
-            const bool take = valid & (d < best);
-            if (RUNNER) {
-                const double loser = take ? best : d;
-                sec = (valid & (loser < sec)) ? loser : sec;
-            }
+            const bool take = (i < n) & (d < best);
             best = take ? d : best;
             bi = take ? i : bi;
         }
     }
-    const int mybi = bi;
-    const double mybest = best;
     group_min_dist_key(best, bi);
     const bool found = bi != 0x7FFFFFFF;
-    second = DBL_MAX;
-    if (RUNNER) {
-        double g2 = (found && mybi == bi) ? sec : (mybest < sec ? mybest : sec);
-        group_fmin_step<0>(g2);
-        group_fmin_step<1>(g2);
-        group_fmin_step<2>(g2);
-        group_fmin_step<3>(g2);
-        group_fmin_step<4>(g2);
-        second = g2;
-    }
     const int p = (int)I[found ? bi : 0];
     nn[0] = found ? P[3 * p] : 0.0;
     nn[1] = found ? P[3 * p + 1] : 0.0;
