@@ -410,6 +410,10 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
  *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
  *                     iterations.  Results are bitwise the same either way.
+ *   "icp_schur_solve"  1 (default): the 6 x 6 normal equations of a Gauss-Newton step, whose top-left block is (sum w) I, are solved
+ *                     through their 3 x 3 Schur complement when that is well conditioned (pivots above 1e-9 of the diagonal);
+ *                     0: always by the pivoted 6 x 6 LDLT of Eigen that the reference calls (Registration.cpp:156).  The two
+ *                     differ by rounding (poses ~1e-13 apart); rank-deficient systems always take the LDLT and its zero-pivot rule.
  *   "icp_wide"        form of the registration's association phase: 0 = a 32-lane group per source point (a few dozen points
  *                     per workgroup, neighbourhoods of hundreds of map points: full-size voxels); 1 = a thread per source
  *                     point (hundreds of points per workgroup: small voxels, large clouds); -1 (default) = by the size of

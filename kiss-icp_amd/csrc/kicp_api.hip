@@ -226,6 +226,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
     const long per_wg = (long)(n_hint / (size_t)(P.force_blocks > 0 ? P.force_blocks : grid));
     P.use_wide = options().icp_wide >= 0 ? (options().icp_wide != 0) : (per_wg > kIcpListRunMax);
     P.wide_prune = (int)options().icp_wide_prune;
+    P.schur_solve = (int)options().icp_schur_solve;
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
     P.wide_stable = (int)options().icp_wide_stable;
@@ -2463,6 +2464,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide_prefill")) {
         if (value < 0 || value > 8) return KICP_ERR_INVALID_ARG;
         options().icp_wide_prefill = value;
+    } else if (!strcmp(name, "icp_schur_solve")) {
+        options().icp_schur_solve = value != 0;
     } else if (!strcmp(name, "icp_wide_prune")) {
         if (value < 0 || value > 2) return KICP_ERR_INVALID_ARG;
         options().icp_wide_prune = value;

@@ -1700,32 +1700,36 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             double S[kIcpSums];
 #pragma unroll
             for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
-            double JTJ[36], nb[6], dx[6];
+            double dx[6];
+            // well-conditioned systems (the rule) through their 3 x 3 Schur complement; anything else the reference's way
+            if (!(P.schur_solve && schur3_solve(S, dx))) {
+                double JTJ[36], nb[6];
 #pragma unroll
-            for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
-            JTJ[0] = JTJ[7] = JTJ[14] = S[0];
-            // top-right block sum w * (-hat(s)) and its transpose
-            JTJ[0 * 6 + 4] = S[3];
-            JTJ[0 * 6 + 5] = -S[2];
-            JTJ[1 * 6 + 3] = -S[3];
-            JTJ[1 * 6 + 5] = S[1];
-            JTJ[2 * 6 + 3] = S[2];
-            JTJ[2 * 6 + 4] = -S[1];
-            JTJ[4 * 6 + 0] = S[3];
-            JTJ[5 * 6 + 0] = -S[2];
-            JTJ[3 * 6 + 1] = -S[3];
-            JTJ[5 * 6 + 1] = S[1];
-            JTJ[3 * 6 + 2] = S[2];
-            JTJ[4 * 6 + 2] = -S[1];
-            JTJ[3 * 6 + 3] = S[4];
-            JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
-            JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
-            JTJ[4 * 6 + 4] = S[7];
-            JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
-            JTJ[5 * 6 + 5] = S[9];
+                for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+                JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+                // top-right block sum w * (-hat(s)) and its transpose
+                JTJ[0 * 6 + 4] = S[3];
+                JTJ[0 * 6 + 5] = -S[2];
+                JTJ[1 * 6 + 3] = -S[3];
+                JTJ[1 * 6 + 5] = S[1];
+                JTJ[2 * 6 + 3] = S[2];
+                JTJ[2 * 6 + 4] = -S[1];
+                JTJ[4 * 6 + 0] = S[3];
+                JTJ[5 * 6 + 0] = -S[2];
+                JTJ[3 * 6 + 1] = -S[3];
+                JTJ[5 * 6 + 1] = S[1];
+                JTJ[3 * 6 + 2] = S[2];
+                JTJ[4 * 6 + 2] = -S[1];
+                JTJ[3 * 6 + 3] = S[4];
+                JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+                JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+                JTJ[4 * 6 + 4] = S[7];
+                JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+                JTJ[5 * 6 + 5] = S[9];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
-            ldlt6_solve(JTJ, nb, dx);
+                for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+                ldlt6_solve(JTJ, nb, dx);
+            }
             est = se3_exp(dx);
 #pragma unroll
             for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];

@@ -218,6 +218,7 @@ struct IcpParams {
     int use_lds;           // stage candidate voxels in LDS (0 disables)
     int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
+    int schur_solve;       // solve well-conditioned normal equations through their 3 x 3 Schur complement (kicp_math.hpp: schur3_solve)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
@@ -258,6 +259,7 @@ struct Options {
     long icp_points_per_group = 1;
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
+    long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
     long icp_wide_promote_from = 1;
