@@ -28,12 +28,12 @@ namespace kicp {
 //      scalars of J^T w J and J^T w r with J = [I | -hat(s)], r = s - nn (:81-98), added in point order.
 // The exchange, once per iteration (tagged 16-byte granule pairs, sc1 stores and loads: the data is its own flag):
 //   1. every workgroup publishes its 18 partial sums;
-//   2. workgroup g < 8 (a "leader") gathers the partials of the workgroups b = g, g + 8, g + 16, ... (at most 32),
+//   2. workgroup g < 16 (a "leader") gathers the partials of the workgroups b = g, g + 16, g + 32, ... (at most 16),
 //      sums them in that order and publishes the group's sums;
-//   3. EVERY workgroup gathers the (at most) 8 group sums, adds them in order, and solves the same 6x6 system on its
+//   3. EVERY workgroup gathers the (at most) 16 group sums, adds them in order, and solves the same 6x6 system on its
 //      first four waves: dx = LDLT(JTJ).solve(-JTr), est = exp(dx), stop when |dx| < convergence_criterion
 //      (:156-163); workgroup 0 also keeps T_icp = est * T_icp and the statistics.
-// Two short hops (28 x 304 B into 8 CUs, then 8 x 304 B into every CU) instead of one long one (224 x 304 B into ONE
+// Two short hops (14 x 304 B into 16 CUs, then 16 x 304 B into every CU) instead of one long one (224 x 304 B into ONE
 // CU's memory queue) plus a broadcast hop for the result; the summation tree depends on G only, never on timing or
 // placement, so results are reproducible bit for bit.
 // ------------------------------------------------------------------------------------------
@@ -52,7 +52,7 @@ static_assert(sizeof(IcpPoint) == 80, "IcpPoint layout");
 constexpr int kBulkFailMax = 30;  // failed cells remembered one by one; more: every query of the chunk searches the map directly
 struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records and the candidate pool follow
     double part[kIcpGroupsPerBlock][kIcpSums];
-    double range_sum[kIcpMaxMembers][kIcpSums];  // leader: its members' partials; every workgroup: the group sums (rows 0..7)
+    double range_sum[kIcpSumRows][kIcpSums];  // leader: its members' partials; every workgroup: the leaders' group sums
     double tot[kIcpSums];
     double est[8];  // q[4], t[3], |dx|
     // kept by ONE thread (kIcpBookThread of workgroup 0), off the critical path and out of registers:
@@ -1671,8 +1671,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpSums) * 16), dummy)) sh.fail = 1;
         }
         __syncthreads();
-        if (tid < ng * kIcpSums && !sh.fail) {
-            const int k = tid % kIcpSums, g = tid / kIcpSums;
+        for (int e = tid; e < ng * kIcpSums && !sh.fail; e += kIcpThreads) {
+            const int k = e % kIcpSums, g = e / kIcpSums;
             double v = 0.0;
             if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpSums + k) * 16), v)) sh.fail = 1;
             sh.range_sum[g][k] = v;

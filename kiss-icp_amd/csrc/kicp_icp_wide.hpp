@@ -108,7 +108,8 @@ struct WideRec {
 };
 static_assert(sizeof(WideRec) == 64, "WideRec layout");
 static_assert(offsetof(IcpShared, range_sum) == offsetof(IcpShared, part) + sizeof(double) * kIcpGroupsPerBlock * kIcpSums, "the records use part and range_sum as one array");
-constexpr int kWideRecs = (int)((sizeof(double) * kIcpGroupsPerBlock * kIcpSums + sizeof(double) * kIcpMaxMembers * kIcpSums) / sizeof(WideRec));  // 114
+constexpr int kWideRecsRoom = (int)((sizeof(double) * kIcpGroupsPerBlock * kIcpSums + sizeof(double) * kIcpSumRows * kIcpSums) / sizeof(WideRec));
+constexpr int kWideRecs = kWideRecsRoom < 128 ? kWideRecsRoom : 128;  // (16 lanes of each of the 8 waves take one)
 
 // ---- lower bounds of the distances to the neighbouring voxel layers --------------------------------------------------
 // A point p stored in voxel c satisfies floor(fl(p / vs)) == c (PointToVoxel, VoxelUtils.hpp:33-37), hence

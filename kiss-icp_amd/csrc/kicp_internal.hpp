@@ -164,8 +164,11 @@ constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;  // 16
 constexpr int kIcpSolveThreads = 256;  // waves 0..3 (one per SIMD) solve the 6x6 system, the rest wait
 constexpr int kIcpBookThread = kIcpThreads - 64;  // first lane of the last wave: pose / statistics bookkeeping
 constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 (scalar, member) pairs gathered per pass by a leader
-constexpr int kIcpExchangeGroups = 8;  // leaders of the two-level exchange (workgroups 0..7)
-constexpr int kIcpMaxMembers = 32;     // workgroups per leader at most (256 / 8)
+constexpr int kIcpExchangeGroups = 16;  // leaders of the two-level exchange (workgroups 0..15).  Measured on one box, bench
+                                        // scene (profiles/r04_ak_exchange_leaders_ab.txt): 4 leaders 2602, 8: 2785, 16: 2856,
+                                        // 32: 2715, 64: 2459 scans/s -- the first hop gets shorter, the second longer
+constexpr int kIcpMaxMembers = 16;      // workgroups per leader at most (256 / 16)
+constexpr int kIcpSumRows = kIcpMaxMembers > kIcpExchangeGroups ? kIcpMaxMembers : kIcpExchangeGroups;
 constexpr int kIcpMaxBlocks = 256;
 constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the whole LDS
 constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time
