@@ -1,13 +1,13 @@
 #!/bin/bash
 # The round's closing GPU call: everything the documentation quotes, in one box session, every piece under its own timeout.
-# Usage (through gpurun): TAG=r03_q bash scripts/gpu_final.sh
+# Usage (through gpurun): TAG=r04_final bash scripts/gpu_final.sh
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T="${TAG:-r03_q}"
+T="${TAG:-r04_final}"
 O=gpurun_out
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 ) > $O/${T}_smoke.log
-( timeout 600 python -m pytest tests -m gpu -q --timeout 200 --durations=8 --tb=short 2>&1 | tail -${PYTEST_TAIL:-30} ) > $O/${T}_pytest_gpu.log
+( timeout 900 python -m pytest tests -m gpu -q --timeout 300 --durations=8 --tb=short 2>&1 | tail -${PYTEST_TAIL:-30} ) > $O/${T}_pytest_gpu.log
 # STOP_ON_FAIL=1: a red suite ends the call here (GPU minutes are for the fix, not for profiles of a wrong kernel)
 if [ "${STOP_ON_FAIL:-0}" = 1 ] && ! grep -q " passed" $O/${T}_pytest_gpu.log; then cat $O/${T}_pytest_gpu.log; exit 1; fi
 if [ "${STOP_ON_FAIL:-0}" = 1 ] && grep -q " failed" $O/${T}_pytest_gpu.log; then cat $O/${T}_pytest_gpu.log; exit 1; fi
@@ -19,11 +19,18 @@ timeout 400 python3 bench.py --gpus 1 --steps 200 --warmup 10 > $O/${T}_bench_20
 ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/${T}_prof -o r -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/${T}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/${T}_prof.err )
 f=$(find $O/${T}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/${T}_kernel_stats.csv
 rm -rf $O/${T}_prof
+# ... of the driver's own command (20 / 5) and of the 1M-point configuration's 100-frame run
+( cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/${T}_prof -o r -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/${T}_bench_20_5_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/${T}_prof_20_5.err )
+f=$(find $O/${T}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/${T}_kernel_stats_20_5.csv
+rm -rf $O/${T}_prof
+( cd /tmp; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/${T}_prof -o r -- python $GRAFT_REPO_ROOT/bench.py --workload livox --steps 100 --warmup 4 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/${T}_bench_livox100_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/${T}_prof_livox.err )
+f=$(find $O/${T}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/${T}_kernel_stats_livox100.csv
+rm -rf $O/${T}_prof
 # HBM traffic (PMC), separate passes, corrected by a known-size copy on this box
 for wl in kitti $([ "${LEAN:-0}" = 1 ] || echo livox); do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     d=$O/${T}_pmc_${wl}_${ctr}
-    st=60; wu=10; [ $wl = livox ] && { st=12; wu=4; }
+    st=60; wu=10; [ $wl = livox ] && { st=30; wu=4; }
     ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $GRAFT_REPO_ROOT/$d -o r -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --no-cpu-baseline --no-extras --steps $st --warmup $wu --gen-procs 1 > /dev/null 2> $GRAFT_REPO_ROOT/$d.err )
     f=$(find $d -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python scripts/pmc_summary.py "$f" > $d.txt 2>&1
     rm -rf $d
@@ -43,7 +50,7 @@ timeout 300 python3 bench.py --gpus 2 --device 0 --steps 20 --warmup 5 > $O/${T}
 timeout 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --device 0 > $O/${T}_bench_2rank_gloo.json 2> $O/${T}_bench_2rank_gloo.err
 # in-kernel phase timers and the kernel timeline of two frames
 timeout 300 python scripts/icp_probe.py frames=160 > $O/${T}_icp_probe_steady.txt 2>&1
-timeout 300 python scripts/icp_probe.py livox=1 frames=24 > $O/${T}_icp_probe_livox.txt 2>&1
+timeout 400 python scripts/icp_probe.py livox=1 frames=100 > $O/${T}_icp_probe_livox100.txt 2>&1
 ( cd /tmp; cd $GRAFT_REPO_ROOT; STEPS=40 timeout 200 bash scripts/timeline.sh > $O/${T}_timeline.txt 2>&1 )
 for f in $O/${T}_smoke.log $O/${T}_pytest_gpu.log; do echo "== $f"; tail -6 $f; done
 for f in 20_5 200_10 mulran street livox100 2streams_1gpu 2rank_gloo; do python3 - <<PY
