@@ -42,7 +42,7 @@ for name in sorted(set(fetch) | set(write)):
     kern[short] = {"fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w,
                    "dispatches": fetch.get(name, {}).get("dispatches", 0)}
 doc[workload] = {
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --no-cpu-baseline --steps 10 --warmup 3",
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --workload <w> --no-cpu-baseline --no-extras --steps 60 --warmup 10 (livox: 30 / 4)",
     "unit_note": "counters in KiB; factors from a 1 GiB device copy on the same box",
     "calibration": {"copy_bytes": copy_bytes, "fetch_reported_bytes": cf, "write_reported_bytes": cw,
                     "fetch_factor": fetch_factor, "write_factor": write_factor},
