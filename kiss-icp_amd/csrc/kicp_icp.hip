@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const int n_full = sh.next_point;  // (the whole workgroup)
                 const bool compact = P.wide_stable && n_full > 0 && n_full <= kWideRecs;
                 WideRec *recs = reinterpret_cast<WideRec *>(sh.part);
+                static_assert(kWideFlatScratchBytes <= sizeof(double) * (kIcpGroupsPerBlock + kIcpSumRows) * kIcpSums, "scratch of the flat service");
                 if (compact) {
                     if (need_full) {
                         WideRec &r = recs[my_rank];
@@ -1258,8 +1259,20 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         ++prof_rounds;
                     }
                     // (the runner-up also in the first iteration: with its margin a good half of the queries need no search in the second)
-                    if (n_m) wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from, true);
-                    if (n_l) wide_serve_items<true>(m, tile, items, n_l, grp, lane, false, true);
+                    // (icp_wide_flat: a thread per point instead of a group per item; the compacted searches' records are in the
+                    // owners' registers by now and go back after the last round: their memory is the flat service's scratch)
+                    if (n_m) {
+                        if (P.wide_flat & 1)
+                            wide_serve_flat<false>(m, tile, items + cap_l, n_m, recs, it >= P.wide_promote_from);
+                        else
+                            wide_serve_items<false>(m, tile, items + cap_l, n_m, grp, lane, it >= P.wide_promote_from, true);
+                    }
+                    if (n_l) {
+                        if (P.wide_flat & 2)
+                            wide_serve_flat<true>(m, tile, items, n_l, recs, false);
+                        else
+                            wide_serve_items<true>(m, tile, items, n_l, grp, lane, false, true);
+                    }
                     __syncthreads();
                     const unsigned tr2 = PROF ? ticks32() : 0u;
                     merge_items(items, base_l, nf_l);

@@ -464,6 +464,171 @@ __device__ __forceinline__ void wide_serve_items(const MapView &m, const Tile &t
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same service by the WHOLE WORKGROUP, a thread per POINT (option icp_wide_flat).  A group serving items one after
+// the other keeps six voxels in flight and spends a round trip to L2 / HBM on each such batch whatever the voxels hold --
+// 22 us per round of ~350 items, 180 us of the first iteration of a workgroup of the 1M-point configuration
+// (profiles/r04_final_icp_probe_livox100.txt), with a handful of points in most voxels.  Here the points of all items of a
+// round form one sequence (prefix sums of the items' counts), thread t takes points t, t + 512, ... (four in flight: 2048
+// points per pass, every load of a pass issued before the first is used), finds the item of each by bisection of the
+// prefix sums, and the items' minima are settled by LDS atomics in the item records themselves:
+//   pass 1  umin of the distance's bit pattern (non-negative doubles order like their bits) into WideItem::d2;
+//   pass 2  the points AT the minimum: umin of {slot | j << 16 | index << 24} -- the smallest index wins, as in the reference's
+//           strict '<' walk (VoxelHashMap.cpp:58-63); every other point: umin of its distance (float, rounded down) into
+//           WideItem::blk_cnt -- the runner-up bound;
+//   pass 3  the winner leaves its coordinates; a point that ties with it counts as a runner-up.
+// PROMOTION is settled before the loads: the leader of an item claims the table entry (compare-and-swap of the entry's map
+// form against the same without kTileReady: one claim per voxel however many queries ask for it in this round -- the
+// group-wise service left a copy per asking group in the store), takes room in the store and enters the new position;
+// the threads of that item's points store what they have loaded.  Nobody reads the table or the store during a service.
+// scr: 2 KiB of LDS nobody uses during a service (kicp_icp.hip: the records of the compacted searches).
+// ------------------------------------------------------------------------------------------
+constexpr int kWideFlatPer = 4;
+constexpr size_t kWideFlatScratchBytes = sizeof(unsigned short) * 2 * (kWideItems + 2) + sizeof(int) * (kIcpThreads / 64);
+static_assert(kWideItems < kIcpThreads, "a thread per item leads it");
+template <bool LDS>
+__device__ __forceinline__ void wide_serve_flat(const MapView &m, const Tile &tile, WideItem *items, int n, void *scr, bool promote) {
+    const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
+    unsigned short *start = reinterpret_cast<unsigned short *>(scr);  // [n + 1]: first point of item e in the round's sequence
+    unsigned short *offs = start + (kWideItems + 2);                  // [n]: where item e's voxel goes in the LDS store (0xFFFF: nowhere)
+    int *wsum = reinterpret_cast<int *>(offs + (kWideItems + 2));     // [8]: points per wave of leaders
+    // (1) item e is led by thread e: its count, the prefix sums, the promotion
+    unsigned bc = 0u;
+    int cnt = 0;
+    if (tid < n) {
+        bc = items[tid].blk_cnt;
+        cnt = (int)((bc >> 24) & 63u);
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane64 >= d) incl += t;
+    }
+    if (lane64 == 63) wsum[wave] = incl;
+    if (tid < n) {
+        unsigned short o16 = 0xFFFFu;
+        if (!LDS && promote && cnt > 0) {
+            const unsigned slot = items[tid].slot;
+            const unsigned in_map = bc | kTileGlobal | kTileReady;  // the entry of a voxel that is read from the map
+            if (atomicCAS(&tile.vals[slot], in_map, bc | kTileGlobal) == in_map) {  // claimed: this leader alone deals with the voxel
+                const int o = atomicAdd(tile.count, cnt);
+                if ((unsigned)(o + cnt) * 24u <= tile.region_bytes && o + cnt <= 0xFFFF) {
+                    atomicMax(tile.stored, o + cnt);
+                    o16 = (unsigned short)o;
+                    __hip_atomic_store(&tile.vals[slot], (unsigned)o | ((unsigned)cnt << 24) | kTileReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    __hip_atomic_store(&tile.vals[slot], in_map, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // no room: it stays where it is
+                }
+            }
+        }
+        offs[tid] = o16;
+    }
+    __syncthreads();
+    {
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < kIcpThreads / 64; ++w) before += w < wave ? wsum[w] : 0;
+        if (tid <= n) start[tid] = (unsigned short)(before + incl - cnt);  // (thread n: the total)
+    }
+    __syncthreads();
+    // (2) passes of at most kWideFlatPer * 512 points (whole items; every thread computes the same bounds)
+    for (int lo = 0; lo < n;) {
+        const int p_lo = (int)start[lo];
+        int hi = lo + 1;  // (an item has at most 63 points)
+#pragma unroll
+        for (int step = 256; step; step >>= 1) {
+            const int c = hi + step;
+            if (c <= n && (int)start[c] - p_lo <= kWideFlatPer * kIcpThreads) hi = c;
+        }
+        const int np = (int)start[hi] - p_lo;
+        int e[kWideFlatPer], idx[kWideFlatPer];
+        double2 xy[kWideFlatPer];
+        double zz[kWideFlatPer], d[kWideFlatPer];
+        bool ok[kWideFlatPer];
+#pragma unroll
+        for (int u = 0; u < kWideFlatPer; ++u) {
+            const int r = tid + u * kIcpThreads, p = p_lo + r;
+            ok[u] = r < np;
+            int x = lo;  // the last item of [lo, hi) that starts at or before p (items without points are passed over)
+#pragma unroll
+            for (int step = 256; step; step >>= 1) {
+                const int c = x + step;
+                if (c < hi && (int)start[c] <= p) x = c;
+            }
+            e[u] = x;
+            idx[u] = p - (int)start[x];
+            d[u] = DBL_MAX;
+            if (ok[u]) {
+                const int blk = (int)(items[x].blk_cnt & 0xFFFFFFu);
+                if (LDS) {
+                    const double *P = tile.points + 3 * (blk + idx[u]);
+                    xy[u].x = P[0];
+                    xy[u].y = P[1];
+                    zz[u] = P[2];
+                } else {
+                    xy[u] = block_xy(m, blk)[idx[u]];
+                    zz[u] = block_z(m, blk)[idx[u]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kWideFlatPer; ++u)
+            if (ok[u]) {
+                WideItem &it = items[e[u]];
+                const double ex = xy[u].x - it.s[0], ey = xy[u].y - it.s[1], ez = zz[u] - it.s[2];
+                d[u] = (ex * ex + ey * ey) + ez * ez;
+                __hip_atomic_fetch_min(reinterpret_cast<unsigned long long *>(&it.d2), (unsigned long long)__double_as_longlong(d[u]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!LDS) {
+                    const unsigned o = offs[e[u]];
+                    if (o != 0xFFFFu) {
+                        double *q = tile.points + 3 * ((int)o + idx[u]);
+                        q[0] = xy[u].x;
+                        q[1] = xy[u].y;
+                        q[2] = zz[u];
+                    }
+                }
+            }
+        __syncthreads();  // every item's minimum is settled; its count and its query have been read
+        if (tid < hi - lo) {
+            WideItem &it = items[lo + tid];
+            it.blk_cnt = __float_as_uint(FLT_MAX);
+            it.k = 0xFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kWideFlatPer; ++u)
+            if (ok[u]) {
+                WideItem &it = items[e[u]];
+                if (d[u] == it.d2) {
+                    unsigned *w = reinterpret_cast<unsigned *>(&it.slot);  // {slot, j, k}: k is the top byte
+                    __hip_atomic_fetch_min(w, ((unsigned)it.slot | ((unsigned)it.j << 16)) | ((unsigned)idx[u] << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    __hip_atomic_fetch_min(&it.blk_cnt, __float_as_uint(d[u] < (double)FLT_MAX ? __double2float_rd(d[u]) : FLT_MAX), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kWideFlatPer; ++u)
+            if (ok[u]) {
+                WideItem &it = items[e[u]];
+                if (d[u] == it.d2) {
+                    if ((int)it.k == idx[u]) {
+                        it.s[0] = xy[u].x;
+                        it.s[1] = xy[u].y;
+                        it.s[2] = zz[u];
+                    } else {
+                        __hip_atomic_fetch_min(&it.blk_cnt, __float_as_uint(d[u] < (double)FLT_MAX ? __double2float_rd(d[u]) : FLT_MAX), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        lo = hi;  // (the next pass touches other items; the caller's barrier ends the service)
+    }
+}
+
 // the end of a full search: its distance, and the bound that lets the next iterations do without a search (WideQuery::Lr)
 // -- the second smallest distance computed, or the smallest box bound of an occupied cell that was not read
 __device__ __forceinline__ void wide_finish(const MapView &m, WideJob &q, const WideBest &b) {
