@@ -430,6 +430,9 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_wide_promote_from"  ... from this iteration on (default 1: the first iteration's reads are the widest, not the lasting ones)
  *   "icp_wide_per_round"  ... items a thread files per round of the voxel queue (default 4; the rest is held against the answers)
  *   "icp_wide_load_eighths"  ... eighths of the workgroup's voxel table that may fill (2 .. 7, default 5)
+ *   "icp_wide_group_max"  thread-per-point form: when at most this many points of a workgroup need a search in an iteration (the
+ *                     later iterations: most keep their neighbour, see icp_wide_stable), each is searched by a 32-lane group
+ *                     reading all 27 voxels, without the voxel queues (0 .. 512, default 128; 0 = always the queues).  Same answers.
  *   "icp_wide_flat"   thread-per-point form: how the queued voxels are read -- bit 0: the map's queue, bit 1: the LDS store's queue
  *                     by a thread per POINT of all queued voxels at once (minima settled by LDS atomics) instead of a 32-lane
  *                     group per voxel (0 .. 3, default 3: 15 % off the registration of the 1M-point

@@ -230,6 +230,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
     P.wide_flat = (int)options().icp_wide_flat;
+    P.wide_group_max = (int)options().icp_wide_group_max;
     P.wide_stable = (int)options().icp_wide_stable;
     P.wide_promote_from = (int)options().icp_wide_promote_from;
     P.wide_load_eighths = (int)options().icp_wide_load_eighths;
@@ -2462,6 +2463,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide_per_round")) {
         if (value < 1 || value > 27) return KICP_ERR_INVALID_ARG;
         options().icp_wide_per_round = value;
+    } else if (!strcmp(name, "icp_wide_group_max")) {
+        if (value < 0 || value > 512) return KICP_ERR_INVALID_ARG;
+        options().icp_wide_group_max = value;
     } else if (!strcmp(name, "icp_wide_flat")) {
         if (value < 0 || value > 3) return KICP_ERR_INVALID_ARG;
         options().icp_wide_flat = value;

@@ -973,6 +973,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     sh.cell_count = 0;    // some query of the chunk needs the map-direct search
                     sh.job_count = 0;     // queue of the voxels in the LDS store that are left to the groups
                     sh.bulk_failed = 0;   // queue of the voxels in the map
+                    if (PROF) sh.bulk_ticks[5] = sh.bulk_ticks[6] = 0u;  // (slowest table lookups of a search, searches that had to look up)
                 }
                 __syncthreads();
                 tile.ox = sh.origin[0];
@@ -1123,7 +1124,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 if (need_full) my_rank = atomicAdd(&sh.next_point, 1);
                 __syncthreads();
                 const int n_full = sh.next_point;  // (the whole workgroup)
-                const bool compact = P.wide_stable && n_full > 0 && n_full <= kWideRecs;
+                // (few of them: a 32-lane group per query, no queues -- wide_group_scan; its records live in the queues' memory)
+                const bool by_groups = P.wide_stable && n_full > 0 && n_full <= min(P.wide_group_max, kWideGroupRecs);
+                const bool compact = !by_groups && P.wide_stable && n_full > 0 && n_full <= kWideRecs;
                 WideRec *recs = reinterpret_cast<WideRec *>(sh.part);
                 static_assert(kWideFlatScratchBytes <= sizeof(double) * (kIcpGroupsPerBlock + kIcpSumRows) * kIcpSums, "scratch of the flat service");
                 if (compact) {
@@ -1182,8 +1185,62 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 wb.seen = 0u;
                 wb.sec = DBL_MAX;
                 int job_bad = 0;
+                bool got = false;  // this thread's query has had its full search
+                if (by_groups) {
+                    WideRec *grecs = reinterpret_cast<WideRec *>(sh.terms);
+                    if (need_full) {
+                        WideRec &r = grecs[my_rank];
+                        r.s[0] = wq.s[0];
+                        r.s[1] = wq.s[1];
+                        r.s[2] = wq.s[2];
+                        r.v[0] = wq.v[0];
+                        r.v[1] = wq.v[1];
+                        r.v[2] = wq.v[2];
+                        r.limit = P.wide_prune > 0 ? limit0 : DBL_MAX;
+                    }
+                    __syncthreads();
+                    for (int r0 = grp; r0 < n_full; r0 += kIcpGroupsPerBlock) {
+                        WideRec &r = grecs[r0];
+                        double gnn[3], gsec;
+                        int gE, gbad;
+                        unsigned gocc;
+                        const double gs[3] = {r.s[0], r.s[1], r.s[2]};
+                        const int gv[3] = {r.v[0], r.v[1], r.v[2]};
+                        const double gd = wide_group_scan(m, tile, gs, gv, r.limit, lane, gnn, gE, gocc, gsec, gbad);
+                        if (lane == 0) {
+                            r.s[0] = gnn[0];
+                            r.s[1] = gnn[1];
+                            r.s[2] = gnn[2];
+                            r.limit = gd;
+                            r.v[2] = gbad;
+                            r.occ = gocc;
+                            r.E = gE;
+                            r.Lr = sqrt(gsec) * (1.0 - 0x1p-30);
+                        }
+                    }
+                    __syncthreads();
+                    if (need_full) {
+                        const WideRec &r = grecs[my_rank];
+                        job_bad = r.v[2];
+                        wb.bx = r.s[0];
+                        wb.by = r.s[1];
+                        wb.bz = r.s[2];
+                        job.d2 = r.limit;
+                        job.occ = r.occ;
+                        job.E = r.E;
+                        job.Lr = r.Lr;
+                        got = true;
+                    }
+                    searching = false;
+                    __syncthreads();  // (the records' memory is the queues')
+                }
                 if (searching) {
+                    const bool looked_up = !job.cached;
                     wide_search_lds<PROF>(m, tile, job, limit0, P.wide_prune > 0, job_bad, ctr, wb);
+                    if (PROF) {
+                        if (looked_up) atomicAdd(&sh.bulk_ticks[6], 1u);
+                        atomicMax(&sh.bulk_ticks[5], ctr.t_lookup + ctr.t_chains);
+                    }
                     if (job_bad) searching = false;  // (the tile cannot answer: a voxel outside the key span, an entry that did not fit)
                 }
                 // Whatever this query still has to look at -- voxels in the LDS store beyond the first, voxels in the map -- goes
@@ -1292,7 +1349,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
                 // (3) the answers go home
                 if (searching) wide_finish(m, job, wb);
-                bool got = false;  // this thread's query has had its full search
                 if (compact) {
                     if (rec_worker) {
                         WideRec &r = recs[my_rec];
@@ -1319,7 +1375,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         job.Lr = r.Lr;
                         got = true;
                     }
-                } else {
+                } else if (!by_groups) {
                     got = need_full;
                 }
                 if (got) {
@@ -1402,6 +1458,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     if (grp == 6) r[2] = min(prof_file, 0xFFFFu) | (min(prof_serve, 0xFFFFu) << 16);  // workgroup: filing (+ wait), serving
                     if (grp == 8) r[2] = min(prof_merge, 0xFFFFu) | (min(prof_c, 0xFFFFu) << 16);     // workgroup: merging, phase C
                     if (grp == 4) r[2] = (unsigned)min(prof_items, 0xFFFF) | ((unsigned)min(prof_map_items, 0xFFFF) << 16);  // workgroup: items served, of them in the map
+                    if (grp == 12) r[2] = (unsigned)min(n_full, 0xFFFF) | (min(sh.bulk_ticks[6], 0xFFFFu) << 16);  // workgroup: full searches, of them with table lookups
+                    if (grp == 14) r[2] = min(sh.bulk_ticks[5], 0xFFFFu) | (compact ? 0x10000u : 0u);  // workgroup: the slowest search's lookups + chains; searches compacted
                     r[3] = 4u;
                     prof_path = 4u;
                 }

@@ -110,6 +110,7 @@ static_assert(sizeof(WideRec) == 64, "WideRec layout");
 static_assert(offsetof(IcpShared, range_sum) == offsetof(IcpShared, part) + sizeof(double) * kIcpGroupsPerBlock * kIcpSums, "the records use part and range_sum as one array");
 constexpr int kWideRecsRoom = (int)((sizeof(double) * kIcpGroupsPerBlock * kIcpSums + sizeof(double) * kIcpSumRows * kIcpSums) / sizeof(WideRec));
 constexpr int kWideRecs = kWideRecsRoom < 128 ? kWideRecsRoom : 128;  // (16 lanes of each of the 8 waves take one)
+constexpr int kWideGroupRecs = (int)((sizeof(double) * kIcpTermChunk * kIcpTerms + sizeof(IcpPoint) * kIcpChunk) / sizeof(WideRec));  // records of the searches by groups (sh.terms + sh.pts)
 
 // ---- lower bounds of the distances to the neighbouring voxel layers --------------------------------------------------
 // A point p stored in voxel c satisfies floor(fl(p / vs)) == c (PointToVoxel, VoxelUtils.hpp:33-37), hence
@@ -627,6 +628,180 @@ __device__ __forceinline__ void wide_serve_flat(const MapView &m, const Tile &ti
             }
         lo = hi;  // (the next pass touches other items; the caller's barrier ends the service)
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// A FEW full searches (the later iterations: 10 - 30 of a workgroup's 400 queries, profiles/r04_ap_icp_probe_livox100.txt)
+// are not worth the queues: filing, two flat services and the merge have fixed costs of ~25 us however few items there
+// are.  A 32-lane group takes a query instead, as in the first form (tile_scan, kicp_search.hpp): lane j < 27 looks up
+// cell j of the reference's shift table and walks its points in the LDS store, the cells whose points are in the map are
+// read by the group together (lane i point i, kChunk voxels in flight) -- the reference's order, its strict '<'.  Unlike
+// tile_scan this one skips cells by their box bounds (wide_gaps: exact, as in the thread's own search) -- with the last
+// neighbour's distance as the first limit a query reads one to four cells, one trip to the map instead of five --, and it
+// returns what the stability test needs: which cells are occupied and a lower bound of the distance to every point but
+// the neighbour: the SECOND smallest distance over the points read (a lane keeps the runner-up of what it has seen; over
+// the group the winner's lane contributes its runner-up, every other lane its best) or the bound of an occupied cell that
+// was not read.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &tile, const double s[3], const int v[3], double limit0, int lane, double nn[3],
+                                                  int &examined, unsigned &occ, double &second, int &bad) {
+    constexpr int U = 4;
+    const double sx = s[0], sy = s[1], sz = s[2];
+    int ref = 0, cnt = 0;
+    int mybad = 0;
+    bool glob = false;
+    double bd = DBL_MAX;  // lower bound of the distance to any point of this lane's cell (wide_gaps)
+    if (lane < 27) {
+        const int cx = (int)((kShift.x >> (2 * lane)) & 3), cy = (int)((kShift.y >> (2 * lane)) & 3), cz = (int)((kShift.z >> (2 * lane)) & 3);
+        const WideGaps gaps = wide_gaps(s, v, m.voxel_size);
+        const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
+        const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
+        const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
+        bd = (bx + by) + bz;
+        unsigned rkey;
+        if (tile_rel(tile, v[0] + cx - 1, v[1] + cy - 1, v[2] + cz - 1, rkey)) {
+            const int slot = tile_find(tile, rkey);
+            if (slot >= 0) {
+                const unsigned val = tile.vals[slot];
+                if (val == kTileOverflow || !(val & kTileReady)) {
+                    mybad = 2;
+                } else {
+                    ref = tile_ref(val);
+                    cnt = tile_cnt(val);
+                    glob = (val & kTileGlobal) != 0u;
+                }
+            }
+        } else {
+            mybad = 2;
+        }
+    }
+    const int half_shift = threadIdx.x & 32;
+    bad = (unsigned)(__ballot(mybad != 0) >> half_shift) != 0u ? 2 : 0;
+    if (bad) cnt = 0;
+    occ = (unsigned)(__ballot(cnt > 0) >> half_shift);
+    int tot = cnt;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
+    examined = tot;
+    // ---- cells in the LDS store: every lane walks its own, unless nothing in it can matter (bound above limit0:
+    // beyond the correspondence threshold, or farther than the last neighbour, which is still there)
+    double best = DBL_MAX, sec = DBL_MAX;
+    int bk = 0;
+    bool read = !glob && cnt > 0 && !(bd > limit0);
+    {
+        const double *P = tile.points + 3 * (read ? ref : 0);
+        const int c = read ? cnt : 0;
+        for (int k0 = 0; __ballot(k0 < c) != 0ull; k0 += U) {  // wave-uniform trip count
+            double x[U], y[U], z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double *q = P + 3 * ((k0 + u < c) ? k0 + u : 0);
+                x[u] = q[0];
+                y[u] = q[1];
+                z[u] = q[2];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const bool in = k0 + u < c;
+                const bool take = in & (d < best);
+                const double loser = take ? best : d;  // (what is not the best after this point)
+                sec = (in & (loser < sec)) ? loser : sec;
+                best = take ? d : best;
+                bk = take ? k0 + u : bk;
+            }
+        }
+    }
+    int key = (read && best < DBL_MAX) ? ((lane << 5) | bk) : 0x7FFFFFFF;
+    double bx = 0.0, by = 0.0, bz = 0.0;
+    if (key != 0x7FFFFFFF) {
+        const double *q = tile.points + 3 * (ref + bk);
+        bx = q[0];
+        by = q[1];
+        bz = q[2];
+    }
+    // ---- cells whose points are in the map: the group reads them together, kChunk cells per trip, and after every trip
+    // the cells left are held against what is in hand (a cell is skipped only when its bound is STRICTLY above it)
+    double limit = limit0;
+    {
+        double g = best;
+        group_fmin_step<0>(g);
+        group_fmin_step<1>(g);
+        group_fmin_step<2>(g);
+        group_fmin_step<3>(g);
+        group_fmin_step<4>(g);
+        limit = g < limit ? g : limit;
+    }
+    unsigned gl = (unsigned)(__ballot(glob && cnt > 0 && !(bd > limit)) >> half_shift);
+    while (__ballot(gl != 0) != 0ull) {  // wave-uniform trip count
+        double2 xy[kChunk];
+        double zz[kChunk];
+        int kj[kChunk];
+        bool ld[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            const int j = gl ? (__ffs(gl) - 1) : -1;
+            gl &= gl - 1;  // (0 & -1) == 0
+            const int bj = __shfl(ref, j & 31, 32);
+            const int cj = __shfl(cnt, j & 31, 32);
+            kj[u] = j;
+            ld[u] = (j >= 0) && (lane < cj);
+            if (j == lane) read = true;
+            if (ld[u]) {
+                xy[u] = block_xy(m, bj)[lane];
+                zz[u] = block_z(m, bj)[lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            if (ld[u]) {
+                const double ex = xy[u].x - sx, ey = xy[u].y - sy, ez = zz[u] - sz;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const int k = (kj[u] << 5) | lane;  // {shift position of the voxel, index inside it}
+                if (d < best || (d == best && k < key)) {
+                    sec = best < sec ? best : sec;
+                    best = d;
+                    key = k;
+                    bx = xy[u].x;
+                    by = xy[u].y;
+                    bz = zz[u];
+                } else {
+                    sec = d < sec ? d : sec;
+                }
+            }
+        }
+        if (__ballot(gl != 0) != 0ull) {  // (more to come: what of it can still matter)
+            double g = best;
+            group_fmin_step<0>(g);
+            group_fmin_step<1>(g);
+            group_fmin_step<2>(g);
+            group_fmin_step<3>(g);
+            group_fmin_step<4>(g);
+            limit = g < limit ? g : limit;
+            gl &= (unsigned)(__ballot(!(bd > limit)) >> half_shift);
+        }
+    }
+    if (best == DBL_MAX) key = 0x7FFFFFFF;
+    const int mykey = key;
+    const double mybest = best;
+    group_min_dist_key(best, key);
+    const bool found = key != 0x7FFFFFFF;
+    const unsigned who = (unsigned)(__ballot(found && mykey == key) >> half_shift);
+    const int wl = who ? (__ffs(who) - 1) : 0;
+    nn[0] = __shfl(bx, wl, 32);
+    nn[1] = __shfl(by, wl, 32);
+    nn[2] = __shfl(bz, wl, 32);
+    // the runner-up: of the points read, and no closer than that can any point of an occupied cell be that was not read
+    double g2 = (found && lane == wl) ? sec : mybest;
+    if (cnt > 0 && !read) g2 = bd < g2 ? bd : g2;
+    group_fmin_step<0>(g2);
+    group_fmin_step<1>(g2);
+    group_fmin_step<2>(g2);
+    group_fmin_step<3>(g2);
+    group_fmin_step<4>(g2);
+    second = g2;
+    return best;
 }
 
 // the end of a full search: its distance, and the bound that lets the next iterations do without a search (WideQuery::Lr)

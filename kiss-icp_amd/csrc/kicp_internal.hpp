@@ -228,6 +228,7 @@ struct IcpParams {
     int wide_promote_from; // thread-per-query form: first iteration whose map reads leave their voxels in the LDS store
     int wide_load_eighths; // thread-per-query form: the tile's table is at most this many eighths full
     int wide_per_round;    // thread-per-query form: items a thread files per round and queue
+    int wide_group_max;    // thread-per-query form: at most this many full searches of a workgroup go to the 32-lane groups, one query each (0: never)
     int wide_flat;         // thread-per-query form: bit 0 / bit 1: the map / the LDS queue is served by a thread per point (wide_serve_flat)
     int wide_prefill;      // thread-per-query form: eighths of the LDS store the window phase fills with points (0: the table only; the
                            // store is then filled by the searches themselves, from the second iteration on)
@@ -269,6 +270,7 @@ struct Options {
     long icp_wide_promote_from = 1;
     long icp_wide_load_eighths = 5;
     long icp_wide_per_round = 4; // thread-per-query form: items a thread files per round and queue (1 .. 27)
+    long icp_wide_group_max = 128; // thread-per-query form: up to this many full searches per workgroup are run by the 32-lane groups (wide_group_scan)
     long icp_wide_flat = 3;      // thread-per-query form: serve the voxel queues by a thread per point (bit 0: the map's, bit 1: the LDS store's)
     long icp_wide_prefill = 0;   // thread-per-query form: eighths of the LDS store filled by the window phase (0 .. 8)
     long icp_wide_prune = 2;     // thread-per-query form: 0 visit every occupied voxel, 1 skip by box distance, 2 + bound from the last neighbour

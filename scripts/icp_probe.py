@@ -38,7 +38,7 @@ if gp.size:
         for j, nm in enumerate(names):
             print('   %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (
                 nm, g[:, j].mean() / 100, np.percentile(g[:, j], 50) / 100, np.percentile(g[:, j], 99) / 100, g[:, j].max() / 100))
-        gc = g.reshape(-1, 16, g.shape[1])[:, [0, 10, 12, 14], :].reshape(-1, g.shape[1]) if (g[:, 6] == 4).all() else g  # (thread-per-query form: the other groups' records carry counters)
+        gc = g.reshape(-1, 16, g.shape[1])[:, [0, 10], :].reshape(-1, g.shape[1]) if (g[:, 6] == 4).all() else g  # (thread-per-query form: the other groups' records carry counters)
         print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (gc[:, 4].mean(), gc[:, 4].max(), gc[:, 5].mean(), gc[:, 5].max()))
         if (g[:, 6] == 4).all():
             # thread-per-query form: the 'xform' field of a record carries the voxels its thread visited {LDS | map << 8}
@@ -57,10 +57,15 @@ if gp.size:
             tf, ts, tm, tc = gw[:, 6, 4] / 100.0, gw[:, 6, 5] / 100.0, gw[:, 8, 4] / 100.0, gw[:, 8, 5] / 100.0
             print('   per workgroup (us): filing + wait mean %.2f max %.2f; serving mean %.2f max %.2f; merging mean %.2f max %.2f; phase C mean %.2f max %.2f' % (
                 tf.mean(), tf.max(), ts.mean(), ts.max(), tm.mean(), tm.max(), tc.mean(), tc.max()))
+            nfull, nlook, tlook, comp = gw[:, 12, 4], gw[:, 12, 5], gw[:, 14, 4] / 100.0, gw[:, 14, 5] & 1
+            print('   per workgroup: full searches mean %.1f max %d (of %d queries at most); of them with table lookups mean %.1f max %d; slowest lookups + chains mean %.2f max %.2f us; compacted in %d of %d workgroups' % (
+                nfull.mean(), nfull.max(), gw[:, 0, 7].max(), nlook.mean(), nlook.max(), tlook.mean(), tlook.max(), comp.sum(), len(comp)))
+            print('   correlation of the workgroup time with: full searches %.2f  searches with lookups %.2f  slowest lookups %.2f  items %.2f' % (
+                np.corrcoef(wgt, nfull)[0, 1], np.corrcoef(wgt, nlook)[0, 1], np.corrcoef(wgt, tlook)[0, 1], np.corrcoef(wgt, wgi)[0, 1]))
             order = np.argsort(-wgt)
             for w in list(order[:8]) + list(order[len(order) // 2: len(order) // 2 + 4]):
-                print('      wg %3d: %6.2f us  run %3d  direct %3d  items %4d (map %4d)  rounds %d   file %5.2f serve %5.2f merge %5.2f C %5.2f' % (
-                    w, wgt[w], gw[w, 0, 7], wgd[w], wgi[w], wgm[w], wgr[w], tf[w], ts[w], tm[w], tc[w]))
+                print('      wg %3d: %6.2f us  run %3d  direct %3d  items %4d (map %4d)  rounds %d   file %5.2f serve %5.2f merge %5.2f C %5.2f   full %3d lookups %3d slowest %5.2f%s' % (
+                    w, wgt[w], gw[w, 0, 7], wgd[w], wgi[w], wgm[w], wgr[w], tf[w], ts[w], tm[w], tc[w], nfull[w], nlook[w], tlook[w], ' compact' if comp[w] else ''))
             slow = np.argsort(-od[:, 3])[:6]
             for w in slow:
                 print('   slow wave: scan %6.2f = lookups %6.2f + chains %6.2f + walk %6.2f us (+ queueing)' % (od[w, 3] / 100, od[w, 4] / 100, od[w, 5] / 100, od[w, 1] / 100))
@@ -85,7 +90,7 @@ if gp.size:
     g = gp[it].reshape(-1, 16, 9)
     wg_t = g[:, :, 8].max(axis=1) / 100.0
     wg_n = g[:, 0, 7]
-    clean = [0, 10, 12, 14] if (gp[it][:, 6] == 4).all() else list(range(16))
+    clean = [0, 10] if (gp[it][:, 6] == 4).all() else list(range(16))
     wg_staged = g[:, clean, 4].max(axis=1)
     wg_ex = g[:, clean, 5].mean(axis=1)
     used = wg_n > 0

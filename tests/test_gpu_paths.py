@@ -366,6 +366,7 @@ def _wide_scene(kind, rng):
     return world, src, 0.25, make_pose((0.06, -0.04, 0.01), (0.001, -0.001, 0.004))
 
 
+_WIDE_GROUP_MAX_DEFAULT = 128
 _WIDE_FLAT_DEFAULT = 3  # the library's default of icp_wide_flat (kicp_internal.hpp), restored by the tests that change it
 
 
@@ -460,7 +461,9 @@ def test_flat_voxel_service_is_bitwise_neutral(gpu, O, kind, blocks):
     atomics (wide_serve_flat), instead of a 32-lane group per voxel -- for the map's queue, the LDS store's, both; with
     voxels promoted into the store from the first iteration on and from the second.  Which copy of a voxel is read, and
     in which round, differs; pose, iterations, correspondences and the points the reference examines may not -- with a
-    far-off guess, so that the store is refilled as points change voxels."""
+    far-off guess, so that the store is refilled as points change voxels.  icp_wide_group_max: the few searches of the later
+    iterations (here, with 27 points per workgroup, all of them) by a 32-lane group per query instead of the queues
+    (wide_group_scan) -- the same again."""
     from kiss_icp_amd import _cabi
     from kiss_icp_amd.mapping import VoxelHashMap
     from kiss_icp_amd.registration import Registration
@@ -475,15 +478,16 @@ def test_flat_voxel_service_is_bitwise_neutral(gpu, O, kind, blocks):
     try:
         _cabi.set_option("icp_blocks", blocks)
         _cabi.set_option("icp_wide", 1)
-        for flat, promote_from in ((0, 1), (1, 1), (2, 1), (3, 1), (3, 0), (0, 0)):
+        for flat, promote_from, group_max in ((0, 1, 0), (1, 1, 0), (2, 1, 0), (3, 1, 0), (3, 0, 0), (0, 0, 0), (3, 1, 64), (0, 1, 64), (3, 0, 512), (3, 1, 8)):
             _cabi.set_option("icp_wide_flat", flat)
             _cabi.set_option("icp_wide_promote_from", promote_from)
+            _cabi.set_option("icp_wide_group_max", group_max)
             r = Registration(500, 1e-5)
-            out[flat, promote_from] = (r.align_points_to_map(src, g, guess, 3.0 * voxel, voxel), dict(r.last_stats))
+            out[flat, promote_from, group_max] = (r.align_points_to_map(src, g, guess, 3.0 * voxel, voxel), dict(r.last_stats))
     finally:
-        for name, v in (("icp_wide_flat", _WIDE_FLAT_DEFAULT), ("icp_wide_promote_from", 1), ("icp_wide", -1), ("icp_blocks", 0)):
+        for name, v in (("icp_wide_flat", _WIDE_FLAT_DEFAULT), ("icp_wide_group_max", _WIDE_GROUP_MAX_DEFAULT), ("icp_wide_promote_from", 1), ("icp_wide", -1), ("icp_blocks", 0)):
             _cabi.set_option(name, v)
-    ref = out[0, 1]
+    ref = out[0, 1, 0]
     for key, got in out.items():
         assert np.array_equal(ref[0], got[0]), key
         for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
@@ -496,9 +500,9 @@ def test_flat_voxel_service_is_bitwise_neutral(gpu, O, kind, blocks):
     assert ref[1]["points_examined"] == ro.last_stats["points_examined"]
 
 
-@pytest.mark.parametrize("flat", [0, 3])
+@pytest.mark.parametrize("flat,group_max", [(0, 0), (3, 0), (3, 64)])
 @pytest.mark.parametrize("prune", [0, 2])
-def test_thread_per_query_form_keeps_the_references_tie_order(gpu, O, prune, flat):
+def test_thread_per_query_form_keeps_the_references_tie_order(gpu, O, prune, flat, group_max):
     """lattice map, queries exactly between lattice points (several candidates at EXACTLY the same distance in different
     voxels), searched by the thread-per-query form: a voxel may only be skipped when its box is STRICTLY farther than what
     is in hand, and among equals the smaller {shift position, index} wins -- VoxelHashMap.cpp:55-63's strict '<'."""
@@ -517,6 +521,7 @@ def test_thread_per_query_form_keeps_the_references_tie_order(gpu, O, prune, fla
         _cabi.set_option("icp_wide", 1)
         _cabi.set_option("icp_wide_prune", prune)
         _cabi.set_option("icp_wide_flat", flat)
+        _cabi.set_option("icp_wide_group_max", group_max)
         for offset in ((0.125, 0.125, 0.125), (0.0625, 0.125, 0.125), (0.9375, 0.125, 0.0625), (0.5, 0.0, 0.25)):
             src = np.stack(np.meshgrid(qa, qa, np.array([-0.5, 0.0]), indexing="ij"), axis=-1).reshape(-1, 3) + np.array(offset)
             for guess in (np.eye(4), make_pose((0.5, -0.25, 0.0))):
@@ -532,6 +537,7 @@ def test_thread_per_query_form_keeps_the_references_tie_order(gpu, O, prune, fla
         _cabi.set_option("icp_wide", -1)
         _cabi.set_option("icp_wide_prune", 2)
         _cabi.set_option("icp_wide_flat", _WIDE_FLAT_DEFAULT)
+        _cabi.set_option("icp_wide_group_max", _WIDE_GROUP_MAX_DEFAULT)
 
 
 def test_thread_per_query_form_in_the_pipeline(gpu, O):
