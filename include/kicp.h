@@ -430,6 +430,11 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_wide_promote_from"  ... from this iteration on (default 1: the first iteration's reads are the widest, not the lasting ones)
  *   "icp_wide_per_round"  ... items a thread files per round of the voxel queue (default 4; the rest is held against the answers)
  *   "icp_wide_load_eighths"  ... eighths of the workgroup's voxel table that may fill (2 .. 7, default 5)
+ *   "frame_events"    pipelines created afterwards: 1 = the events that order a frame's buffers, tell the front stages that the
+ *                     pose is ready and time the registration are attached to the dispatches of the registration and of the last
+ *                     map kernel (hipExtLaunchKernel) instead of being recorded between the kernels of the serial chain (0, the
+ *                     default).  Same results; kept as the record of an experiment: a dispatch that carries a completion signal
+ *                     costs more than the recorded event it saves (0.387 against 0.360 ms per frame).
  *   "icp_wide_group_max"  thread-per-point form: when at most this many points of a workgroup need a search in an iteration (the
  *                     later iterations: most keep their neighbour, see icp_wide_stable), each is searched by a 32-lane group
  *                     reading all 27 voxels, without the voxel queues (0 .. 512, default 128; 0 = always the queues).  Same answers.

@@ -53,10 +53,12 @@ int DevBuf::reserve(size_t need, bool keep, hipStream_t s) {
     if (keep && bytes) nb = nb < bytes * 2 ? bytes * 2 : nb;
     void *np = nullptr;
     KICP_HIP(hipMalloc(&np, nb));
-    if (keep && p && bytes) {
-        KICP_HIP(hipMemcpyAsync(np, p, bytes, hipMemcpyDeviceToDevice, s));
-        KICP_HIP(hipStreamSynchronize(s));
-    }
+    // A new buffer starts as zeros, not as whatever the allocator hands out (fresh device memory, or a freed buffer of
+    // this process): nothing is meant to read a word before it was written, but if something does, it reads the same
+    // thing in every process -- buffers are (re)allocated a handful of times in a pipeline's life, so this costs nothing.
+    KICP_HIP(hipMemsetAsync(np, 0, nb, s));
+    if (keep && p && bytes) KICP_HIP(hipMemcpyAsync(np, p, bytes, hipMemcpyDeviceToDevice, s));
+    KICP_HIP(hipStreamSynchronize(s));
     if (p) KICP_HIP(hipFree(p));
     p = np;
     bytes = nb;
@@ -168,7 +170,7 @@ static void icp_gate_declare_share(int device_id, int share) {
     if (share > g.lanes) g.lanes = share < kIcpMaxLanes ? share : kIcpMaxLanes;
 }
 // launch k_icp on `s` through the device's gate
-static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s) {
+static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     IcpDeviceGate &g = icp_gate(device_id);
     std::lock_guard<std::mutex> lk(g.mu);
     int mine = -1, pick = 0;
@@ -185,7 +187,7 @@ static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profil
             KICP_HIP(hipStreamWaitEvent(s, g.ev, 0));
         }
     }
-    launch_icp(P, grid, profile, P.use_wide != 0, s);
+    launch_icp(P, grid, profile, P.use_wide != 0, s, start, stop);
     g.lane[mine].stream = s;
     g.lane[mine].stamp = ++g.clock;
     return KICP_OK;
@@ -1220,6 +1222,15 @@ struct kicp_pipeline {
     static constexpr int kRing = 256;
     FrameRecord *ring = nullptr;  // hipHostMalloc
     hipEvent_t ev[kRing][2];
+    // Option "frame_events" (off by default): the three per-frame events attached to dispatches (hipExtLaunchKernel) instead
+    // of being packets of their own in the queue.  The idea: the kernel timeline shows 0 us between k_map_link / apply /
+    // prune, which have nothing between them, 7 us behind k_icp with one recorded event, 13 - 16 in front of it with a wait
+    // and a record (profiles/r04_final_timeline.txt).  The measurement: a dispatch that carries a completion signal costs
+    // more than the packet it saves -- 0.387 against 0.360 ms per frame (profiles/r04_av_frame_events_sweep.txt).  ev[i][0] /
+    // [1] are then the start / stop of frame i's k_icp dispatch (timing; [1] also "the pose is ready"), ev_done[i] the
+    // completion of its k_map_prune: "frame i is completely done" -- what ev[i + 1][0] says when events are recorded.
+    hipEvent_t ev_done[kRing];
+    bool ext_events = false;
     bool ev_ok = false;
     int in_flight = 0;
     int done_upto = 0;    // frames [0, done_upto) of the ring are known to be complete (their successor's launch event fired)
@@ -1336,12 +1347,16 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
 // Tighten the host-side upper bounds of the map counters WITHOUT synchronising: the newest frame
 // whose last kernel has completed left its exact counters in the pinned ring; frames queued behind
 // it can each have added at most one voxel per raw point.
+// the event that says "frame i (of the current batch) is completely done"; recorded events: the one in front of frame i + 1's
+// registration, which therefore must have been queued
+static hipEvent_t pipe_frame_done_event(kicp_pipeline *p, int i) { return p->ext_events ? p->ev_done[i] : p->ev[i + 1][0]; }
+
 static void pipe_refresh_bounds(kicp_pipeline *p) {
     kicp_map *m = p->map;
     // ev[i + 1][0] sits in front of frame i+1's registration launch, i.e. behind frame i's last kernel
     long pending = p->in_flight > 0 ? (long)p->ring[p->in_flight - 1].n_raw : 0;
     for (int i = p->in_flight - 2; i >= 0; --i) {
-        if (i + 1 <= p->done_upto || hipEventQuery(p->ev[i + 1][0]) == hipSuccess) {
+        if (i + 1 <= p->done_upto || hipEventQuery(pipe_frame_done_event(p, i)) == hipSuccess) {
             if (i + 1 > p->done_upto) p->done_upto = i + 1;
             const FrameRecord &r = p->ring[i];
             const long used = (long)r.map_ctr[C_USED] + pending, bump = (long)r.map_ctr[C_BUMP] + pending,
@@ -1366,10 +1381,10 @@ static int pipe_backpressure(kicp_pipeline *p) {
     if (depth < 2 || p->in_flight < depth) return KICP_OK;
     const int k = p->in_flight - depth + 1;  // frame k - 1 must be done = the event in front of frame k's registration
     if (k <= p->done_upto) return KICP_OK;
-    if (hipEventQuery(p->ev[k][0]) != hipSuccess) {
+    if (hipEventQuery(pipe_frame_done_event(p, k - 1)) != hipSuccess) {
         (void)hipGetLastError();
         const double t0 = now_ms();
-        KICP_HIP(hipEventSynchronize(p->ev[k][0]));
+        KICP_HIP(hipEventSynchronize(pipe_frame_done_event(p, k - 1)));
         p->hs.backpressure_waits++;
         p->hs.backpressure_ms += now_ms() - t0;
     }
@@ -1429,7 +1444,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
             // launch-start event of the frame behind it), i.e. at most two frames are still queued; then the bound
             // (exact counters of the newest finished frame + two frames of slack) fits
             const double t0 = now_ms();
-            KICP_HIP(hipEventSynchronize(p->ev[p->in_flight - 2][0]));
+            KICP_HIP(hipEventSynchronize(pipe_frame_done_event(p, p->in_flight - 3)));
             p->hs.capacity_waits++;
             p->hs.wait_ms += now_ms() - t0;
             pipe_refresh_bounds(p);
@@ -1452,7 +1467,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // done: the event in front of frame k-1's registration launch says so (frames of earlier batches
     // are done anyway: the host synchronised on them).  The pose of frame k-1 is only needed to
     // deskew; without timestamps the front stages run under frame k-1's registration.
-    if (p->in_flight >= 2) KICP_HIP(hipStreamWaitEvent(sp, p->ev[p->in_flight - 1][0], 0));
+    if (p->in_flight >= 2) KICP_HIP(hipStreamWaitEvent(sp, pipe_frame_done_event(p, p->in_flight - 2), 0));
     if (do_deskew && p->icp_done_event) KICP_HIP(hipStreamWaitEvent(sp, p->icp_done_event, 0));
     // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
     if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, prep, sp);
@@ -1590,13 +1605,20 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // Two events per frame, each doing double duty: ev[slot][0] in front of the launch opens the timing
     // bracket and marks "the previous frame is completely done" (buffer reuse, capacity bounds);
     // ev[slot][1] behind it closes the bracket and tells prep_stream the pose is ready.
-    KICP_HIP(hipEventRecord(p->ev[slot][0], s));
-    KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s));
-    // (skipped when nobody would look at it: timing off and a configuration that never deskews)
+    // (the pose-ready event is skipped when nobody would look at it: timing off and a configuration that never deskews)
+    const bool want_done = options().icp_timing != 0 || c.deskew;
     p->icp_done_event = nullptr;
-    if (options().icp_timing != 0 || c.deskew) {
-        p->icp_done_event = p->ev[slot][1];
-        KICP_HIP(hipEventRecord(p->icp_done_event, s));
+    if (p->ext_events) {
+        KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s, options().icp_timing != 0 ? p->ev[slot][0] : nullptr,
+                                    want_done ? p->ev[slot][1] : nullptr));
+        if (want_done) p->icp_done_event = p->ev[slot][1];
+    } else {
+        KICP_HIP(hipEventRecord(p->ev[slot][0], s));
+        KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s));
+        if (want_done) {
+            p->icp_done_event = p->ev[slot][1];
+            KICP_HIP(hipEventRecord(p->icp_done_event, s));
+        }
     }
 
     // --- local_map_.Update(frame_downsample, new_pose) (KissICP.cpp:61) --------------------------
@@ -1612,7 +1634,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // --- ... and the frame record, written by the kernel itself into the pinned host ring ---------
     FrameRecord *rec = p->ring + slot;
     rec->n_raw = n;
-    launch_map_prune(v, m->bump_ub, st, 1, nullptr, reinterpret_cast<unsigned *>(rec), kRecWords, s);
+    launch_map_prune(v, m->bump_ub, st, 1, nullptr, reinterpret_cast<unsigned *>(rec), kRecWords, s, p->ext_events ? p->ev_done[slot] : nullptr);
     KICP_HIP(hipGetLastError());
     p->in_flight++;
     p->frames_enqueued++;
@@ -1807,11 +1829,13 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
         hipEventCreateWithFlags(&p->ev_prep_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_prep_done[1], hipEventDisableTiming) != hipSuccess)
         s = KICP_ERR_HIP;
+    p->ext_events = options().frame_events != 0;
     if (s == KICP_OK) {
         p->ev_ok = true;
         for (int i = 0; i < kicp_pipeline::kRing && p->ev_ok; ++i) {
             for (int j = 0; j < 2; ++j)
                 if (hipEventCreate(&p->ev[i][j]) != hipSuccess) p->ev_ok = false;
+            if (hipEventCreate(&p->ev_done[i]) != hipSuccess) p->ev_ok = false;
         }
     }
     if (s == KICP_OK && !p->ev_ok) s = KICP_ERR_HIP;  // the events order buffer reuse between the two streams
@@ -1873,6 +1897,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (p->ev_ok)
         for (int i = 0; i < kicp_pipeline::kRing; ++i) {
             for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
+            (void)hipEventDestroy(p->ev_done[i]);
         }
     if (p->ring) (void)hipHostFree(p->ring);
     if (p->stream) {
@@ -1894,7 +1919,15 @@ static void pipe_collect(kicp_pipeline *p, int count, int &err_bits) {
             else (void)hipGetLastError();  // e.g. the option was switched on while frames were queued
             if (i > 0) {  // device time between two registrations: the previous frame's map update + the front of this one
                 float gap = 0.f;
-                if (hipEventElapsedTime(&gap, p->ev[i - 1][1], p->ev[i][0]) == hipSuccess) {
+                hipError_t ge;
+                if (p->ext_events) {  // (stop to stop, minus this registration: a start event reads as its dispatch's end outside its own pair)
+                    ge = hipEventElapsedTime(&gap, p->ev[i - 1][1], p->ev[i][1]);
+                    gap -= ms;
+                    if (gap < 0.f) gap = 0.f;
+                } else {
+                    ge = hipEventElapsedTime(&gap, p->ev[i - 1][1], p->ev[i][0]);
+                }
+                if (ge == hipSuccess) {
                     p->hs.device_gap_ms += gap;
                     if (gap > p->hs.max_device_gap_ms) p->hs.max_device_gap_ms = gap;
                 } else {
@@ -2463,6 +2496,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide_per_round")) {
         if (value < 1 || value > 27) return KICP_ERR_INVALID_ARG;
         options().icp_wide_per_round = value;
+    } else if (!strcmp(name, "frame_events")) {
+        options().frame_events = value != 0;
     } else if (!strcmp(name, "icp_wide_group_max")) {
         if (value < 0 || value > 512) return KICP_ERR_INVALID_ARG;
         options().icp_wide_group_max = value;

@@ -1979,17 +1979,24 @@ int icp_blocks_per_cu(int lds_bytes) {
     return r;
 }
 // wide: the thread-per-query form of the association (kicp_icp_wide.hpp) -- same result, for clouds of many points per workgroup
-void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s) {
+template <bool PROF, bool WIDE>
+static void launch_icp_as(const IcpParams &P, int G, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    if (start || stop)
+        hipExtLaunchKernelGGL((k_icp<PROF, WIDE>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, start, stop, 0, P);
+    else
+        hipLaunchKernelGGL((k_icp<PROF, WIDE>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+}
+void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (wide) {
         if (profile)
-            hipLaunchKernelGGL((k_icp<true, true>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+            launch_icp_as<true, true>(P, G, s, start, stop);
         else
-            hipLaunchKernelGGL((k_icp<false, true>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+            launch_icp_as<false, true>(P, G, s, start, stop);
     } else {
         if (profile)
-            hipLaunchKernelGGL((k_icp<true, false>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+            launch_icp_as<true, false>(P, G, s, start, stop);
         else
-            hipLaunchKernelGGL((k_icp<false, false>), dim3(G), dim3(kIcpThreads), (size_t)P.lds_bytes, s, P);
+            launch_icp_as<false, false>(P, G, s, start, stop);
     }
 }
 

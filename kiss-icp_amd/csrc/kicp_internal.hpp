@@ -17,6 +17,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstddef>
 #include <cstdint>
@@ -270,6 +271,8 @@ struct Options {
     long icp_wide_promote_from = 1;
     long icp_wide_load_eighths = 5;
     long icp_wide_per_round = 4; // thread-per-query form: items a thread files per round and queue (1 .. 27)
+    long frame_events = 0;       // pipelines created afterwards: 1 = the per-frame events ride on the dispatches of k_icp and k_map_prune (hipExtLaunchKernel)
+                                 // instead of being recorded between them -- measured: 26 us per frame SLOWER (profiles/r04_av_frame_events_sweep.txt)
     long icp_wide_group_max = 128; // thread-per-query form: up to this many full searches per workgroup are run by the 32-lane groups (wide_group_scan)
     long icp_wide_flat = 3;      // thread-per-query form: serve the voxel queues by a thread per point (bit 0: the map's, bit 1: the LDS store's)
     long icp_wide_prefill = 0;   // thread-per-query form: eighths of the LDS store filled by the window phase (0 .. 8)

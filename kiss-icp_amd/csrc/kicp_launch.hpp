@@ -70,7 +70,9 @@ int icp_prepare(int device_id);
 int icp_blocks_per_cu(int lds_bytes);
 void launch_selftest_solve(const double *A, const double *b, int n, double *x, hipStream_t s);  // co-resident k_icp workgroups per CU (occupancy query, current device)
 size_t icp_granule_words(int G);
-void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s);
+// start / stop: events attached to the dispatch itself (hipExtLaunchKernel: its own completion signal and timestamps --
+// no packet of their own in the queue, unlike hipEventRecord); either may be null
+void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s);
 void launch_ts_minmax(const double *ts, int n_ts, PrepState *prep, hipStream_t s);
@@ -85,7 +87,7 @@ void launch_map_link(const MapView &m, const InsertScratch &sc, const double *in
                      int n_max, const PipeState *state, int use_pose, hipStream_t s);
 void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipStream_t s);
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
-                      const double origin[3], unsigned *host_rec, int rec_words, hipStream_t s);
+                      const double origin[3], unsigned *host_rec, int rec_words, hipStream_t s, hipEvent_t done = nullptr);  // done: attached to the dispatch (see launch_icp)
 void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s);
 void launch_map_count_points(const MapView &m, long bump_ub, hipStream_t s);
 

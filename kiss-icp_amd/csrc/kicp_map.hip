@@ -411,12 +411,17 @@ void launch_map_apply(const MapView &m, const InsertScratch &sc, int n_max, hipS
         hipLaunchKernelGGL(k_map_apply<256>, dim3(grid_for((long)n_max * 32, 256, 2048)), dim3(256), 0, s, m, sc);
 }
 void launch_map_prune(const MapView &m, long bump_ub, const PipeState *state, int use_state_origin,
-                      const double origin[3], unsigned *host_rec, int rec_words, hipStream_t s) {
+                      const double origin[3], unsigned *host_rec, int rec_words, hipStream_t s, hipEvent_t done) {
     // grid-stride over the blocks; at most 256 workgroups: every one of them signs off with a fenced
     // atomic (frame-record hand-off), which would serialise over thousands of workgroups
-    hipLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 256)), dim3(256), 0, s, m, state,
-                       use_state_origin, origin ? origin[0] : 0.0, origin ? origin[1] : 0.0,
-                       origin ? origin[2] : 0.0, host_rec, rec_words);
+    if (done)
+        hipExtLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 256)), dim3(256), 0, s, nullptr, done, 0, m, state,
+                              use_state_origin, origin ? origin[0] : 0.0, origin ? origin[1] : 0.0,
+                              origin ? origin[2] : 0.0, host_rec, rec_words);
+    else
+        hipLaunchKernelGGL(k_map_prune, dim3(grid_for(bump_ub, 256, 256)), dim3(256), 0, s, m, state,
+                           use_state_origin, origin ? origin[0] : 0.0, origin ? origin[1] : 0.0,
+                           origin ? origin[2] : 0.0, host_rec, rec_words);
 }
 void launch_map_rehash(const MapView &m, long bump_ub, hipStream_t s) {
     hipLaunchKernelGGL(k_map_rehash, dim3(grid_for(bump_ub, 256, 2048)), dim3(256), 0, s, m);
