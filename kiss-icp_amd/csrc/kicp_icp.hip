@@ -1690,8 +1690,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // partial -- round 1 -- moved 17.5 MB per iteration.)
         const unsigned c2 = PROF ? ticks32() : 0u;
         const int ng = min(kIcpExchangeGroups, G);  // groups = leaders; group g holds the workgroups g, g + ng, g + 2 ng, ...
-        unsigned long long *grp = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpSums) + (size_t)(it & 1) * kIcpExchangeGroups * (2 * kIcpSums);
-        const __amdgpu_buffer_rsrc_t grp_rsrc = granule_rsrc(grp, (unsigned)(kIcpExchangeGroups * 2 * kIcpSums * sizeof(unsigned long long)));
+        unsigned long long *grp_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpSums) + (size_t)(it & 1) * kIcpExchangeGroups * (2 * kIcpSums);
+        const __amdgpu_buffer_rsrc_t grp_rsrc = granule_rsrc(grp_gran, (unsigned)(kIcpExchangeGroups * 2 * kIcpSums * sizeof(unsigned long long)));
         // poll one granule pair until both halves carry this iteration's tag; false: gave up (bounded spin, or another
         // workgroup has already raised the timeout)
         auto poll_pair = [&](const __amdgpu_buffer_rsrc_t &r, unsigned off, double &out) -> bool {
