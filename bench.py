@@ -280,6 +280,11 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = multistream.init_process_group(args.backend) if world > 1 else None
     comm_device = device if args.backend == "nccl" else None  # gloo exchanges host tensors
+    if args.device >= 0 and world > 1:
+        # ranks stacked on ONE GPU (a plumbing run): the persistent registrations of different PROCESSES are ordered by nobody
+        # (the launch gate is per process), so each rank takes 1 / world of the co-resident workgroups and all of them fit
+        # side by side -- with full grids two ranks wait for each other's workgroups until one gives up (KICP_ERR_TIMEOUT)
+        _cabi.set_option("icp_device_streams", min(world, 8))
     for kv in args.opt:
         name, value = kv.split("=")
         _cabi.set_option(name, int(value))
