@@ -194,7 +194,10 @@ int kicp_pipeline_register_frame_outputs(kicp_pipeline *p, const double *xyz, si
                                          double *src_out, size_t src_cap, size_t *n_src);
 /* ... for hosts that build their own containers from the result (std::vector's range constructor, a JNI array
  * copy): the two clouds stay in pinned host memory OWNED BY THE PIPELINE and *pre_view / *src_view point into it,
- * valid until the next call on this pipeline.  One copy fewer than the entry above. */
+ * valid until the next kicp_pipeline_register_frame_outputs / _views, kicp_pipeline_output or kicp_pipeline_destroy on this
+ * pipeline -- the only entries that write or reallocate that memory.  The getters (kicp_pipeline_pose, _delta,
+ * _last_stats, _host_stats, _synced_poses, _map) leave it alone: a wrapper may read the pose before it copies the
+ * clouds out, as kiss_icp::pipeline::KissICP::RegisterFrame in kiss-icp_amd/cpp does.  One copy fewer than the entry above. */
 int kicp_pipeline_register_frame_views(kicp_pipeline *p, const double *xyz, size_t n,
                                        const double *timestamps, size_t n_timestamps,
                                        const double **pre_view, size_t *n_pre,

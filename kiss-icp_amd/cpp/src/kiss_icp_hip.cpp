@@ -329,10 +329,12 @@ KissICP::Vector3dVectorTuple KissICP::RegisterFrame(PointSpan frame, const doubl
     check(kicp_pipeline_register_frame_views(handle_, frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps, &pre,
                                              &n_pre, &src, &n_src),
           "KissICP::RegisterFrame");
-    CollectState();
+    // (the vectors first, the getters after: the views are only promised until the next call that stages an output)
     const auto *p3 = reinterpret_cast<const Eigen::Vector3d *>(pre);
     const auto *s3 = reinterpret_cast<const Eigen::Vector3d *>(src);
-    return {Vector3dVector(p3, p3 + n_pre), Vector3dVector(s3, s3 + n_src)};  // KissICP.cpp:67
+    Vector3dVectorTuple out{Vector3dVector(p3, p3 + n_pre), Vector3dVector(s3, s3 + n_src)};  // KissICP.cpp:67
+    CollectState();
+    return out;
 }
 
 KissICP::Vector3dVectorTuple KissICP::RegisterFrameDevice(const double *d_xyz, std::size_t n, const double *d_timestamps,
