@@ -370,6 +370,11 @@ int kicp_device_synchronize(int device_id);
  * compared with the oracle's on the same inputs -- pivot order, zero-pivot rule and all -- without a registration
  * around it (tests/test_gpu_paths.py). */
 int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t n, double *x);
+/* Device self-test: the spatial order k_icp takes its runs from (kicp_sort.hip) -- keys[i] = {30-bit Morton code of the
+ * 2-voxel cell of a point << 24 | index of the point}, ascending, for the n points of xyz, computed as the pipeline
+ * computes it: the count lives on the device, the host knows only a bound (n_bound >= n, at most 2^24) and a hint (n_hint,
+ * 0 = none) that decides how the sorted runs of 2048 keys are merged -- never the result. */
+int kicp_selftest_tile_sort(int device_id, const double *xyz, size_t n, double voxel_size, size_t n_hint, size_t n_bound, uint64_t *keys);
 /* Host self-test (no device needed): the float64 -> float32 narrowing the host-input entries apply to a scan before
  * its upload (option "staging_f32").  dst receives the narrowed values; *exact = 1 iff every value survives the
  * round trip, which is the only case in which a scan travels as float32 (one NaN, one value with more than 24

@@ -907,7 +907,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         const size_t tb = tile_sort_temp_bytes(n);
         KICP_TRY(r->sort_tmp.reserve(tb));
         const int se = launch_tile_sort(r->frame.as<double>(), nullptr, (int)n, n, map->voxel_size, r->sort_in.as<unsigned long long>(),
-                                        r->sort_out.as<unsigned long long>(), r->sort_tmp.p, r->sort_tmp.bytes, r->stream);
+                                        r->sort_out.as<unsigned long long>(), n, r->stream);
         if (se != 0) {
             set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
             return KICP_ERR_HIP;
@@ -1551,8 +1551,9 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // --- spatial order of the source cloud: the ICP kernel hands every workgroup a compact patch of it ----
     const bool sorted = n <= ((size_t)1 << 24);
     if (sorted && n) {
+        // (how many points there will be is known on the device only; the previous frame's count says how to merge the sorted runs)
         const int se = launch_tile_sort(p->src[par].as<double>(), &prep->n_src, 0, n, c.voxel_size, p->sort_in.as<unsigned long long>(),
-                                        p->sort_out[par].as<unsigned long long>(), p->sort_tmp.p, p->sort_tmp_bytes, sp);
+                                        p->sort_out[par].as<unsigned long long>(), p->have_last ? (size_t)p->last.st.n_src : n / 8, sp);
         if (se != 0) {
             set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
             return KICP_ERR_HIP;
@@ -2446,6 +2447,30 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
     if (!exact) return KICP_ERR_INVALID_ARG;
     *exact = narrow_exact(src, dst, count) ? 1 : 0;
     return KICP_OK;
+}
+
+int kicp_selftest_tile_sort(int device_id, const double *xyz, size_t n, double voxel_size, size_t n_hint, size_t n_bound, uint64_t *keys) {
+    if ((n && !xyz) || (n && !keys) || !(voxel_size > 0.0) || n_bound < n || n_bound > ((size_t)1 << 24)) return KICP_ERR_INVALID_ARG;
+    KICP_TRY(check_device(device_id));
+    if (n == 0) return KICP_OK;
+    DevBuf pts, a, b, cnt;
+    int s = pts.reserve(n * 3 * sizeof(double));
+    if (s == KICP_OK) s = a.reserve(n_bound * sizeof(unsigned long long));
+    if (s == KICP_OK) s = b.reserve(n_bound * sizeof(unsigned long long));
+    if (s == KICP_OK) s = cnt.reserve(sizeof(int));
+    const int n_i = (int)n;
+    if (s == KICP_OK && (hipMemcpy(pts.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                         hipMemcpy(cnt.p, &n_i, sizeof n_i, hipMemcpyHostToDevice) != hipSuccess))
+        s = KICP_ERR_HIP;
+    // as the pipeline calls it: the count on the device, the host knows a bound and a hint
+    if (s == KICP_OK && launch_tile_sort(pts.as<double>(), cnt.as<int>(), 0, n_bound, voxel_size, a.as<unsigned long long>(), b.as<unsigned long long>(), n_hint, nullptr) != 0)
+        s = KICP_ERR_HIP;
+    if (s == KICP_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(keys, b.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)) s = KICP_ERR_HIP;
+    pts.release();
+    a.release();
+    b.release();
+    cnt.release();
+    return s;
 }
 
 int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t n, double *x) {

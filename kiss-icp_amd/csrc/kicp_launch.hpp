@@ -61,11 +61,11 @@ struct DsParams {
     int *err;
 };
 
-// spatial order of the source cloud (kicp_sort.hip): keys = {Morton code of the 2-voxel cell, index}, radix-sorted
+// spatial order of the source cloud (kicp_sort.hip): keys = {Morton code of the 2-voxel cell, index}, sorted runs merged by rank
 size_t tile_sort_temp_bytes(size_t n_max);
 int tile_sort_prepare(int device_id);  // LDS opt-in of the block sort, once per device
 int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_max, double voxel_size, unsigned long long *keys_in,
-                     unsigned long long *keys_out, void *temp, size_t temp_bytes, hipStream_t s);
+                     unsigned long long *keys_out, size_t n_hint, hipStream_t s);
 int icp_prepare(int device_id);
 int icp_blocks_per_cu(int lds_bytes);
 void launch_selftest_solve(const double *A, const double *b, int n, double *x, hipStream_t s);  // co-resident k_icp workgroups per CU (occupancy query, current device)

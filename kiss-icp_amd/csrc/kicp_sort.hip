@@ -10,9 +10,10 @@
 // The sort sorts what EXISTS: the cloud has a few thousand points (N_src, known on the device only), the scan it came
 // from 130 k.  A library radix sort sized by the host-side bound spent ~70 us in nine launches ordering 126 k padding
 // keys (round 2).  Here: k_tile_sort_blocks computes the keys and sorts runs of 2048 of them in LDS (bitonic network,
-// in place, one workgroup per run; workgroups beyond N_src leave at once), and k_tile_merge_runs merges ALL runs in one
-// step by rank: position = rank in the own run + number of smaller keys in every other run (binary searches; the keys
-// are unique).  The result is THE ascending order of the keys, whatever produced it.
+// in place, one workgroup per run; workgroups beyond N_src leave at once), and k_tile_merge_runs merges the runs by
+// rank: position = rank in the own run + number of smaller keys in every other run of its group (binary searches; the keys
+// are unique) -- all runs in one step when they are few, eight at a time first when they are many.  The result is THE
+// ascending order of the keys, whatever produced it.
 #include <cstring>
 #include <mutex>
 
@@ -81,20 +82,30 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort_blocks(const double 
     for (int i = threadIdx.x; i < cnt; i += kSortThreads) out[first + i] = skeys[i];
 }
 
-// all runs merged in one step: a key's final position = its rank in its own run + the number of smaller keys in every
-// other run (a binary search each; the keys are unique).  A few runs for a full-size-voxel scan, tens for a 1M-point one.
-__global__ __launch_bounds__(256) void k_tile_merge_runs(const unsigned long long *runs, unsigned long long *out, const int *n_ptr, int n_imm) {
+// A merge PASS by rank: the keys come as sorted runs of run_len (the last one shorter); consecutive runs are merged in
+// groups of `fan` (0: all of them in one group): a key's position = the group's start + its rank in its own run + the
+// number of smaller keys in every other run of the group (a binary search each; the keys are unique).  A group of one
+// run is copied.  With fan = 0 and run_len = kSortRun this is "all runs in one step" -- right for the few runs of a
+// full-size-voxel scan (3 runs: two searches per key); its cost grows as n x runs x log, so a cloud of many runs
+// (the 1M-point configuration: 46; the entry admits 8192) is first merged eight runs at a time: launch_tile_sort.
+__global__ __launch_bounds__(256) void k_tile_merge_runs(const unsigned long long *runs, unsigned long long *out, const int *n_ptr, int n_imm,
+                                                         int run_len, int fan) {
     const int n = n_ptr ? *n_ptr : n_imm;
-    if (n <= kSortRun) return;  // a single run: k_tile_sort_blocks has already written it to `out`
-    const int n_runs = (n + kSortRun - 1) / kSortRun;
+    if (n <= kSortRun) return;  // a single run: k_tile_sort_blocks has already written it to the final buffer
+    const int n_runs = (n + run_len - 1) / run_len;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long key = runs[i];
-        const int own = i / kSortRun;
-        int pos = i - own * kSortRun;
-        for (int r = 0; r < n_runs; ++r) {
+        const int own = i / run_len;
+        const int g0 = fan > 0 ? (own / fan) * fan : 0, g1 = fan > 0 ? min(g0 + fan, n_runs) : n_runs;
+        int pos = g0 * run_len + (i - own * run_len);
+        // (the searches one after the other.  Eight runs in lock step -- one load per run in flight instead of a chain of
+        // 7 x 11 -- measured SLOWER: 156 + 55 us against 120 + 18 for the two passes of the 1M-point configuration, 8 - 12
+        // against 6 - 7 us on the bench scene, profiles/r04_ax_*: the merge runs beside k_map_prune, which keeps the memory
+        // system saturated, and more requests in flight buy nothing there)
+        for (int r = g0; r < g1; ++r) {
             if (r == own) continue;
-            const int r0 = r * kSortRun;
-            int lo = 0, hi = min(kSortRun, n - r0);
+            const int r0 = r * run_len;
+            int lo = 0, hi = min(run_len, n - r0);
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (runs[r0 + mid] < key) lo = mid + 1;
@@ -110,16 +121,33 @@ size_t tile_sort_temp_bytes(size_t) { return 256; }  // (the sort needs no scrat
 
 int tile_sort_prepare(int) { return 0; }  // (the block sort's 16 KiB of LDS need no opt-in)
 
-// sorted keys of the cloud -> keys_out; keys_in holds the sorted runs in between (both hold n_max keys)
+// sorted keys of the cloud -> keys_out; keys_in is the other buffer of the merge passes (both hold n_max keys).
+// n_hint: about how many points there will be (the previous frame's count; 0: unknown -> n_max): it only decides HOW the
+// runs are merged -- passes of fan-in 8 first when there are many, and a last pass that merges whatever is left all
+// against all, so a wrong hint costs time, never the order.
 int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_max, double voxel_size, unsigned long long *keys_in,
-                     unsigned long long *keys_out, void *, size_t, hipStream_t s) {
+                     unsigned long long *keys_out, size_t n_hint, hipStream_t s) {
     if (n_max == 0) return 0;
     if (n_max > ((size_t)1 << 24)) return (int)hipErrorInvalidValue;  // 24 index bits
     const int runs = (int)((n_max + kSortRun - 1) / kSortRun);
-    hipLaunchKernelGGL(k_tile_sort_blocks, dim3(runs), dim3(kSortThreads), 0, s, xyz, n_ptr, n_imm, 1.0 / (2.0 * voxel_size), keys_in, keys_out);
+    if (n_hint == 0 || n_hint > n_max) n_hint = n_max;
+    const size_t runs_hint = (n_hint + n_hint / 4 + kSortRun - 1) / kSortRun + 1;
+    int passes = 1;
+    for (size_t cover = 12; runs_hint > cover && passes < 6; cover *= 8) ++passes;  // (the last pass takes ~a dozen runs gladly)
+    unsigned long long *a = (passes & 1) ? keys_in : keys_out, *b = (passes & 1) ? keys_out : keys_in;  // ... so that the last pass ends in keys_out
+    hipLaunchKernelGGL(k_tile_sort_blocks, dim3(runs), dim3(kSortThreads), 0, s, xyz, n_ptr, n_imm, 1.0 / (2.0 * voxel_size), a, keys_out);
     if (runs > 1) {
         const int grid = (int)((n_max + 255) / 256 < 2048 ? (n_max + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_tile_merge_runs, dim3(grid), dim3(256), 0, s, keys_in, keys_out, n_ptr, n_imm);
+        long run_len = kSortRun;
+        for (int k = 1; k <= passes; ++k) {
+            // (run_len beyond n: one run, the pass copies)
+            const int rl = (int)(run_len < ((long)1 << 24) ? run_len : ((long)1 << 24));
+            hipLaunchKernelGGL(k_tile_merge_runs, dim3(grid), dim3(256), 0, s, a, b, n_ptr, n_imm, rl, k == passes ? 0 : 8);
+            unsigned long long *t = a;
+            a = b;
+            b = t;
+            run_len *= 8;
+        }
     }
     return (int)hipGetLastError();
 }

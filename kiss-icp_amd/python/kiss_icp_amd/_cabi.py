@@ -131,6 +131,7 @@ SIGNATURES = {
     "kicp_device_download": [_i, _vp, _vp, _sz],
     "kicp_device_synchronize": [_i],
     "kicp_selftest_solve": [_i, _vp, _vp, _sz, _vp],
+    "kicp_selftest_tile_sort": [_i, _vp, _sz, C.c_double, _sz, _sz, _vp],
     "kicp_selftest_narrow": [_vp, _sz, _vp, C.POINTER(_i)],
     "kicp_batch_unique_id": [_vp],
     "kicp_batch_create": [C.POINTER(Config), C.POINTER(_i), _i, _i, _i, _vp, _vp, _sz, C.POINTER(_vp)],

@@ -563,6 +563,40 @@ def test_thread_per_query_form_in_the_pipeline(gpu, O):
     assert poses[0][1:] == poses[1][1:]
 
 
+def _morton_keys(xyz, voxel):
+    """kicp_sort.hip: tile_key -- {30-bit Morton code of the point's 2-voxel cell, +-512 cells around the origin, clamped} << 24 | index"""
+    c = np.clip(np.floor(xyz * (1.0 / (2.0 * voxel))) + 512.0, 0.0, 1023.0).astype(np.uint64)
+
+    def spread(v):
+        v = v & np.uint64(0x3FF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x030000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x0300F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x030C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x09249249)
+        return v
+
+    m = spread(c[:, 0]) | (spread(c[:, 1]) << np.uint64(1)) | (spread(c[:, 2]) << np.uint64(2))
+    return (m << np.uint64(24)) | np.arange(len(xyz), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n", [1, 2047, 2048, 2049, 5000, 16384, 16385, 40000, 150000, 300000])
+def test_spatial_order_of_the_source_cloud(gpu, n):
+    """the order k_icp takes its runs from: sorted runs of 2048 keys merged by rank -- all at once when they are few,
+    eight at a time first when they are many (which of the two is decided by a HINT of the count, the previous
+    frame's; the count itself is on the device).  Whatever the hint and the host-side bound: THE ascending order of
+    the keys, which are those of a numpy restatement."""
+    from kiss_icp_amd import _cabi
+
+    rng = np.random.default_rng(n)
+    xyz = np.ascontiguousarray(rng.uniform(-60.0, 60.0, (n, 3)) * np.array([1.0, 1.0, 0.1]))
+    want = np.sort(_morton_keys(xyz, 0.5))
+    assert len(np.unique(want)) == n
+    for hint, bound in ((0, n), (n, n), (max(1, n // 20), n), (min(20 * n, 1 << 24), min(4 * n + 7, 1 << 24)), (n, min(8 * n, 1 << 24))):
+        got = np.zeros(n, dtype=np.uint64)
+        _cabi.check(_cabi.lib().kicp_selftest_tile_sort(0, _cabi.ptr(xyz), n, 0.5, hint, bound, _cabi.ptr(got)))
+        assert np.array_equal(got, want), (n, hint, bound)
+
+
 # ---- robustness ---------------------------------------------------------------------------------------------
 def test_two_pipelines_on_one_gpu_from_two_threads(gpu, O):
     """two LiDAR streams, two pipelines, two host threads, ONE GPU: the persistent registration kernels of the
