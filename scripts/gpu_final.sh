@@ -4,6 +4,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export KICP_BENCH_SUPERVISE=0  # (bench.py measures in this process: rocprofv3 and the tails below look at one process)
 T="${TAG:-r04_final}"
 O=gpurun_out
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 ) > $O/${T}_smoke.log
