@@ -320,8 +320,33 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
         BlockHdr *hdr = block_hdr(m, b);
         if (hdr->count <= 0) continue;
         const double2 p0 = block_xy(m, b)[0];
-        const double dx = p0.x - ox, dy = p0.y - oy, dz = block_z(m, b)[0] - oz;
-        if ((dx * dx + dy * dy) + dz * dz >= md2) {
+        const double dx = p0.x - ox, dy = p0.y - oy;
+        const double a = dx * dx + dy * dy;
+        // The header and xy[0] share the block's first cache line, z[0] lies in another.  The key says which layer of voxels z[0]
+        // is in: floor(fl(z / v)) == vz puts z into [vz v, (vz + 1) v] up to a few units in the last place (the slack below is
+        // 2^-48 of the magnitudes, as in kicp_icp_wide.hpp: wide_gaps), subtraction and the sum below are monotone under
+        // rounding, so dz = fl(z - oz) lies in [lo, hi] and the test's left-hand side between the two sums formed from the
+        // smallest and the largest |dz| -- when both fall on the same side of max_distance^2, as they do for all but a thin
+        // shell of voxels, the verdict is the reference's without z ever being read: half the kernel's traffic (the prune of a
+        // 2.4 M-voxel map read 283 MB, 0.2 - 0.3 ms, profiles/r04_final2_*).
+        bool dies;
+        {
+            int vx, vy, vz;
+            unpack_voxel(hdr->key, vx, vy, vz);
+            const double f0 = (double)vz * m.voxel_size, f1 = (double)(vz + 1) * m.voxel_size;
+            const double slack = (fabs(f0) + fabs(f1)) * 0x1p-48 + DBL_MIN;
+            const double lo = (f0 - slack) - oz, hi = (f1 + slack) - oz;
+            const double d_far = fmax(fabs(lo), fabs(hi)), d_near = (lo <= 0.0 && hi >= 0.0) ? 0.0 : fmin(fabs(lo), fabs(hi));
+            if (a + d_far * d_far < md2) {
+                dies = false;
+            } else if (a + d_near * d_near >= md2) {
+                dies = true;
+            } else {
+                const double dz = block_z(m, b)[0] - oz;
+                dies = a + dz * dz >= md2;  // VoxelHashMap.cpp:126-128
+            }
+        }
+        if (dies) {
             Slot *sl = m.slots + hdr->slot;
             sl->key = kKeyTomb;
             sl->block = -1;

@@ -186,6 +186,34 @@ def test_map_update_and_prune(gpu, O):
     assert g.empty() and len(g.point_cloud()) == 0
 
 
+@pytest.mark.parametrize("voxel,max_dist", [(1.0, 100.0), (0.1, 20.0), (0.5, 37.3)])
+def test_prune_decides_the_shell_like_the_reference(gpu, O, voxel, max_dist):
+    """RemovePointsFarFromLocation (VoxelHashMap.cpp:121-132): a voxel dies iff its FIRST point is at least max_distance from
+    the origin, decided on squared norms.  The device settles most voxels from the first point's x, y and the voxel's
+    z-layer alone (k_map_prune) and reads z only in the shell where that cannot decide: points at max_distance exactly, a
+    few ulps / 1e-12 / ... either side, steep and flat directions, origins off the lattice -- the same voxels must die."""
+    rng = np.random.default_rng(int(voxel * 100 + max_dist))
+    g, o = _maps(O, voxel=voxel, max_dist=max_dist)
+    n = 6000
+    d = rng.normal(size=(n, 3))
+    d[:, 2] *= rng.choice([0.02, 0.3, 1.0, 3.0], n)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    eps = rng.choice([0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-12, -1e-12, 1e-9, -1e-9, 1e-6, -1e-6, 1e-3, -1e-3, 0.02, -0.02, 0.3, -0.3], n)
+    origin = rng.uniform(-3.0, 3.0, 3)
+    pts = origin + d * (max_dist * (1.0 + eps))[:, None]
+    g.add_points(pts)
+    o.add_points(pts)
+    assert g.num_voxels() == o.num_voxels() > n // 2
+    g.remove_far_away_points(origin)
+    o.remove_far_away_points(origin)
+    assert 0 < o.num_voxels() < n and g.num_voxels() == o.num_voxels()
+    assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud()))
+    shifted = origin + np.array([0.37 * voxel, -0.11 * voxel, 0.73 * voxel])  # the same shell seen from next door
+    g.remove_far_away_points(shifted)
+    o.remove_far_away_points(shifted)
+    assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud()))
+
+
 def test_map_copy_is_an_independent_map(gpu, O):
     """the reference's VoxelHashMap is a copyable value type (VoxelHashMap.hpp:38-57): kicp_map_clone / VoxelHashMap.copy()
     give a second device map with the same voxels and points, which neither follows nor disturbs the original -- also
