@@ -27,9 +27,15 @@
 //      a face neighbour) always -- it gives a distance to skip by --, then at most four voxels / 24 points in all.  What
 //      survives beyond that (in dense surroundings a query that floats beside a surface keeps ten voxels of twenty
 //      points; its 63 neighbours in the wave would wait for it: 52 us per iteration in such workgroups,
-//      profiles/r04_d_icp_probe_livox.txt) is filed as {query, voxel} items in two queues in LDS and served by the
-//      32-lane groups: lane i point i, six voxels in flight -- voxels in the LDS store, and voxels the store had no room
-//      for (kTileGlobal: read from the map in HBM / L2); the owners merge the answers.
+//      profiles/r04_d_icp_probe_livox.txt) is filed as {query, voxel} items in two queues in LDS -- voxels in the LDS
+//      store, and voxels the store had no room for (kTileGlobal: read from the map in HBM / L2) -- and served by the
+//      whole workgroup, a thread per POINT of all queued voxels (wide_serve_flat; a 32-lane group per item, six in
+//      flight, was 22 us per round); the owners merge the answers;
+//   4. most iterations most queries need NO search: the last search left a lower bound of the distance to every point
+//      but the neighbour (the runner-up, or the bound of a cell that was not read), the query has moved by so much
+//      since, and while the neighbour's new distance stays strictly below the difference it is still the reference's
+//      answer (WideQuery::Lr).  The 10 - 30 queries of a workgroup that do need one are then searched by a 32-lane
+//      group each, with the same skipping (wide_group_scan): the queues' fixed costs are for the first iteration or two.
 // Queries the tile cannot serve (outside the key span, table full) and queries of runs longer than one chunk go
 // through a small queue served by the 32-lane groups with the map-direct search of the first form (closest_neighbor_any).
 // The partition of the cloud (runs), the order in which products are added (phase C) and the exchange are those of
