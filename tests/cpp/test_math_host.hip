@@ -108,6 +108,87 @@ int main() {
         ldlt6_solve(Z, bz, x);  // empty correspondence set: JTJ = 0 -> dx = 0 (Registration.cpp:156)
         for (int i = 0; i < 6; ++i) CHECK(x[i] == 0.0);
     }
+    // 5. schur3_solve: the Gauss-Newton step of Registration.cpp:80-121,156 through the 3 x 3 Schur complement of its
+    //    normal equations -- against ldlt6_solve on the SAME sixteen sums, formed as k_icp's phase C forms them, for
+    //    clouds of every shape an odometry frame takes (room, corridor, slab; tens to thousands of correspondences,
+    //    coordinates up to a kilometre from the origin); and the systems it must REFUSE: no correspondence, one point,
+    //    points on a line through the origin (rank 4) -- those go to the LDLT and its zero-pivot rule.
+    {
+        auto sums = [&](int n, const double ext[3], const double off[3], double noise, double S[16]) {
+            for (int k = 0; k < 16; ++k) S[k] = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double s[3] = {off[0] + ext[0] * n01(gen), off[1] + ext[1] * n01(gen), off[2] + ext[2] * n01(gen)};
+                const double r[3] = {noise * n01(gen), noise * n01(gen), noise * n01(gen)};
+                const double r2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2], ks = 0.3;
+                const double w = (ks * ks) / ((ks + r2) * (ks + r2));
+                const double T[16] = {w, w * s[0], w * s[1], w * s[2], w * (s[1] * s[1] + s[2] * s[2]), w * (-(s[0] * s[1])), w * (-(s[0] * s[2])),
+                                      w * (s[0] * s[0] + s[2] * s[2]), w * (-(s[1] * s[2])), w * (s[0] * s[0] + s[1] * s[1]), w * r[0], w * r[1], w * r[2],
+                                      w * (s[1] * r[2] - s[2] * r[1]), w * (s[2] * r[0] - s[0] * r[2]), w * (s[0] * r[1] - s[1] * r[0])};
+                for (int k = 0; k < 16; ++k) S[k] += T[k];
+            }
+        };
+        auto by_ldlt = [&](const double S[16], double x[6]) {
+            double J[36] = {0}, nb[6];
+            J[0] = J[7] = J[14] = S[0];
+            J[0 * 6 + 4] = J[4 * 6 + 0] = S[3];
+            J[0 * 6 + 5] = J[5 * 6 + 0] = -S[2];
+            J[1 * 6 + 3] = J[3 * 6 + 1] = -S[3];
+            J[1 * 6 + 5] = J[5 * 6 + 1] = S[1];
+            J[2 * 6 + 3] = J[3 * 6 + 2] = S[2];
+            J[2 * 6 + 4] = J[4 * 6 + 2] = -S[1];
+            J[3 * 6 + 3] = S[4];
+            J[3 * 6 + 4] = J[4 * 6 + 3] = S[5];
+            J[3 * 6 + 5] = J[5 * 6 + 3] = S[6];
+            J[4 * 6 + 4] = S[7];
+            J[4 * 6 + 5] = J[5 * 6 + 4] = S[8];
+            J[5 * 6 + 5] = S[9];
+            for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+            ldlt6_solve(J, nb, x);
+        };
+        const double shapes[4][3] = {{20, 20, 3}, {60, 4, 2}, {30, 30, 0.05}, {2, 2, 2}};
+        int taken = 0, refused = 0;
+        double worst = 0.0;
+        for (int trial = 0; trial < 4000; ++trial) {
+            const double *ext = shapes[trial & 3];
+            const double far = (trial % 5 == 0) ? 1000.0 : ((trial % 7 == 0) ? 100.0 : 0.0);
+            const double off[3] = {far * n01(gen), far * n01(gen), 0.1 * far * n01(gen)};
+            const int n = 30 + (trial * 37) % 4000;
+            double S[16], xs[6], xl[6];
+            sums(n, ext, off, (trial & 8) ? 0.3 : 0.02, S);
+            by_ldlt(S, xl);
+            if (!schur3_solve(S, xs)) {  // (a slab seen from a kilometre away may be refused: that is what the guard is for)
+                ++refused;
+                continue;
+            }
+            ++taken;
+            double nl = 0.0, nd = 0.0;
+            for (int i = 0; i < 6; ++i) {
+                nl += xl[i] * xl[i];
+                nd += (xs[i] - xl[i]) * (xs[i] - xl[i]);
+            }
+            const double rel = std::sqrt(nd) / std::fmax(std::sqrt(nl), 1e-300);
+            worst = std::fmax(worst, rel);
+            // two stable eliminations of the same SPD system: they differ by rounding amplified by the condition number; the
+            // guard (pivots above 1e-9 of the largest diagonal entry) keeps that far below the convergence threshold's 1e-4
+            CHECK(rel < 1e-6);
+        }
+        std::printf("schur3_solve: %d systems taken (largest relative difference to the LDLT %.3g), %d refused\n", taken, worst, refused);
+        CHECK(taken > 3000);
+        double S[16] = {0}, x[6] = {9, 9, 9, 9, 9, 9};
+        CHECK(!schur3_solve(S, x) && x[0] == 9);  // no correspondence
+        const double one_ext[3] = {0, 0, 0}, one_off[3] = {3, -2, 1};
+        sums(1, one_ext, one_off, 0.1, S);
+        CHECK(!schur3_solve(S, x));  // one point: the rotation about the ray to it is free
+        for (int k = 0; k < 16; ++k) S[k] = 0.0;
+        for (int i = 1; i <= 50; ++i) {  // points on a line through the origin: rank 4
+            const double s[3] = {0.3 * i, -0.2 * i, 0.1 * i}, r[3] = {0.01, -0.02, 0.005}, w = 1.0;
+            const double T[16] = {w, w * s[0], w * s[1], w * s[2], w * (s[1] * s[1] + s[2] * s[2]), w * (-(s[0] * s[1])), w * (-(s[0] * s[2])),
+                                  w * (s[0] * s[0] + s[2] * s[2]), w * (-(s[1] * s[2])), w * (s[0] * s[0] + s[1] * s[1]), w * r[0], w * r[1], w * r[2],
+                                  w * (s[1] * r[2] - s[2] * r[1]), w * (s[2] * r[0] - s[0] * r[2]), w * (s[0] * r[1] - s[1] * r[0])};
+            for (int k = 0; k < 16; ++k) S[k] += T[k];
+        }
+        CHECK(!schur3_solve(S, x));
+    }
     std::printf(failures ? "%d check(s) FAILED\n" : "all checks passed\n", failures);
     return failures != 0;
 }
