@@ -165,3 +165,44 @@ def test_flat_service_settles_an_item_like_the_references_walk():
         arg, best = _reference_search(pts, range(n), s)
         assert k == arg and d[k] == best
         assert runner >= best and (len(others) == 0 or runner == sorted(d)[1])
+
+
+def test_prune_verdict_from_the_z_layer_is_the_plain_test():
+    """k_map_prune (kicp_map.hip): RemovePointsFarFromLocation's test (dx^2 + dy^2) + dz^2 >= max_distance^2 on a voxel's first
+    point, decided from x, y and the LAYER of voxels z lies in wherever the layer's nearest and farthest |dz| give the same
+    answer -- restated here; whenever it decides without z, the plain test on the real z must say the same.  Points at
+    max_distance to the last bit either side, z on layer faces to the last bit, steep and flat directions."""
+    rng = np.random.default_rng(5)
+    decided = undecided = 0
+    for vs, md in ((1.0, 100.0), (0.1, 20.0), (0.5, 37.3), (0.3, 250.0), (2.5, 100.0)):
+        n = 60000
+        d = rng.normal(size=(n, 3))
+        d[:, 2] *= rng.choice([0.01, 0.1, 1.0, 5.0], n)
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        eps = rng.choice([0.0, 1e-16, -1e-16, 2e-16, -2e-16, 1e-15, -1e-15, 1e-12, -1e-12, 1e-8, -1e-8, 1e-4, -1e-4, 0.01, -0.01, 0.5, -0.5], n)
+        origin = rng.uniform(-500.0, 500.0, 3) * rng.choice([0.0, 0.01, 1.0])
+        p = origin + d * (md * (1.0 + eps))[:, None]
+        # a third of the points: z moved onto a face of its layer, or a few ulps beside it
+        on_face = rng.random(n) < 0.33
+        face = (np.floor(p[:, 2] / vs) + rng.integers(0, 2, n)) * vs
+        for _ in range(3):
+            face = np.where(rng.random(n) < 0.5, np.nextafter(face, np.inf), np.nextafter(face, -np.inf))
+        p[:, 2] = np.where(on_face, face, p[:, 2])
+        vz = np.floor(p[:, 2] / vs)  # the layer PointToVoxel puts z in (the key's third component)
+        dx, dy = p[:, 0] - origin[0], p[:, 1] - origin[1]
+        a = dx * dx + dy * dy
+        md2 = md * md
+        f0, f1 = vz * vs, (vz + 1.0) * vs
+        slack = (np.abs(f0) + np.abs(f1)) * 2.0 ** -48 + DBL_MIN
+        lo, hi = (f0 - slack) - origin[2], (f1 + slack) - origin[2]
+        d_far = np.maximum(np.abs(lo), np.abs(hi))
+        d_near = np.where((lo <= 0.0) & (hi >= 0.0), 0.0, np.minimum(np.abs(lo), np.abs(hi)))
+        keeps = a + d_far * d_far < md2
+        dies = ~keeps & (a + d_near * d_near >= md2)
+        dz = p[:, 2] - origin[2]
+        plain = a + dz * dz >= md2
+        assert np.all((lo <= dz) & (dz <= hi))  # the interval really contains fl(z - oz)
+        assert not np.any(plain[keeps]) and np.all(plain[dies])
+        decided += int(keeps.sum() + dies.sum())
+        undecided += int((~keeps & ~dies).sum())
+    assert decided > 50000 and undecided > 50000, (decided, undecided)  # (both roads taken: most of these points sit in the shell on purpose)
