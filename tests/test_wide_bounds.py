@@ -206,3 +206,46 @@ def test_prune_verdict_from_the_z_layer_is_the_plain_test():
         decided += int(keeps.sum() + dies.sum())
         undecided += int((~keeps & ~dies).sum())
     assert decided > 50000 and undecided > 50000, (decided, undecided)  # (both roads taken: most of these points sit in the shell on purpose)
+
+
+def test_flat_service_index_arithmetic():
+    """wide_serve_flat's integer part, restated: prefix sums of the items' point counts, passes of whole items with at most
+    2048 points found by descending powers of two, and each point's item found the same way (the last item that starts at
+    or before the point; items without points are passed over).  Every point of every item is visited exactly once, by the
+    (item, index) pair the kernel would compute."""
+    rng = np.random.default_rng(3)
+    per_pass = 4 * 512
+    for trial in range(300):
+        n = int(rng.integers(1, 487))
+        cnt = rng.integers(0, 21, n) if trial % 3 else rng.choice([0, 1, 20, 63], n)
+        start = np.concatenate([[0], np.cumsum(cnt)])
+        seen = [np.zeros(c, dtype=int) for c in cnt]
+        lo = 0
+        passes = 0
+        while lo < n:
+            p_lo = start[lo]
+            hi = lo + 1
+            step = 256
+            while step:
+                c = hi + step
+                if c <= n and start[c] - p_lo <= per_pass:
+                    hi = c
+                step >>= 1
+            assert hi == n or start[hi + 1] - p_lo > per_pass  # as many whole items as fit
+            assert start[hi] - p_lo <= per_pass or hi == lo + 1
+            for r in range(start[hi] - p_lo):
+                p = p_lo + r
+                x = lo
+                step = 256
+                while step:
+                    c = x + step
+                    if c < hi and start[c] <= p:
+                        x = c
+                    step >>= 1
+                idx = p - start[x]
+                assert 0 <= idx < cnt[x], (trial, p, x)
+                seen[x][idx] += 1
+            lo = hi
+            passes += 1
+        assert all((s == 1).all() for s in seen)
+        assert passes <= (start[-1] + per_pass - 1) // per_pass + n // 32 + 1
