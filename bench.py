@@ -368,7 +368,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_icp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload),
-            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, a separate run of this command; null = not collected for this workload)",
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this workload -- kitti: 60 + 10 frames, livox: 30 + 4 --, corrected by a 1 GiB calibration copy on the same box; null = not collected for this workload)",
             "bytes_per_launch": icp["algorithmic_bytes"] / max(1, icp["launches"]),
             "ms_per_launch": icp["total_ms"] / max(1, icp["launches"]),
         }
