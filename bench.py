@@ -429,33 +429,6 @@ def main():
         for f in host[W:W + K]:
             ko.register_frame(*f)  # returns (preprocessed frame, source) as numpy arrays
         rate_out = K / (time.perf_counter() - t)
-        # (d) batch mode folded onto this ONE GPU (BASELINE configs[3]; option "icp_device_streams"): S streams, each with
-        #     1 / S of the persistent registration grid, registering side by side; driven through the C-ABI's batch entry
-        #     (a worker thread per stream inside libkicp.so; a host communicator, since RCCL refuses two ranks on a device).
-        #     Every stream runs the same K frames.  The headline `value` stays the single stream's.
-        out["batch_on_one_gpu"] = {}
-        for S in (2, 4):
-            try:
-                comm = host_communicator(S, local_rank)
-                batch = multistream.StreamBatch(load_config(**cfg_over), [local_rank] * S, comm=comm)
-                for f in host[:W]:
-                    batch.register_frames([f[0]] * S, [f[1]] * S)
-                batch.sync()
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for f in host[W:W + K]:
-                    batch.register_frames([f[0]] * S, [f[1]] * S)
-                batch.sync()
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t
-                pb = [batch.poses(r)[-1] for r in range(S)]
-                out["batch_on_one_gpu"][f"streams{S}"] = {
-                    "aggregate_scans_per_s": S * K / dt, "per_stream_scans_per_s": K / dt, "vs_single_stream": S * K / dt / out["value"],
-                    "streams_agree": bool(all((q == pb[0]).all() for q in pb)),
-                    "note": "every stream registers with 1/%d of the workgroups: its poses are those of a lone pipeline with that share, not bitwise the headline's" % S}
-                batch.close()
-            except Exception as e:  # noqa: BLE001 -- a secondary measurement must not cost the line
-                out["batch_on_one_gpu"][f"streams{S}"] = {"error": repr(e)}
         out["sync_per_frame"] = {"scans_per_s": rate_sync, "ms_per_frame": 1e3 / rate_sync,
                                  "same_trajectory_as_host_input": bool((ks.last_pose == local_poses[-1]).all())}
         out["sync_with_outputs"] = {"scans_per_s": rate_out, "ms_per_frame": 1e3 / rate_out,
@@ -488,60 +461,6 @@ def main():
     print(json.dumps(out))
 
 
-def supervise(argv):
-    """A plain `python bench.py ...` measures in a CHILD process (this script again).  A device fault makes the HIP runtime abort
-    the process that caused it, and a bench that died prints nothing: one sweep run of round 4 ended that way and nothing
-    reproduced it (profiles/README.md, r04_au).  If the child ends without its JSON line it is started ONCE more, and the line
-    says so ("attempts": 2) -- everything measured is measured inside one child, nothing is carried over.  Ranks under
-    torch.distributed.run are not supervised (the launcher owns them); KICP_BENCH_SUPERVISE=0 runs in this process."""
-    import subprocess
-
-    env = dict(os.environ, KICP_BENCH_CHILD="1")
-    status = 1
-    for attempt in (1, 2):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, stdout=subprocess.PIPE)
-        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.strip()]
-        at = None
-        for i in range(len(lines) - 1, -1, -1):
-            if lines[i].lstrip().startswith("{"):
-                try:
-                    json.loads(lines[i])
-                    at = i
-                    break
-                except ValueError:
-                    pass
-        if r.returncode == 0 and at is not None:
-            for i, ln in enumerate(lines):  # (whatever else the child printed stays in front of the line)
-                if i != at:
-                    print(ln)
-            out = json.loads(lines[at])
-            out["attempts"] = attempt
-            print(json.dumps(out))
-            return 0
-        if r.returncode == 0:  # nothing to measure (--help)
-            for ln in lines:
-                print(ln)
-            return 0
-        for ln in lines:
-            sys.stderr.write(ln + "\n")
-        status = r.returncode
-        if status in (2, 3):  # usage error, refusal: the same again would say the same
-            break
-        sys.stderr.write("[bench] attempt %d: the measuring process ended with status %d and no result line%s\n" % (
-            attempt, r.returncode, "; once more" if attempt == 1 else ""))
-    return status
-
-
 if __name__ == "__main__":
-    if "WORLD_SIZE" in os.environ or os.environ.get("KICP_BENCH_SUPERVISE", "1") == "0":
-        main()
-    elif os.environ.get("KICP_BENCH_CHILD") == "1":
-        try:
-            main()
-        except SystemExit as e:  # a refusal (no GPU, flags that disagree): status 3 -- the same again would say the same
-            if isinstance(e.code, str):
-                sys.stderr.write(e.code + "\n")
-                sys.exit(3)
-            raise
-    else:
-        sys.exit(supervise(sys.argv[1:]))
+    # (measured in THIS process, once: a bench whose process dies has failed -- there is no second attempt)
+    main()

@@ -40,7 +40,10 @@ typedef enum kicp_status {
     KICP_ERR_OOM = 3,         /* device or host allocation failed */
     KICP_ERR_CAPACITY = 4,    /* a device table could not grow any further */
     KICP_ERR_RANGE = 5,       /* voxel coordinate outside +-2^20 */
-    KICP_ERR_TIMEOUT = 6,     /* a bounded in-kernel wait gave up (never hangs the GPU) */
+    KICP_ERR_TIMEOUT = 6,     /* a bounded wait gave up: inside the registration kernel (its workgroups were not all resident; the
+                                 launch commits nothing and is replayed), or on the host -- EVERY wait of this library for the
+                                 device has a deadline ("wait_timeout_ms"): the call returns, the work stays queued, a later
+                                 sync collects it; a handle destroyed while its work does not end is leaked, not waited for */
     KICP_ERR_NO_DEVICE = 7,   /* no usable gfx950 GPU */
     KICP_ERR_TIMESTAMPS = 8   /* 0 < n_timestamps < n_points (std::vector::at would throw,
                                  core/Preprocessing.cpp:76-77) */
@@ -130,8 +133,9 @@ int kicp_registration_last_system(const kicp_registration *reg, double JTJ[36], 
  * Free functions of the stages either side of the path ("next" rows of SURVEY.md section 8f)
  * ---------------------------------------------------------------------------------------- */
 /* VoxelDownsample(frame, voxel_size)  core/VoxelUtils.cpp:7-21 / pybind _voxel_down_sample.
- * Keeps the first point per voxel; output order = ascending original index (the reference's
- * is robin_map bucket order, unspecified).  out_xyz must hold n points. */
+ * Keeps the first point per voxel; the survivors leave in the REFERENCE's order -- the bucket order of the
+ * tsl::robin_map 1.4.0 it collects them in (VoxelUtils.cpp:17-19) -- unless option "downsample_order" is 0
+ * (ascending original index).  out_xyz must hold n points. */
 int kicp_voxel_downsample(const double *xyz, size_t n, double voxel_size, int device_id,
                           double *out_xyz, size_t *n_out);
 /* Preprocessor(max_range, min_range, deskew, max_num_threads).Preprocess(frame, timestamps,
@@ -418,6 +422,11 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
  *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
  *                     iterations.  Results are bitwise the same either way.
+ *   "icp_group_prune"  1 (default): the 32-lane-group form of the association skips cells of the 27 whose box lies strictly farther
+ *                     than a candidate already in hand (first the last iteration's neighbour, then the best of every trip) and
+ *                     spreads the points of the cells it does read over the lanes; 0: every point of the 27 cells is read
+ *                     (scan lists / a lane per cell, rounds 2-4).  Exact: a skipped cell loses every comparison of
+ *                     VoxelHashMap.cpp:58-63 anyway; pose, iteration count and examined count are bitwise the same.
  *   "icp_schur_solve"  1 (default): the 6 x 6 normal equations of a Gauss-Newton step, whose top-left block is (sum w) I, are solved
  *                     through their 3 x 3 Schur complement when that is well conditioned (pivots above 1e-9 of the diagonal);
  *                     0: always by the pivoted 6 x 6 LDLT of Eigen that the reference calls (Registration.cpp:156).  The two
@@ -460,6 +469,13 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     their workgroups never became co-resident (exercises the replay path)
  *   "icp_inject_timeout_skip"  ... after leaving its first M registrations alone
  *   "map_rehash_every"  test hook: pipelines rebuild their map's slot array (in stream order, no host wait) every N frames
+ *   "wait_timeout_ms"  deadline of every host-side wait for the device, in milliseconds (default 120000; 0 = none).  The library
+ *                     never blocks in hipStreamSynchronize / hipEventSynchronize: it polls, and a wait that does not end in time
+ *                     returns KICP_ERR_TIMEOUT and names what it waited for.  The reference cannot hang
+ *                     (core/Registration.cpp:138-167 terminates, always); neither may its drop-in
+ *   "inject_stall_ms"  test hook: the next piece of work any handle queues is preceded by a kernel that occupies its stream this
+ *                     long (0 .. 60000; consumed by the first taker) -- the dependency that is not signalled in time
+ *                     (tests/test_gpu_deadlines.py)
  *   "map_apply_threads"  workgroup size of the AddPoints apply kernel: 256, 512 (default) or 1024
  *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
  *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)

@@ -47,25 +47,183 @@ static bool host_trace_on() {
     return on;
 }
 
+// ---- bounded waits --------------------------------------------------------------------------------------------------
+// (declared in kicp_internal.hpp, which says why)
+static thread_local bool t_gave_up = false;  // this thread's most recent wait ended in KICP_ERR_TIMEOUT
+template <class Query>
+static int wait_poll(Query query, const char *kind, const char *what) {
+    const double t0 = now_ms();
+    const double limit = (double)options().wait_timeout_ms;
+    for (;;) {
+        const hipError_t e = query();
+        if (e == hipSuccess) {
+            t_gave_up = false;
+            return KICP_OK;
+        }
+        (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error
+        if (e != hipErrorNotReady) {
+            set_error("%s(%s) failed: %s", kind, what, hipGetErrorString(e));
+            return KICP_ERR_HIP;
+        }
+        const double dt = now_ms() - t0;
+        if (limit > 0.0 && dt > limit) {
+            t_gave_up = true;
+            set_error("%s: the device did not finish within %ld ms (wait_timeout_ms); the work is still queued", what, options().wait_timeout_ms);
+            return KICP_ERR_TIMEOUT;
+        }
+        // a registration is a fraction of a millisecond: poll closely at first, then leave the core to others
+        if (dt < 0.05) {
+            for (int k = 0; k < 8; ++k) _mm_pause();
+        } else if (dt < 2.0) {
+            std::this_thread::yield();
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(dt < 50.0 ? 50 : 500));
+        }
+    }
+}
+static bool wait_blocking() {  // KICP_WAIT_BLOCKING=1 (diagnostics): the runtime's own unbounded waits instead of the polls
+    static const bool on = [] {
+        const char *e = getenv("KICP_WAIT_BLOCKING");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+int wait_stream(hipStream_t s, const char *what) {
+    if (wait_blocking()) {
+        KICP_HIP(hipStreamSynchronize(s));
+        return KICP_OK;
+    }
+    return wait_poll([s] { return hipStreamQuery(s); }, "hipStreamQuery", what);
+}
+int wait_event(hipEvent_t e, const char *what) {
+    if (wait_blocking()) {
+        KICP_HIP(hipEventSynchronize(e));
+        return KICP_OK;
+    }
+    return wait_poll([e] { return hipEventQuery(e); }, "hipEventQuery", what);
+}
+
+struct StreamRegistry {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> v;
+};
+static StreamRegistry &stream_registry() {
+    static StreamRegistry *r = new StreamRegistry();  // (never destroyed: handles may be released from static destructors)
+    return *r;
+}
+void stream_register(int device_id, hipStream_t s) {
+    if (!s) return;
+    StreamRegistry &r = stream_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.v.emplace_back(device_id, s);
+}
+void stream_forget(hipStream_t s) {
+    StreamRegistry &r = stream_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    for (size_t i = 0; i < r.v.size(); ++i)
+        if (r.v[i].second == s) {
+            r.v[i] = r.v.back();
+            r.v.pop_back();
+            return;
+        }
+}
+int wait_device(int device_id, const char *what) {
+    std::vector<hipStream_t> mine;
+    {
+        StreamRegistry &r = stream_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        for (const auto &e : r.v)
+            if (e.first == device_id) mine.push_back(e.second);
+    }
+    // (a stream destroyed by another thread between the copy and the query: the query fails, which ends the wait --
+    // handles are not destroyed under other threads' calls by contract)
+    // (the NULL stream is not polled: the library queues nothing on it -- its blocking copies are over when they return.
+    // A first version zero-filled new buffers on the null stream and polled hipStreamQuery(nullptr): the first process of
+    // a fresh box died of a memory fault in its first kernels, profiles/README.md r05_e; with a stream of the library's own
+    // the polling is the same mechanism as everywhere else)
+    for (hipStream_t s : mine) KICP_TRY(wait_stream(s, what));
+    return KICP_OK;
+}
+struct UtilStreams {
+    std::mutex mu;
+    hipStream_t s[64] = {nullptr};
+};
+hipStream_t util_stream(int device_id) {
+    static UtilStreams *u = new UtilStreams();
+    std::lock_guard<std::mutex> lk(u->mu);
+    hipStream_t &s = u->s[device_id & 63];
+    if (!s) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            s = nullptr;
+            return nullptr;
+        }
+        stream_register(device_id, s);
+    }
+    return s;
+}
+int stream_destroy(hipStream_t s) {
+    if (!s) return KICP_OK;
+    const int st = wait_stream(s, "stream teardown");
+    // leaked: hipStreamDestroy would wait for the work that does not end.  The stream STAYS in the registry: whoever frees
+    // memory on this device later must keep finding it busy (and give up in time) rather than walk into hipFree's own wait.
+    if (st == KICP_ERR_TIMEOUT) return st;
+    stream_forget(s);
+    (void)hipStreamDestroy(s);
+    return KICP_OK;
+}
+
+// test hook: a kernel that occupies the stream for a while (the dependency that is not signalled in time)
+__global__ void k_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+void inject_stall(hipStream_t s) {
+    const long ms = options().inject_stall_ms;
+    if (ms <= 0) return;
+    options().inject_stall_ms = 0;  // once
+    hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, s, (unsigned long long)ms * 100000ull);
+}
+
+static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+
 int DevBuf::reserve(size_t need, bool keep, hipStream_t s) {
     if (need <= bytes && p) return KICP_OK;
     size_t nb = need < 256 ? 256 : need;
     if (keep && bytes) nb = nb < bytes * 2 ? bytes * 2 : nb;
+    if (!s) s = util_stream(current_device());
+    if (!s) {
+        set_error("no utility stream on device %d", current_device());
+        return KICP_ERR_HIP;
+    }
     void *np = nullptr;
     KICP_HIP(hipMalloc(&np, nb));
-    // A new buffer starts as zeros, not as whatever the allocator hands out (fresh device memory, or a freed buffer of
-    // this process): nothing is meant to read a word before it was written, but if something does, it reads the same
-    // thing in every process -- buffers are (re)allocated a handful of times in a pipeline's life, so this costs nothing.
-    KICP_HIP(hipMemsetAsync(np, 0, nb, s));
-    if (keep && p && bytes) KICP_HIP(hipMemcpyAsync(np, p, bytes, hipMemcpyDeviceToDevice, s));
-    KICP_HIP(hipStreamSynchronize(s));
+    // zeros, not whatever the allocator hands out: the contract of this type (see its declaration)
+    hipError_t e = hipMemsetAsync(np, 0, nb, s);
+    if (e == hipSuccess && keep && p && bytes) e = hipMemcpyAsync(np, p, bytes, hipMemcpyDeviceToDevice, s);
+    int st = e == hipSuccess ? wait_stream(s, "buffer initialisation") : KICP_ERR_HIP;
+    // the old buffer: hipFree waits for the whole device, so that wait is made here, with a deadline
+    if (st == KICP_OK && p) st = wait_device(current_device(), "buffer growth (work that may still read the old buffer)");
+    if (st != KICP_OK) {
+        if (e != hipSuccess) set_error("device buffer initialisation failed: %s", hipGetErrorString(e));
+        if (st != KICP_ERR_TIMEOUT) (void)hipFree(np);  // (timeout: both buffers stay -- hipFree would not return)
+        return st;
+    }
     if (p) KICP_HIP(hipFree(p));
     p = np;
     bytes = nb;
     return KICP_OK;
 }
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    // hipFree synchronises with the device: only behind a bounded wait (a device that does not answer keeps the buffer)
+    if (p) drop(wait_device(current_device(), "buffer release") != KICP_ERR_TIMEOUT);
+}
+void DevBuf::drop(bool device_idle) {
+    if (p && device_idle) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
 }
@@ -99,8 +257,41 @@ static uint32_t next_pow2(size_t v) {
     return c;
 }
 
+// the device's record of the bounds-asserting build
+struct BoundsSlot {
+    std::mutex mu;
+    BoundsRec *p = nullptr;
+};
+static BoundsSlot &bounds_slot(int device_id) {
+    static BoundsSlot slots[64];
+    return slots[device_id & 63];
+}
+BoundsRec *bounds_rec(int device_id) {
+    BoundsSlot &b = bounds_slot(device_id);
+    std::lock_guard<std::mutex> lk(b.mu);
+    if (!b.p) {
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(BoundsRec)) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, sizeof(BoundsRec)) != hipSuccess) {
+            (void)hipFree(q);
+            return nullptr;
+        }
+        b.p = static_cast<BoundsRec *>(q);
+    }
+    return b.p;
+}
+
 static int err_bits_to_status(int bits) {
     if (!bits) return KICP_OK;
+    if (bits & E_BOUNDS) {  // (only the bounds-asserting build raises it)
+        BoundsRec r;
+        memset(&r, 0, sizeof r);
+        BoundsRec *d = bounds_rec(current_device());
+        if (d && hipMemcpy(&r, d, sizeof r, hipMemcpyDeviceToHost) == hipSuccess) (void)hipMemset(d, 0, sizeof r);
+        set_error("bounds check failed on the device: source line %d (tag %d), index %lld, limit %lld, workgroup %d, thread %d (bits 0x%x)", r.line, r.tag,
+                  r.idx, r.limit, r.block, r.thread, bits);
+        return KICP_ERR_HIP;
+    }
     if (bits & E_TIMEOUT) {
         set_error("a bounded in-kernel wait gave up (ICP workgroups not co-resident?)");
         return KICP_ERR_TIMEOUT;
@@ -229,6 +420,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
     P.use_wide = options().icp_wide >= 0 ? (options().icp_wide != 0) : (per_wg > kIcpListRunMax);
     P.wide_prune = (int)options().icp_wide_prune;
     P.schur_solve = (int)options().icp_schur_solve;
+    P.group_prune = (int)options().icp_group_prune;
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
     P.wide_flat = (int)options().icp_wide_flat;
@@ -378,13 +570,16 @@ MapView kicp_map::view() const {
     v.voxel_size = voxel_size;
     v.max_distance = max_distance;
     v.map_resolution = sqrt(voxel_size * voxel_size / (double)max_points);
+    v.dbg = kDebugBounds ? bounds_rec(device) : nullptr;
     return v;
 }
 
 int kicp_map::refresh_counters() {
     const double t0 = now_ms();
-    KICP_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
-    KICP_HIP(hipStreamSynchronize(stream));
+    // (the wait first, bounded; then the copy: a device-to-host copy into pageable memory BLOCKS inside the runtime until the
+    // stream has reached it -- queued in front of the wait it would be the unbounded wait this library does not have)
+    KICP_TRY(wait_stream(stream, "map counters"));
+    KICP_HIP(hipMemcpy(h_ctr, ctr.p, sizeof h_ctr, hipMemcpyDeviceToHost));
     n_refresh++;
     wait_ms += now_ms() - t0;
     used_ub = h_ctr[C_USED];
@@ -424,7 +619,7 @@ int kicp_map::check_errors() {
         const int bits = h_ctr[C_ERR];
         int zero = 0;
         KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_ERR, &zero, sizeof zero, hipMemcpyHostToDevice, stream));
-        KICP_HIP(hipStreamSynchronize(stream));
+        KICP_TRY(wait_stream(stream, "map error word"));
         return err_bits_to_status(bits);
     }
     return KICP_OK;
@@ -437,7 +632,7 @@ static int map_rehash(kicp_map *m, uint32_t new_cap) {
     if (new_cap != m->slot_cap) {
         DevBuf ns;
         KICP_TRY(ns.reserve((size_t)new_cap * sizeof(Slot)));
-        KICP_HIP(hipStreamSynchronize(m->stream));
+        KICP_TRY(wait_stream(m->stream, "map rehash"));
         m->slots.release();
         m->slots = ns;
         m->slot_cap = new_cap;
@@ -495,8 +690,8 @@ int kicp_map::ensure_capacity(size_t incoming) {
             if ((int)(tail - head) < 0) head = tail;
             const size_t count = (size_t)(pend - head);
             std::vector<int> old_ring((size_t)blocks_cap), lin(count ? count : 1);
-            KICP_HIP(hipMemcpyAsync(old_ring.data(), free_ids.p, (size_t)blocks_cap * sizeof(int), hipMemcpyDeviceToHost, stream));
-            KICP_HIP(hipStreamSynchronize(stream));
+            KICP_TRY(wait_stream(stream, "map growth"));  // (the copy below goes into a local buffer: nothing may be pending when it starts)
+            KICP_HIP(hipMemcpy(old_ring.data(), free_ids.p, (size_t)blocks_cap * sizeof(int), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < count; ++i) lin[i] = old_ring[(head + (unsigned)i) % (unsigned)blocks_cap];
             KICP_TRY(free_ids.reserve(want * sizeof(int)));
             if (count) KICP_HIP(hipMemcpyAsync(free_ids.p, lin.data(), count * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -504,7 +699,7 @@ int kicp_map::ensure_capacity(size_t incoming) {
             KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FHEAD, &cur[0], sizeof(int), hipMemcpyHostToDevice, stream));
             KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FTAIL, &cur[1], sizeof(int), hipMemcpyHostToDevice, stream));
             KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FPEND, &cur[2], sizeof(int), hipMemcpyHostToDevice, stream));
-            KICP_HIP(hipStreamSynchronize(stream));
+            KICP_TRY(wait_stream(stream, "map growth"));
         }
         blocks_cap = (int)want;
     }
@@ -524,7 +719,7 @@ static int map_alloc(kicp_map *m) {
     KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
     KICP_HIP(hipMemsetAsync(m->blocks.p, 0, m->blocks.bytes, m->stream));
     KICP_HIP(hipMemsetAsync(m->ctr.p, 0, m->ctr.bytes, m->stream));
-    KICP_HIP(hipStreamSynchronize(m->stream));
+    KICP_TRY(wait_stream(m->stream, "map creation"));
     m->used_ub = m->bump_ub = m->live_ub = 0;
     return KICP_OK;
 }
@@ -559,6 +754,7 @@ static int map_create_on_stream(double voxel_size, double max_distance, unsigned
             set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
             return KICP_ERR_HIP;
         }
+        stream_register(device_id, m->stream);
     }
     int s = map_alloc(m);
     if (s != KICP_OK) {
@@ -579,22 +775,17 @@ int kicp_map_create(double voxel_size, double max_distance, unsigned max_points_
 int kicp_map_destroy(kicp_map *m) {
     if (!m) return KICP_OK;
     (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream);
-    m->slots.release();
-    m->heads.release();
-    m->blocks.release();
-    m->free_ids.release();
-    m->ctr.release();
-    m->pts_in.release();
-    m->world.release();
-    m->next.release();
-    m->rec_slot.release();
-    m->rec_count.release();
-    m->rec_head.release();
-    m->rec_list.release();
-    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    // (one bounded wait for everything the map owns; a device that does not answer keeps the memory)
+    int idle = wait_stream(m->stream, "map teardown");
+    if (idle == KICP_OK) idle = wait_device(m->device, "map teardown");
+    for (DevBuf *b : {&m->slots, &m->heads, &m->blocks, &m->free_ids, &m->ctr, &m->pts_in, &m->world, &m->next, &m->rec_slot, &m->rec_count,
+                      &m->rec_head, &m->rec_list})
+        b->drop(idle == KICP_OK);
+    if (m->own_stream && m->stream) {
+        if (idle == KICP_OK) (void)stream_destroy(m->stream);  // (else leaked with the rest, and kept in the registry)
+    }
     delete m;
-    return KICP_OK;
+    return idle;
 }
 
 int kicp_map_clone(const kicp_map *csrc, kicp_map **out) {
@@ -602,7 +793,7 @@ int kicp_map_clone(const kicp_map *csrc, kicp_map **out) {
     if (!src || !out) return KICP_ERR_INVALID_ARG;
     *out = nullptr;
     KICP_HIP(hipSetDevice(src->device));
-    KICP_HIP(hipStreamSynchronize(src->stream));  // everything queued on the source has happened
+    KICP_TRY(wait_stream(src->stream, "map copy (source)"));  // everything queued on the source has happened
     kicp_map *m = nullptr;
     KICP_TRY(map_create_on_stream(src->voxel_size, src->max_distance, src->max_points, src->device, nullptr, &m));
     int s = KICP_OK;
@@ -620,7 +811,7 @@ int kicp_map_clone(const kicp_map *csrc, kicp_map **out) {
     copy(m->blocks, src->blocks);
     copy(m->free_ids, src->free_ids);
     copy(m->ctr, src->ctr);
-    if (s == KICP_OK && hipStreamSynchronize(m->stream) != hipSuccess) s = KICP_ERR_HIP;
+    if (s == KICP_OK) s = wait_stream(m->stream, "map copy");
     if (s != KICP_OK) {
         kicp_map_destroy(m);
         return s;
@@ -645,7 +836,7 @@ int kicp_map_clear(kicp_map *m) {
     KICP_HIP(hipMemsetAsync(m->heads.p, 0xFF, (size_t)m->slot_cap * sizeof(int), m->stream));
     KICP_HIP(hipMemsetAsync(m->blocks.p, 0, (size_t)m->bump_ub * m->stride, m->stream));
     KICP_HIP(hipMemsetAsync(m->ctr.p, 0, sizeof(int) * C_COUNT, m->stream));
-    KICP_HIP(hipStreamSynchronize(m->stream));
+    KICP_TRY(wait_stream(m->stream, "map clear"));
     m->used_ub = m->bump_ub = m->live_ub = 0;
     return KICP_OK;
 }
@@ -699,6 +890,7 @@ static int map_upload(kicp_map *m, const double *xyz, size_t n) {
         return KICP_ERR_INVALID_ARG;
     }
     KICP_TRY(m->pts_in.reserve((n ? n : 1) * 3 * sizeof(double)));
+    inject_stall(m->stream);
     if (n) KICP_HIP(hipMemcpyAsync(m->pts_in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, m->stream));
     return KICP_OK;
 }
@@ -714,6 +906,7 @@ int kicp_map_add_points(kicp_map *m, const double *xyz, size_t n) {
 int kicp_map_remove_far(kicp_map *m, const double origin[3]) {
     if (!m || !origin) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(m->device));
+    inject_stall(m->stream);
     launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
@@ -753,10 +946,7 @@ int kicp_map_pointcloud(const kicp_map *cm, double *out_xyz, size_t cap, size_t 
     KICP_TRY(m->refresh_counters());
     const size_t nb = (size_t)m->bump_ub;
     std::vector<char> host(nb * m->stride);
-    if (nb) {
-        KICP_HIP(hipMemcpyAsync(host.data(), m->blocks.p, nb * m->stride, hipMemcpyDeviceToHost, m->stream));
-        KICP_HIP(hipStreamSynchronize(m->stream));
-    }
+    if (nb) KICP_HIP(hipMemcpy(host.data(), m->blocks.p, nb * m->stride, hipMemcpyDeviceToHost));  // (the stream is idle: refresh_counters waited)
     size_t k = 0;
     for (size_t b = 0; b < nb; ++b) {
         const BlockHdr *h = reinterpret_cast<const BlockHdr *>(host.data() + b * m->stride);
@@ -784,9 +974,10 @@ int kicp_map_closest_neighbor(const kicp_map *cm, const double *q, size_t nq, do
     double *d_dist = d_nn + 3 * nq;
     launch_closest_neighbor(m->view(), m->pts_in.as<double>(), (int)nq, d_nn, d_dist, m->stream);
     KICP_HIP(hipGetLastError());
-    KICP_HIP(hipMemcpyAsync(nn, d_nn, nq * 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-    KICP_HIP(hipMemcpyAsync(dist, d_dist, nq * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-    KICP_HIP(hipStreamSynchronize(m->stream));
+    // (the caller's buffers are only written once the kernel is known to have ended: a wait that gives up leaves no copy pending)
+    KICP_TRY(wait_stream(m->stream, "closest-neighbour search"));
+    KICP_HIP(hipMemcpy(nn, d_nn, nq * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    KICP_HIP(hipMemcpy(dist, d_dist, nq * sizeof(double), hipMemcpyDeviceToHost));
     return KICP_OK;
 }
 
@@ -835,6 +1026,7 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
         kicp_registration_destroy(r);
         return KICP_ERR_HIP;
     }
+    stream_register(device_id, r->stream);
     int s = r->state.reserve(sizeof(PipeState));
     if (s == KICP_OK && (icp_prepare(device_id) != 0 || tile_sort_prepare(device_id) != 0)) {
         set_error("hipFuncSetAttribute(k_icp, 160 KiB LDS) failed");
@@ -849,7 +1041,13 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
     init_state(st, 0.0);
     KICP_HIP(hipMemcpyAsync(r->state.p, &st, sizeof st, hipMemcpyHostToDevice, r->stream));
     KICP_HIP(hipMemsetAsync(r->granules.p, 0, r->granules.bytes, r->stream));
-    KICP_HIP(hipStreamSynchronize(r->stream));
+    {
+        const int ws = wait_stream(r->stream, "registration creation");
+        if (ws != KICP_OK) {
+            kicp_registration_destroy(r);
+            return ws;
+        }
+    }
     *out = r;
     return KICP_OK;
 }
@@ -857,23 +1055,19 @@ int kicp_registration_create(int max_num_iterations, double convergence_criterio
 int kicp_registration_destroy(kicp_registration *r) {
     if (!r) return KICP_OK;
     (void)hipSetDevice(r->device);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
-    r->frame.release();
-    r->work.release();
-    r->sort_in.release();
-    r->sort_out.release();
-    r->sort_tmp.release();
-    r->run_wts.release();
-    r->granules.release();
-    r->state.release();
-    if (r->ev0) (void)hipEventDestroy(r->ev0);
-    if (r->ev1) (void)hipEventDestroy(r->ev1);
+    int idle = r->stream ? wait_stream(r->stream, "registration teardown") : KICP_OK;
+    if (idle == KICP_OK) idle = wait_device(r->device, "registration teardown");
+    for (DevBuf *b : {&r->frame, &r->work, &r->sort_in, &r->sort_out, &r->sort_tmp, &r->run_wts, &r->granules, &r->state}) b->drop(idle == KICP_OK);
+    if (idle == KICP_OK) {
+        if (r->ev0) (void)hipEventDestroy(r->ev0);
+        if (r->ev1) (void)hipEventDestroy(r->ev1);
+    }
     if (r->stream) {
         icp_forget_stream(r->device, r->stream);
-        (void)hipStreamDestroy(r->stream);
+        if (idle == KICP_OK) (void)stream_destroy(r->stream);
     }
     delete r;
-    return KICP_OK;
+    return idle;
 }
 
 int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size_t n,
@@ -893,8 +1087,9 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         set_error("initial_guess is not a rigid transform (SOPHUS_ENSURE)");
         return KICP_ERR_INVALID_ARG;
     }
-    KICP_HIP(hipStreamSynchronize(map->stream));  // the map's own work is done before we read it
+    KICP_TRY(wait_stream(map->stream, "AlignPointsToMap (the map's pending work)"));  // the map's own work is done before we read it
     KICP_TRY(r->frame.reserve((n ? n : 1) * 3 * sizeof(double)));
+    inject_stall(r->stream);
     KICP_TRY(r->work.reserve((n ? n : 1) * 3 * sizeof(double)));
     if (n) KICP_HIP(hipMemcpyAsync(r->frame.p, frame_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, r->stream));
     PipeState *st = r->state.as<PipeState>();
@@ -947,8 +1142,10 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         KICP_TRY(icp_launch_ordered(r->device, P, G, options().icp_profile != 0, r->stream));
         KICP_HIP(hipGetLastError());
         KICP_HIP(hipEventRecord(r->ev1, r->stream));
-        KICP_HIP(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, r->stream));
-        KICP_HIP(hipStreamSynchronize(r->stream));
+        // (the result is fetched only once the launch is known to have ended: `h` is a local, and a wait that gives up must
+        // leave no copy pending into it)
+        KICP_TRY(wait_stream(r->stream, "AlignPointsToMap"));
+        KICP_HIP(hipMemcpy(&h, st, sizeof h, hipMemcpyDeviceToHost));
         if (!h.err) break;
         int zero = 0;
         KICP_HIP(hipMemcpy(&st->err, &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -1006,14 +1203,22 @@ int kicp_registration_last_system(const kicp_registration *r, double JTJ[36], do
 // ==============================================================================================
 struct ScopedStream {
     hipStream_t s = nullptr;
+    int create(int device_id) {
+        KICP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        stream_register(device_id, s);
+        return KICP_OK;
+    }
     ~ScopedStream() {
-        if (s) (void)hipStreamDestroy(s);
+        if (s && hipStreamQuery(s) == hipSuccess) (void)stream_destroy(s);  // (still busy -- the call gave up on it: leaked, and kept in the registry)
+        (void)hipGetLastError();
     }
 };
-struct ScopedBufs {
+struct ScopedBufs {  // (declared AFTER the call's ScopedStream: destroyed first, and its one wait covers the stream's teardown too)
     std::vector<DevBuf *> v;
     ~ScopedBufs() {
-        for (auto *b : v) b->release();
+        // (a call that has just given up on the device does not wait for it a second time: its buffers are leaked)
+        const bool idle = !t_gave_up && wait_device(current_device(), "temporary buffers") == KICP_OK;
+        for (auto *b : v) b->drop(idle);
     }
 };
 
@@ -1038,6 +1243,7 @@ static int downsample_device(const double *d_in, const int *n_ptr, int n_imm, in
     P.out = d_out;
     P.n_out = d_nout;
     P.err = d_err;
+    P.dbg = kDebugBounds ? bounds_rec(current_device()) : nullptr;
     if (claim) launch_ds_claim(P, s);
     if (order) {
         launch_ds_arrange(P, s);
@@ -1060,8 +1266,7 @@ static int init_ds_table(DevBuf &tab, uint32_t cap, hipStream_t s) {
         e.pad = 0;
     }
     KICP_HIP(hipMemcpyAsync(tab.p, h.data(), (size_t)cap * sizeof(DsSlot), hipMemcpyHostToDevice, s));
-    KICP_HIP(hipStreamSynchronize(s));
-    return KICP_OK;
+    return wait_stream(s, "downsample table initialisation");
 }
 
 extern "C" {
@@ -1074,7 +1279,7 @@ int kicp_voxel_downsample(const double *xyz, size_t n, double voxel_size, int de
     *n_out = 0;
     if (n == 0) return KICP_OK;
     ScopedStream ss;
-    KICP_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    KICP_TRY(ss.create(device_id));
     DevBuf in, out, tab, slot_of, counts, misc, rb;
     ScopedBufs sb;
     sb.v = {&in, &out, &tab, &slot_of, &counts, &misc, &rb};
@@ -1087,14 +1292,15 @@ int kicp_voxel_downsample(const double *xyz, size_t n, double voxel_size, int de
     KICP_TRY(misc.reserve(2 * sizeof(int)));
     if (order) KICP_TRY(rb.reserve((size_t)cap * 2 * sizeof(int)));
     KICP_TRY(init_ds_table(tab, cap, ss.s));
+    inject_stall(ss.s);
     KICP_HIP(hipMemsetAsync(misc.p, 0, 2 * sizeof(int), ss.s));
     KICP_HIP(hipMemcpyAsync(in.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ss.s));
     KICP_TRY(downsample_device(in.as<double>(), nullptr, (int)n, (int)n, voxel_size, tab, cap, slot_of.as<int>(),
                                counts.as<int>(), out.as<double>(), misc.as<int>(), misc.as<int>() + 1, true, order,
                                order ? rb.as<int>() : nullptr, order ? rb.as<int>() + cap : nullptr, ss.s));
     int h[2];
-    KICP_HIP(hipMemcpyAsync(h, misc.p, sizeof h, hipMemcpyDeviceToHost, ss.s));
-    KICP_HIP(hipStreamSynchronize(ss.s));
+    KICP_TRY(wait_stream(ss.s, "VoxelDownsample"));  // (then the results: nothing is left pending into locals or the caller's buffers)
+    KICP_HIP(hipMemcpy(h, misc.p, sizeof h, hipMemcpyDeviceToHost));
     if (h[1]) return err_bits_to_status(h[1]);
     KICP_HIP(hipMemcpy(out_xyz, out.p, (size_t)h[0] * 3 * sizeof(double), hipMemcpyDeviceToHost));
     *n_out = (size_t)h[0];
@@ -1120,7 +1326,7 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
     }
     if (n == 0) return KICP_OK;
     ScopedStream ss;
-    KICP_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    KICP_TRY(ss.create(device_id));
     DevBuf in, ts, tmp, out, counts, st, prep;
     ScopedBufs sb;
     sb.v = {&in, &ts, &tmp, &out, &counts, &st, &prep};
@@ -1131,6 +1337,7 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
     KICP_TRY(st.reserve(sizeof(PipeState)));
     PipeState hs;
     init_state(hs, 0.0);
+    inject_stall(ss.s);
     KICP_HIP(hipMemcpyAsync(st.p, &hs, sizeof hs, hipMemcpyHostToDevice, ss.s));
     KICP_TRY(prep.reserve(sizeof(PrepState)));
     PrepState hp = idle_prep_state();
@@ -1159,12 +1366,13 @@ int kicp_preprocess(const double *xyz, size_t n, const double *timestamps, size_
     P.n_out = &prep.as<PrepState>()->n_pre;
     P.ds_tab = nullptr;
     P.err = &st.as<PipeState>()->err;
+    P.dbg = kDebugBounds ? bounds_rec(device_id) : nullptr;
     launch_pre_flags(P, ss.s);
     launch_pre_scatter(P, ss.s);
     KICP_HIP(hipGetLastError());
-    KICP_HIP(hipMemcpyAsync(&hs, st.p, sizeof hs, hipMemcpyDeviceToHost, ss.s));
-    KICP_HIP(hipMemcpyAsync(&hp, prep.p, sizeof hp, hipMemcpyDeviceToHost, ss.s));
-    KICP_HIP(hipStreamSynchronize(ss.s));
+    KICP_TRY(wait_stream(ss.s, "Preprocess"));
+    KICP_HIP(hipMemcpy(&hs, st.p, sizeof hs, hipMemcpyDeviceToHost));
+    KICP_HIP(hipMemcpy(&hp, prep.p, sizeof hp, hipMemcpyDeviceToHost));
     if (hs.err) return err_bits_to_status(hs.err);
     KICP_HIP(hipMemcpy(out_xyz, out.p, (size_t)hp.n_pre * 3 * sizeof(double), hipMemcpyDeviceToHost));
     *n_out = (size_t)hp.n_pre;
@@ -1274,7 +1482,7 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     if (p->cap_points && n <= p->cap_points) return KICP_OK;
     if (p->cap_points) p->hs.buffer_grows++;
     if (p->in_flight) KICP_TRY(pipe_sync(p, false));
-    KICP_HIP(hipStreamSynchronize(p->prep_stream));
+    KICP_TRY(wait_stream(p->prep_stream, "pipeline buffers (front stages)"));
     // never less than a minimum: an EMPTY first scan must still find its buffers (the front-stage
     // kernels write their counts even for zero points)
     size_t cap = n + n / 8 + 1024;
@@ -1320,9 +1528,12 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
 static int pipe_reserve_staging(kicp_pipeline *p) {
     if (p->stage_points >= p->cap_points && p->stage[0]) return KICP_OK;
     for (int i = 0; i < kicp_pipeline::kStage; ++i) {
-        if (p->stage_busy[i]) KICP_HIP(hipEventSynchronize(p->ev_h2d[i]));
+        if (p->stage_busy[i]) KICP_TRY(wait_event(p->ev_h2d[i], "staging slot"));
         p->stage_busy[i] = false;
-        if (p->stage[i]) KICP_HIP(hipHostFree(p->stage[i]));
+        if (p->stage[i]) {
+            KICP_TRY(wait_device(p->device, "staging slot release"));  // (hipHostFree waits for the whole device)
+            KICP_HIP(hipHostFree(p->stage[i]));
+        }
         p->stage[i] = nullptr;
     }
     for (int i = 0; i < kicp_pipeline::kStage; ++i) {
@@ -1384,7 +1595,7 @@ static int pipe_backpressure(kicp_pipeline *p) {
     if (hipEventQuery(pipe_frame_done_event(p, k - 1)) != hipSuccess) {
         (void)hipGetLastError();
         const double t0 = now_ms();
-        KICP_HIP(hipEventSynchronize(pipe_frame_done_event(p, k - 1)));
+        KICP_TRY(wait_event(pipe_frame_done_event(p, k - 1), "queue back-pressure"));
         p->hs.backpressure_waits++;
         p->hs.backpressure_ms += now_ms() - t0;
     }
@@ -1444,7 +1655,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
             // launch-start event of the frame behind it), i.e. at most two frames are still queued; then the bound
             // (exact counters of the newest finished frame + two frames of slack) fits
             const double t0 = now_ms();
-            KICP_HIP(hipEventSynchronize(pipe_frame_done_event(p, p->in_flight - 3)));
+            KICP_TRY(wait_event(pipe_frame_done_event(p, p->in_flight - 3), "map capacity"));
             p->hs.capacity_waits++;
             p->hs.wait_ms += now_ms() - t0;
             pipe_refresh_bounds(p);
@@ -1494,6 +1705,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     P.ds_voxel = c.voxel_size * 0.5;  // KissICP.cpp:72
     P.ds_slot_of = p->slot1.as<int>();
     P.err = &st->err;
+    P.dbg = kDebugBounds ? bounds_rec(p->device) : nullptr;
     launch_pre_flags(P, sp);
     launch_pre_scatter(P, sp);
 
@@ -1519,6 +1731,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     D1.next_voxel = c.voxel_size * 1.5;  // KissICP.cpp:73
     D1.next_slot_of = p->slot2.as<int>();
     D1.err = &st->err;
+    D1.dbg = kDebugBounds ? bounds_rec(p->device) : nullptr;
     DsParams D2;
     memset(&D2, 0, sizeof D2);
     D2.order = p->ds_order;
@@ -1536,6 +1749,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     D2.out = p->src[par].as<double>();
     D2.n_out = &prep->n_src;
     D2.err = &st->err;
+    D2.dbg = kDebugBounds ? bounds_rec(p->device) : nullptr;
     if (p->ds_order) {  // the reference's output order: arrange the grid's clusters, then compact bucket by bucket
         launch_ds_arrange(D1, sp);
         launch_ds_scatter_rb(D1, sp);
@@ -1562,6 +1776,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     KICP_HIP(hipEventRecord(p->ev_prep_done[par], sp));
 
     // ===== stream: the serial chain =================================================================
+    inject_stall(s);
     KICP_HIP(hipStreamWaitEvent(s, p->ev_prep_done[par], 0));
     // --- AlignPointsToMap + threshold / pose bookkeeping (KissICP.cpp:44-63) ---------------------
     IcpParams I;
@@ -1677,7 +1892,7 @@ static int pipe_stage_and_enqueue(kicp_pipeline *p, const double *xyz64, const f
         if (hipEventQuery(p->ev_h2d[slot]) != hipSuccess) {
             (void)hipGetLastError();
             const double t0 = now_ms();
-            KICP_HIP(hipEventSynchronize(p->ev_h2d[slot]));
+            KICP_TRY(wait_event(p->ev_h2d[slot], "staging slot"));
             p->hs.staging_waits++;
             p->hs.wait_ms += now_ms() - t0;
         }
@@ -1830,6 +2045,8 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
         hipEventCreateWithFlags(&p->ev_prep_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_prep_done[1], hipEventDisableTiming) != hipSuccess)
         s = KICP_ERR_HIP;
+    stream_register(device_id, p->stream);
+    stream_register(device_id, p->prep_stream);
     p->ext_events = options().frame_events != 0;
     if (s == KICP_OK) {
         p->ev_ok = true;
@@ -1864,7 +2081,13 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     KICP_HIP(hipMemsetAsync(p->granules.p, 0, p->granules.bytes, p->stream));
     const PrepState idle[2] = {idle_prep_state(), idle_prep_state()};
     KICP_HIP(hipMemcpyAsync(p->prep.p, idle, sizeof idle, hipMemcpyHostToDevice, p->stream));
-    KICP_HIP(hipStreamSynchronize(p->stream));
+    {
+        const int ws = wait_stream(p->stream, "pipeline creation");
+        if (ws != KICP_OK) {
+            kicp_pipeline_destroy(p);
+            return ws;
+        }
+    }
     memset(&p->last, 0, sizeof p->last);
     p->last.st = st;
     *out = p;
@@ -1874,39 +2097,50 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
 int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (!p) return KICP_OK;
     (void)hipSetDevice(p->device);
-    if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
-    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    // Everything the pipeline has queued must have ended before its memory goes; every wait has its deadline, and a device
+    // that does not answer keeps what it may still touch (device and pinned memory, streams, events are leaked): the call
+    // returns KICP_ERR_TIMEOUT instead of never.
+    int idle = KICP_OK;
+    for (hipStream_t s : {p->prep_stream, p->copy_stream, p->stream})
+        if (s && idle == KICP_OK) idle = wait_stream(s, "pipeline teardown");
+    if (idle == KICP_OK) idle = wait_device(p->device, "pipeline teardown");  // (hipHostFree below waits for the whole device)
+    const bool gone = idle == KICP_OK;  // nothing of this pipeline is in flight any more
     delete p->pool;
     p->pool = nullptr;
-    if (p->map) kicp_map_destroy(p->map);
+    if (p->map) {  // (the map lives on the pipeline's stream: the wait above was its wait too)
+        kicp_map *m = p->map;
+        for (DevBuf *b : {&m->slots, &m->heads, &m->blocks, &m->free_ids, &m->ctr, &m->pts_in, &m->world, &m->next, &m->rec_slot, &m->rec_count,
+                          &m->rec_head, &m->rec_list})
+            b->drop(gone);
+        delete m;
+        p->map = nullptr;
+    }
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
                       &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->rb1, &p->rb2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
                       &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_wts})
-        b->release();
-    for (int i = 0; i < 2; ++i)
-        if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
-    for (int i = 0; i < kicp_pipeline::kStage; ++i) {
-        if (p->ev_h2d[i]) (void)hipEventDestroy(p->ev_h2d[i]);
-        if (p->stage[i]) (void)hipHostFree(p->stage[i]);
-    }
-    if (p->out_stage) (void)hipHostFree(p->out_stage);
-    if (p->copy_stream) {
-        (void)hipStreamSynchronize(p->copy_stream);
-        (void)hipStreamDestroy(p->copy_stream);
-    }
-    if (p->prep_stream) (void)hipStreamDestroy(p->prep_stream);
-    if (p->ev_ok)
-        for (int i = 0; i < kicp_pipeline::kRing; ++i) {
-            for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
-            (void)hipEventDestroy(p->ev_done[i]);
+        b->drop(gone);
+    if (gone) {
+        for (int i = 0; i < 2; ++i)
+            if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
+        for (int i = 0; i < kicp_pipeline::kStage; ++i) {
+            if (p->ev_h2d[i]) (void)hipEventDestroy(p->ev_h2d[i]);
+            if (p->stage[i]) (void)hipHostFree(p->stage[i]);
         }
-    if (p->ring) (void)hipHostFree(p->ring);
-    if (p->stream) {
-        icp_forget_stream(p->device, p->stream);
-        (void)hipStreamDestroy(p->stream);
+        if (p->out_stage) (void)hipHostFree(p->out_stage);
+        if (p->ev_ok)
+            for (int i = 0; i < kicp_pipeline::kRing; ++i) {
+                for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
+                (void)hipEventDestroy(p->ev_done[i]);
+            }
+        if (p->ring) (void)hipHostFree(p->ring);
+    }
+    for (hipStream_t s : {p->copy_stream, p->prep_stream, p->stream}) {
+        if (!s) continue;
+        if (s == p->stream) icp_forget_stream(p->device, s);
+        if (gone) (void)stream_destroy(s);  // (else leaked with the rest, and kept in the registry)
     }
     delete p;
-    return KICP_OK;
+    return gone ? KICP_OK : idle;
 }
 
 // fold the completed frames [0, count) of the ring into the accumulators
@@ -1990,7 +2224,7 @@ static int pipe_sync(kicp_pipeline *p, bool user_call) {
 }
 static int pipe_sync_impl(kicp_pipeline *p) {
     for (int attempt = 0;; ++attempt) {
-        KICP_HIP(hipStreamSynchronize(p->stream));
+        KICP_TRY(wait_stream(p->stream, "pipeline sync"));  // (gives up with everything still queued: a later sync collects it)
         // a registration whose workgroups were not all resident gives up (bounded spin), commits nothing
         // and poisons the frames queued behind it (they do nothing either): the frames in front are good
         int good = p->in_flight;
@@ -2131,7 +2365,10 @@ int kicp_pipeline_output_size(kicp_pipeline *p, int which, size_t *n) {
 // pinned bounce buffer of the output downloads
 static int pipe_out_stage(kicp_pipeline *p, size_t bytes) {
     if (p->out_stage_bytes >= bytes) return KICP_OK;
-    if (p->out_stage) KICP_HIP(hipHostFree(p->out_stage));
+    if (p->out_stage) {
+        KICP_TRY(wait_device(p->device, "output buffer growth"));  // (hipHostFree waits for the whole device)
+        KICP_HIP(hipHostFree(p->out_stage));
+    }
     p->out_stage = nullptr;
     p->out_stage_bytes = 0;
     const size_t want = bytes + bytes / 4;
@@ -2165,9 +2402,8 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
         const unsigned par = (unsigned)((p->frames_enqueued - 1) & 1u);  // the last frame's buffers
         const DevBuf &b = which == KICP_OUT_PREPROCESSED ? p->pre : which == KICP_OUT_SOURCE ? p->src[par] : p->fd[par];
         const size_t bytes = c * 3 * sizeof(double);
-        if (bytes < (size_t)256 * 1024) {  // small clouds: one direct copy
-            KICP_HIP(hipMemcpyAsync(out, b.p, bytes, hipMemcpyDeviceToHost, p->stream));
-            KICP_HIP(hipStreamSynchronize(p->stream));
+        if (bytes < (size_t)256 * 1024) {  // small clouds: one direct copy (the stream is idle: the size query above synchronised)
+            KICP_HIP(hipMemcpy(out, b.p, bytes, hipMemcpyDeviceToHost));
             return KICP_OK;
         }
         // large clouds (the preprocessed frame is ~3 MB): DMA into a pinned bounce buffer, then the helper
@@ -2175,7 +2411,7 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
         KICP_TRY(pipe_out_stage(p, bytes));
         KICP_TRY(pipe_reserve_staging(p));  // (creates the helper threads)
         KICP_HIP(hipMemcpyAsync(p->out_stage, b.p, bytes, hipMemcpyDeviceToHost, p->stream));
-        KICP_HIP(hipStreamSynchronize(p->stream));
+        KICP_TRY(wait_stream(p->stream, "output download"));
         pipe_spread_copy(p, out, p->out_stage, bytes);
     }
     return KICP_OK;
@@ -2194,7 +2430,10 @@ static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, 
     if (p->in_flight) KICP_TRY(pipe_sync(p, false));  // `pre` exists once: no frame may be queued behind this one
     KICP_TRY(pipe_stage_and_enqueue(p, xyz ? xyz : kNone, nullptr, n, timestamps, n_ts));
     const int par = (int)((p->frames_enqueued - 1) & 1u);
-    if (!p->copy_stream) KICP_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    if (!p->copy_stream) {
+        KICP_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        stream_register(p->device, p->copy_stream);
+    }
     // everything the front stages may have produced (at most n points) plus their counts, in one go: the counts are
     // only known on the device, and a second round trip to size the copy would cost more than the few bytes saved
     const size_t want = views ? n : (n < pre_cap ? n : pre_cap);
@@ -2205,7 +2444,7 @@ static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, 
     KICP_HIP(hipStreamWaitEvent(p->copy_stream, p->ev_prep_done[par], 0));
     KICP_HIP(hipMemcpyAsync(h_prep, p->prep.as<PrepState>() + par, sizeof(PrepState), hipMemcpyDeviceToHost, p->copy_stream));
     if (bytes) KICP_HIP(hipMemcpyAsync(p->out_stage, p->pre.p, bytes, hipMemcpyDeviceToHost, p->copy_stream));
-    KICP_HIP(hipStreamSynchronize(p->copy_stream));
+    KICP_TRY(wait_stream(p->copy_stream, "early download of the preprocessed frame"));
     const size_t got_pre = (size_t)h_prep->n_pre;
     const size_t c = got_pre < want ? got_pre : want;
     if (!views && c) pipe_spread_copy(p, pre_out, p->out_stage, c * 3 * sizeof(double));
@@ -2222,7 +2461,7 @@ static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, 
     *src_view = reinterpret_cast<const double *>(p->out_stage + off_src);
     if (*n_src) {
         KICP_HIP(hipMemcpyAsync(p->out_stage + off_src, p->src[par].p, *n_src * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-        KICP_HIP(hipStreamSynchronize(p->stream));
+        KICP_TRY(wait_stream(p->stream, "download of the source cloud"));
     }
     return KICP_OK;
 }
@@ -2420,7 +2659,10 @@ int kicp_device_alloc(int device_id, size_t bytes, void **d_ptr) {
 }
 int kicp_device_free(int device_id, void *d_ptr) {
     KICP_HIP(hipSetDevice(device_id));
-    if (d_ptr) KICP_HIP(hipFree(d_ptr));
+    if (d_ptr) {
+        KICP_TRY(wait_device(device_id, "kicp_device_free"));  // (hipFree waits for the whole device)
+        KICP_HIP(hipFree(d_ptr));
+    }
     return KICP_OK;
 }
 int kicp_device_upload(int device_id, void *d_dst, const void *h_src, size_t bytes) {
@@ -2437,8 +2679,7 @@ int kicp_device_download(int device_id, void *h_dst, const void *d_src, size_t b
 }
 int kicp_device_synchronize(int device_id) {
     KICP_HIP(hipSetDevice(device_id));
-    KICP_HIP(hipDeviceSynchronize());
-    return KICP_OK;
+    return wait_device(device_id, "kicp_device_synchronize");  // (the library's own streams and the null stream, with the deadline)
 }
 // Host self-test: the staging path's float64 -> float32 narrowing (AVX2 or scalar, as the staging threads run it).
 // *exact = 1 iff every value survives the round trip -- the only case in which a scan is uploaded as float32.
@@ -2463,9 +2704,11 @@ int kicp_selftest_tile_sort(int device_id, const double *xyz, size_t n, double v
                          hipMemcpy(cnt.p, &n_i, sizeof n_i, hipMemcpyHostToDevice) != hipSuccess))
         s = KICP_ERR_HIP;
     // as the pipeline calls it: the count on the device, the host knows a bound and a hint
-    if (s == KICP_OK && launch_tile_sort(pts.as<double>(), cnt.as<int>(), 0, n_bound, voxel_size, a.as<unsigned long long>(), b.as<unsigned long long>(), n_hint, nullptr) != 0)
+    hipStream_t us = util_stream(device_id);
+    if (s == KICP_OK && (!us || launch_tile_sort(pts.as<double>(), cnt.as<int>(), 0, n_bound, voxel_size, a.as<unsigned long long>(), b.as<unsigned long long>(), n_hint, us) != 0))
         s = KICP_ERR_HIP;
-    if (s == KICP_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(keys, b.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)) s = KICP_ERR_HIP;
+    if (s == KICP_OK) s = wait_stream(us, "sort self-test");
+    if (s == KICP_OK && hipMemcpy(keys, b.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) s = KICP_ERR_HIP;
     pts.release();
     a.release();
     b.release();
@@ -2485,9 +2728,11 @@ int kicp_selftest_solve(int device_id, const double *A, const double *b, size_t 
     KICP_TRY(dx.reserve(n * 6 * sizeof(double)));
     KICP_HIP(hipMemcpy(dA.p, A, n * 36 * sizeof(double), hipMemcpyHostToDevice));
     KICP_HIP(hipMemcpy(db.p, b, n * 6 * sizeof(double), hipMemcpyHostToDevice));
-    launch_selftest_solve(dA.as<double>(), db.as<double>(), (int)n, dx.as<double>(), nullptr);
+    hipStream_t us = util_stream(device_id);
+    if (!us) return KICP_ERR_HIP;
+    launch_selftest_solve(dA.as<double>(), db.as<double>(), (int)n, dx.as<double>(), us);
     KICP_HIP(hipGetLastError());
-    KICP_HIP(hipDeviceSynchronize());
+    KICP_TRY(wait_stream(us, "solve self-test"));
     KICP_HIP(hipMemcpy(x, dx.p, n * 6 * sizeof(double), hipMemcpyDeviceToHost));
     return KICP_OK;
 }
@@ -2532,6 +2777,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide_prefill")) {
         if (value < 0 || value > 8) return KICP_ERR_INVALID_ARG;
         options().icp_wide_prefill = value;
+    } else if (!strcmp(name, "icp_group_prune")) {
+        options().icp_group_prune = value != 0;
     } else if (!strcmp(name, "icp_schur_solve")) {
         options().icp_schur_solve = value != 0;
     } else if (!strcmp(name, "icp_wide_prune")) {
@@ -2587,6 +2834,12 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "queue_depth")) {
         if (value != 0 && (value < 2 || value > kicp_pipeline::kRing - 1)) return KICP_ERR_INVALID_ARG;
         options().queue_depth = value;
+    } else if (!strcmp(name, "wait_timeout_ms")) {
+        if (value < 0) return KICP_ERR_INVALID_ARG;
+        options().wait_timeout_ms = value;
+    } else if (!strcmp(name, "inject_stall_ms")) {
+        if (value < 0 || value > 60000) return KICP_ERR_INVALID_ARG;
+        options().inject_stall_ms = value;
     } else if (!strcmp(name, "map_apply_threads")) {
         if (value != 256 && value != 512 && value != 1024) return KICP_ERR_INVALID_ARG;
         options().map_apply_threads = value;

@@ -43,6 +43,7 @@ struct HipPipe {
         if (rc != KICP_OK) return rc;
         if ((rc = hip(hipSetDevice(dev), "hipSetDevice")) != KICP_OK) return rc;
         if ((rc = hip(hipStreamCreateWithFlags(&xchg, hipStreamNonBlocking), "hipStreamCreate")) != KICP_OK) return rc;
+        stream_register(dev, xchg);
         if ((rc = hip(hipMalloc(&d_send, bytes), "hipMalloc")) != KICP_OK) return rc;
         if ((rc = hip(hipMalloc(&d_recv, bytes * total), "hipMalloc")) != KICP_OK) return rc;
         if ((rc = hip(hipHostMalloc((void **)&h_send, bytes, hipHostMallocDefault), "hipHostMalloc")) != KICP_OK) return rc;
@@ -65,7 +66,10 @@ struct HipPipe {
     int get(void *host, size_t bytes) {
         int rc = hip(hipMemcpyAsync(h_recv, d_recv, bytes, hipMemcpyDeviceToHost, xchg), "hipMemcpyAsync(recv)");
         if (rc != KICP_OK) return rc;
-        if ((rc = hip(hipStreamSynchronize(xchg), "hipStreamSynchronize")) != KICP_OK) return rc;
+        if ((rc = wait_stream(xchg, "pose exchange")) != KICP_OK) {  // (bounded: a peer that never joins the collective must not hang this rank's host)
+            err = kicp_last_error();
+            return rc;
+        }
         memcpy(host, h_recv, bytes);
         return KICP_OK;
     }
@@ -73,11 +77,15 @@ struct HipPipe {
         if (device >= 0) (void)hipSetDevice(device);
         if (pipe) kicp_pipeline_destroy(pipe);
         pipe = nullptr;
-        if (d_send) (void)hipFree(d_send);
-        if (d_recv) (void)hipFree(d_recv);
-        if (h_send) (void)hipHostFree(h_send);
-        if (h_recv) (void)hipHostFree(h_recv);
-        if (xchg) (void)hipStreamDestroy(xchg);
+        // (hipFree / hipHostFree wait for the whole device: only behind a bounded wait; a device that does not answer keeps them)
+        const bool gone = (!xchg || wait_stream(xchg, "batch teardown") == KICP_OK) && (device < 0 || wait_device(device, "batch teardown") == KICP_OK);
+        if (gone) {
+            if (d_send) (void)hipFree(d_send);
+            if (d_recv) (void)hipFree(d_recv);
+            if (h_send) (void)hipHostFree(h_send);
+            if (h_recv) (void)hipHostFree(h_recv);
+        }
+        if (xchg) (void)stream_destroy(xchg);
         d_send = d_recv = nullptr;
         h_send = h_recv = nullptr;
         xchg = nullptr;

@@ -381,7 +381,7 @@ __device__ __forceinline__ bool tile_fill_bulk(MapView m, Tile tile, IcpShared *
                     const unsigned j = owner[p - s0];
                     if (j != 0xFFFFu) {
                         const unsigned w0 = jobs[2 * j], w1 = jobs[2 * j + 1];
-                        const int blk = (int)(w0 & 0xFFFFFFu), i = p - (int)(w1 & 0xFFFFu);
+                        const int blk = (int)(w0 & 0xFFFFFFu), i = KICP_IDX(m.dbg, m.ctr + C_ERR, p - (int)(w1 & 0xFFFFu), m.max_points, 5);
                         xy[u] = block_xy(m, blk)[i];
                         zz[u] = block_z(m, blk)[i];
                         ok[u] = true;
@@ -467,6 +467,7 @@ struct IcpRunArgs {  // (by value: a reference would pin the kernel's parameter 
     PipeState *state;
     int weight_base, weight_long_base, weight_long_emul, weight_quad, dense_min, dense_div;
     unsigned spin_limit;
+    BoundsRec *dbg;
 };
 // THREAD_PER_POINT: long runs are weighed by a thread per point (the thread-per-query form of the kernel; the group form
 // keeps its registers as they were)
@@ -502,7 +503,7 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     // configuration (profiles/r04_r_icp_probe_livox100.txt).  Same c, same E, same weight.
     if (THREAD_PER_POINT && long_runs) {
         for (int q = s0 + tid; q < s1; q += kIcpThreads) {
-            const int p = min((int)(P.order[q] & 0xFFFFFFull), n - 1);
+            const int p = KICP_IDX(P.dbg, &st->err, key_index(P.order[q]), n, 1);
             const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
             double sp[3];
             se3_act(guess, pin, sp);
@@ -546,10 +547,7 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     }
     // (short runs) one 32-lane group per point: lane j looks up the j-th voxel of the point's 27-neighbourhood (all in flight together)
     for (int q = s0 + tid / kIcpGroup; !(THREAD_PER_POINT && long_runs) && q < s1; q += kIcpGroupsPerBlock) {
-        // (The clamp never changes a value -- checked on the device: every key read here has index < n -- yet without it
-        // this loop raised a memory fault (ROCm 7.2, gfx950): the point load evidently also executes, at some index
-        // made of a stale key, for lanes the loop condition excludes.  With the clamp any such load stays inside the cloud.)
-        const int p = min((int)(P.order[q] & 0xFFFFFFull), n - 1);
+        const int p = KICP_IDX(P.dbg, &st->err, key_index(P.order[q]), n, 2);
         const double pin[3] = {P.frame[3 * p], P.frame[3 * p + 1], P.frame[3 * p + 2]};
         double sp[3];
         se3_act(guess, pin, sp);
@@ -755,6 +753,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         R.dense_min = P.weight_dense_min;
         R.dense_div = P.weight_dense_div;
         R.spin_limit = P.spin_limit;
+        R.dbg = m.dbg;
         if (!icp_weighted_run<WIDE>(R, &sh, guess, epoch_base, n, G)) {
             if (tid == 0) {
                 atomicOr(&st->err, E_TIMEOUT);
@@ -771,7 +770,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         n_local = max(0, min(n_run, n - q0));
     }
     const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, WIDE ? kWideChunk : kIcpMaxMeta) : 0;
-    const bool use_lists = !WIDE && n_meta > 0 && n_local <= kIcpListRunMax;
+    const bool use_lists = !WIDE && !P.group_prune && n_meta > 0 && n_local <= kIcpListRunMax;  // (the pruned search keeps no lists: the region is all points)
     // LDS behind the fixed part: only as many point slots of a chunk as the run can fill (a run of 16 points leaves
     // 9 KiB of the 128 to the tile), then the query records, the table, and the region of points and lists
     // (WIDE: all of sh.pts stays -- the slow-path queue and, with sh.terms, phase C's rows; 20-byte query records)
@@ -899,7 +898,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 if (active) {
                     double pin[3];
                     if (it == 0) {
-                        const int p = P.order ? (int)(P.order[q0 + j] & 0xFFFFFFull) : q0 + j;
+                        const int p = KICP_IDX(m.dbg, &st->err, P.order ? key_index(P.order[q0 + j]) : q0 + j, n, 3);
                         pin[0] = P.frame[3 * p];
                         pin[1] = P.frame[3 * p + 1];
                         pin[2] = P.frame[3 * p + 2];
@@ -985,7 +984,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 auto serve = [&](int mode, int *counter) -> int {
                     bool pending = active && wq.flag == mode;
                     int served = 0;
-                    for (;;) {
+                    // (every round serves up to kWideQueue of the at most kWideChunk pending queries: the trip count is bounded)
+                    for (int round = 0; round < kWideChunk / kWideQueue + 2; ++round) {
                         int slot = -1;
                         if (pending) {
                             slot = atomicAdd(counter, 1);
@@ -1287,6 +1287,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                 };
                 for (int round = 0;; ++round) {
+                    if (round >= kWideRoundLimit) {  // (every round files at least one item while any is pending: far beyond any real count)
+                        if (tid == 0) sh.fail = 1;   // ... the launch gives up like a failed exchange instead of spinning
+                        break;
+                    }
                     const unsigned tr0 = PROF ? ticks32() : 0u;
                     // (while the store is empty -- the first iteration, as a rule -- the whole queue is the map's.  The store only
                     // changes between barriers of this loop and in the window phases: every thread reads the same value here.)
@@ -1470,7 +1474,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // ---- A -------------------------------------------------------------------------------------
             if (tid < cn) {
                 const int j = base + tid;
-                const int p = P.order ? (int)(P.order[q0 + j] & 0xFFFFFFull) : q0 + j;
+                const int p = KICP_IDX(m.dbg, &st->err, P.order ? key_index(P.order[q0 + j]) : q0 + j, n, 4);
                 const bool has_meta = j < n_meta;
                 IcpQueryMeta *meta = metas + (has_meta ? j : 0);
                 double pin[3];
@@ -1565,7 +1569,36 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 double d2 = DBL_MAX;
                 int E = 0;
                 bool listed = false;
-                if (flag == 0 && use_lists && meta->list_state >= 0) {
+                if (flag == 0 && P.group_prune) {
+                    // cells skipped by their box bounds (group_scan_pruned, kicp_icp_wide.hpp).  First limit: the last
+                    // neighbour's distance, as the scan itself would compute it -- it is a point of these 27 cells as long as
+                    // the query is in the voxel it was found from (meta: lv = that voxel, list_base = its position in the
+                    // store, list_state 2) --, else the correspondence threshold.
+                    double limit0 = (max_dist * max_dist) * (1.0 + 0x1p-40);  // sqrt(d) < max_dist (Registration.cpp:72) implies d below this
+                    if (meta->list_state == 2 && meta->list_base >= 0 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz) {
+                        const double *q = tile.points + 3 * meta->list_base;
+                        const double ex = q[0] - s[0], ey = q[1] - s[1], ez = q[2] - s[2];
+                        const double dp = (ex * ex + ey * ey) + ez * ez;
+                        limit0 = dp < limit0 ? dp : limit0;
+                    }
+                    const int vv[3] = {vx, vy, vz};
+                    int bad, npos;
+                    d2 = group_scan_pruned(m, tile, s, vv, limit0, lane, nn, E, bad, npos);
+                    listed = true;
+                    path = 2;
+                    if (bad) {
+                        if (bad == 2 && lane == 0) meta->valid = -1;
+                        flag = 2;
+                        path = 3;
+                    } else if (lane == 0) {
+                        meta->lv[0] = vx;
+                        meta->lv[1] = vy;
+                        meta->lv[2] = vz;
+                        meta->list_base = npos;
+                        meta->list_state = 2;
+                    }
+                }
+                if (flag == 0 && !listed && use_lists && meta->list_state >= 0) {
                     // the scan list belongs to the voxel the query was in when it was built
                     if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz)
                         tile_list_build(tile, vx, vy, vz, lane, meta);

@@ -69,7 +69,46 @@ enum MapCtr {
     C_COUNT = 12 * kCtrStride
 };
 
-enum ErrBits { E_RANGE = 1, E_TABLE_FULL = 2, E_POOL_FULL = 4, E_TIMEOUT = 8 };
+enum ErrBits { E_RANGE = 1, E_TABLE_FULL = 2, E_POOL_FULL = 4, E_TIMEOUT = 8, E_BOUNDS = 16 };
+
+// ---- the bounds-asserting build (make DEBUG_BOUNDS=1 -> -DKICP_DEBUG_BOUNDS) --------------------------------------
+// Every index a kernel takes FROM DEVICE MEMORY and then dereferences -- sorted keys, point indices, block ids, slot
+// numbers, store positions, list offsets -- goes through KICP_IDX(dbg, err, idx, limit, tag).  The debug build checks it:
+// the first violation of a launch is recorded in the device's BoundsRec {source line, tag, index, limit, workgroup,
+// thread}, E_BOUNDS is raised in the error word the kernel reports through, and the index is replaced by 0 so that the
+// launch ends instead of faulting; the host turns the bit into KICP_ERR_HIP with the record spelled out.  The release
+// build compiles the macro to the bare index: no instruction, no register.
+struct BoundsRec {
+    int taken;  // 0 until the first violation claims the record (atomicCAS)
+    int line;
+    long long idx, limit;
+    int block, thread;
+    int tag, pad;
+};
+#ifdef KICP_DEBUG_BOUNDS
+__device__ __forceinline__ long long kicp_bounds_fail(BoundsRec *dbg, int *err, long long idx, long long limit, int line, int tag) {
+    if (err) atomicOr(err, E_BOUNDS);
+    if (dbg && atomicCAS(&dbg->taken, 0, 1) == 0) {
+        dbg->line = line;
+        dbg->idx = idx;
+        dbg->limit = limit;
+        dbg->block = (int)blockIdx.x;
+        dbg->thread = (int)threadIdx.x;
+        dbg->tag = tag;
+    }
+    return 0;
+}
+template <class T>
+__device__ __forceinline__ T kicp_idx(BoundsRec *dbg, int *err, T idx, long long limit, int line, int tag) {
+    if ((unsigned long long)(long long)idx < (unsigned long long)limit) return idx;
+    return (T)kicp_bounds_fail(dbg, err, (long long)idx, limit, line, tag);
+}
+#define KICP_IDX(dbg, err, idx, limit, tag) ::kicp::kicp_idx((dbg), (err), (idx), (long long)(limit), __LINE__, (tag))
+constexpr bool kDebugBounds = true;
+#else
+#define KICP_IDX(dbg, err, idx, limit, tag) (idx)
+constexpr bool kDebugBounds = false;
+#endif
 
 struct MapView {
     Slot *slots;
@@ -86,15 +125,20 @@ struct MapView {
     double voxel_size;
     double max_distance;
     double map_resolution;  // sqrt(voxel_size^2 / max_points)  VoxelHashMap.cpp:98
+    BoundsRec *dbg;         // the device's record of the bounds-asserting build (never touched by the release build)
 };
 
+// (every block id comes from device memory -- a slot, a table entry, the free ring: the bounds-asserting build checks them all here)
 __device__ __forceinline__ BlockHdr *block_hdr(const MapView &m, int b) {
+    b = KICP_IDX(m.dbg, m.ctr + C_ERR, b, m.blocks_cap, 100);
     return reinterpret_cast<BlockHdr *>(m.blocks + (size_t)b * m.stride);
 }
 __device__ __forceinline__ double2 *block_xy(const MapView &m, int b) {
+    b = KICP_IDX(m.dbg, m.ctr + C_ERR, b, m.blocks_cap, 101);
     return reinterpret_cast<double2 *>(m.blocks + (size_t)b * m.stride + kBlockHeader);
 }
 __device__ __forceinline__ double *block_z(const MapView &m, int b) {
+    b = KICP_IDX(m.dbg, m.ctr + C_ERR, b, m.blocks_cap, 102);
     return reinterpret_cast<double *>(m.blocks + (size_t)b * m.stride + m.z_off);
 }
 
@@ -223,6 +267,7 @@ struct IcpParams {
     int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int schur_solve;       // solve well-conditioned normal equations through their 3 x 3 Schur complement (kicp_math.hpp: schur3_solve)
+    int group_prune;       // group form: searches skip cells by their box bounds, the last neighbour's distance as first limit (group_scan_pruned)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
@@ -265,6 +310,7 @@ struct Options {
     long icp_points_per_group = 1;
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
+    long icp_group_prune = 1;    // group form of the association: skip cells by their box bounds (exact; 0: every point of the 27 cells is read)
     long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
@@ -298,15 +344,34 @@ struct Options {
     long map_rehash_every = 0;   // test hook: a pipeline rebuilds its map's slot array in stream order every N frames
     long downsample_order = 1;   // VoxelDownsample output order: 1 the reference's (tsl::robin_map bucket order), 0 ascending index
     long queue_depth = 4;        // frames a pipeline keeps queued on the device before an asynchronous entry waits (>= 2; 0: no limit)
+    long wait_timeout_ms = 120000;  // deadline of every host-side wait for the device (kicp_wait.hpp); 0: none
+    long inject_stall_ms = 0;    // test hook: the next piece of work a handle queues is preceded by a kernel that spins this long
 };
 Options &options();
 
-// growable device buffer
+// ---- every host-side wait for the device has a deadline (kicp_api.hip) ---------------------------------------------
+// hipStreamSynchronize / hipEventSynchronize block for as long as the device takes -- for ever, if a kernel never ends.
+// The library never calls them: a stream or an event is POLLED (hipStreamQuery / hipEventQuery) against a wall-clock
+// limit (option "wait_timeout_ms"), and a wait that does not end returns KICP_ERR_TIMEOUT naming what was waited for.
+// The calls that synchronise implicitly (hipFree, hipHostFree, hipStreamDestroy, the blocking hipMemcpy) are only made
+// behind such a wait, over every stream the library has created on the device; when that wait gives up the resource is
+// leaked, not freed -- a leak can be lived with, a process that never returns cannot.
+int wait_stream(hipStream_t s, const char *what);
+int wait_event(hipEvent_t e, const char *what);
+int wait_device(int device_id, const char *what);  // every stream libkicp has created on the device
+hipStream_t util_stream(int device_id);            // the library's own stream for buffer initialisation (nullptr: creation failed)
+void stream_register(int device_id, hipStream_t s);
+void stream_forget(hipStream_t s);
+int stream_destroy(hipStream_t s);  // waits (bounded), forgets, destroys; KICP_ERR_TIMEOUT: the stream is leaked
+void inject_stall(hipStream_t s);   // test hook (option "inject_stall_ms")
+
+// growable device buffer; a new buffer starts as zeros (the tagged-granule exchanges rely on it: no launch uses tag 0)
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    int reserve(size_t need, bool keep = false, hipStream_t s = nullptr);
-    void release();
+    int reserve(size_t need, bool keep = false, hipStream_t s = nullptr);  // s: the stream the old contents are final on (keep); nullptr: the device's utility stream
+    void release();             // behind a bounded wait for the device (hipFree synchronises); a device that does not answer keeps the memory
+    void drop(bool device_idle);  // the caller has made that wait for several buffers at once: free (idle) or leak (not)
     template <class T>
     T *as() const {
         return static_cast<T *>(p);
@@ -314,6 +379,7 @@ struct DevBuf {
 };
 
 int check_device(int device_id);
+BoundsRec *bounds_rec(int device_id);  // the device's BoundsRec (allocated on first use, zeroed), or nullptr
 
 }  // namespace kicp
 

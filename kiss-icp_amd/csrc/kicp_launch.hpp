@@ -28,6 +28,7 @@ struct PreParams {
     double ds_voxel;
     int *ds_slot_of;
     int *err;
+    BoundsRec *dbg;  // (bounds-asserting build)
 };
 
 // VoxelDownsample (core/VoxelUtils.cpp:7-21)
@@ -59,6 +60,7 @@ struct DsParams {
     double next_voxel;
     int *next_slot_of;
     int *err;
+    BoundsRec *dbg;  // (bounds-asserting build)
 };
 
 // spatial order of the source cloud (kicp_sort.hip): keys = {Morton code of the 2-voxel cell, index}, sorted runs merged by rank

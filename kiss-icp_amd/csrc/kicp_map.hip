@@ -187,6 +187,7 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
         int slot = -1, L = 0, head = -1, my_idx = 0x7FFFFFFF;
         if (t < touched) {
             slot = sc.rec_slot[t];
+            if (slot >= 0) slot = KICP_IDX(m.dbg, m.ctr + C_ERR, slot, (long long)m.mask + 1, 31);
             L = sc.rec_count[t];
             head = sc.rec_head[t];
             if (lane < L && lane < kRecList) my_idx = sc.rec_list[t * kRecList + lane];
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void k_map_prune(MapView m, const PipeState *s
             }
         }
         if (dies) {
-            Slot *sl = m.slots + hdr->slot;
+            Slot *sl = m.slots + KICP_IDX(m.dbg, m.ctr + C_ERR, hdr->slot, (long long)m.mask + 1, 30);
             sl->key = kKeyTomb;
             sl->block = -1;
             sl->count = 0;
@@ -387,10 +388,18 @@ __global__ __launch_bounds__(256) void k_map_rehash(MapView m) {
         if (hdr->count <= 0) continue;
         const unsigned long long key = hdr->key;
         uint32_t s = hash_key(key, m.mask);
-        for (;;) {
+        bool placed = false;
+        for (uint32_t probes = 0; probes <= m.mask; ++probes) {  // (bounded by the table: a slot array without room is an error, not a spin)
             const unsigned long long old = atomicCAS(&m.slots[s].key, kKeyEmpty, key);
-            if (old == kKeyEmpty) break;
+            if (old == kKeyEmpty) {
+                placed = true;
+                break;
+            }
             s = (s + 1) & m.mask;
+        }
+        if (!placed) {
+            atomicOr(&m.ctr[C_ERR], E_TABLE_FULL);
+            continue;
         }
         m.slots[s].block = b;
         m.slots[s].count = hdr->count;

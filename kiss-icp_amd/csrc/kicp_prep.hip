@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
     int s = -1;
     if (i < n) {
         s = P.slot_of[i];
+        if (s >= 0) s = KICP_IDX(P.dbg, P.err, s, (long long)P.mask + 1, 21);
         keep = (s >= 0) && (P.tab[s].minidx == i);
     }
     int total, grand;
@@ -395,7 +396,11 @@ __device__ __forceinline__ void ds_arrange_wave(const DsParams &P, uint32_t mask
 // a cluster longer than a wave (an adversarial cloud: the table is at most half full): one lane replays it in global memory
 __device__ void ds_arrange_serial(const DsParams &P, uint32_t mask, int b) {
     int c = 0;
-    while (P.tab[((uint32_t)b + (uint32_t)c) & mask].key != kKeyEmpty) ++c;
+    while ((uint32_t)c <= mask && P.tab[((uint32_t)b + (uint32_t)c) & mask].key != kKeyEmpty) ++c;
+    if ((uint32_t)c > mask) {  // no empty bucket at all: the grid is at most half full by construction, so this is a broken table -- say so, do not spin
+        atomicOr(P.err, E_TABLE_FULL);
+        return;
+    }
     for (int j = 0; j < c; ++j) P.rb_elem[((uint32_t)b + (uint32_t)j) & mask] = -1;
     int last = -1;
     for (int step = 0; step < c; ++step) {
@@ -411,7 +416,7 @@ __device__ void ds_arrange_serial(const DsParams &P, uint32_t mask, int b) {
         const unsigned long long key = P.tab[((uint32_t)b + (uint32_t)bj) & mask].key;
         int cur_t = best;
         int cur_h = (int)((ref_home(key, mask) - (uint32_t)b) & mask);
-        for (int pos = cur_h;; ++pos) {
+        for (int pos = cur_h; pos < c; ++pos) {  // (a walker settles inside its cluster: c buckets hold c elements)
             const uint32_t slot = ((uint32_t)b + (uint32_t)pos) & mask;
             const int et = P.rb_elem[slot];
             if (et < 0) {
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter_rb(DsParams P) {
     const int base = block_base(P.blk_counts, &grand);
     const int j = base + block_exclusive_scan(occ, total);
     if (occ) {
-        const int i = P.rb_elem[b];
+        const int i = KICP_IDX(P.dbg, P.err, P.rb_elem[b], n, 20);
         const double x = P.in[3 * i], y = P.in[3 * i + 1], z = P.in[3 * i + 2];
         P.out[3 * j] = x;
         P.out[3 * j + 1] = y;

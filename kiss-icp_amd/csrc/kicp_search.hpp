@@ -47,6 +47,25 @@ __device__ __forceinline__ void granule_store_pair(__amdgpu_buffer_rsrc_t r, uns
 
 __device__ __forceinline__ int count_of(const int *n_ptr, int n_imm) { return n_ptr ? *n_ptr : n_imm; }
 
+// Point index of a sorted tile key {30-bit Morton code | 24-bit index} (kicp_sort.hip).
+// THE ROOT CAUSE OF ROUND 3's "memory fault that vanishes with a clamp" (profiles/README.md r05_g): hipcc (ROCm 7.2, gfx950)
+// miscompiles  frame[3 * (int)(key & 0xFFFFFF)]  when the product feeds a 64-bit address.  The 24-bit mask lets the backend
+// treat the multiplication as a 24-bit one (MUL_U24), whose operands demand only their low 24 bits -- so the AND is deleted
+// as redundant -- and then the multiply-add is selected as the FULL 32-bit v_mad_u64_u32 after all:
+//     global_load_dword v6, v[8:9], off                   ; low half of the key
+//     v_mad_u64_u32 v[12:13], s[18:19], v6, 24, s[20:21]  ; frame + 24 * v6 -- the Morton code's low byte still in bits 24..31
+// i.e. a load up to 96 GB beyond the cloud whenever that byte is not zero: a memory fault, or -- where the address happens
+// to be mapped -- a garbage point (in the run-weight prologue that changes a weight, hence nothing).  Any use of the masked
+// value that is not a multiplication (round 3's min(p, n - 1)) makes the compiler keep the AND, which is why the clamp
+// "fixed" it.  Here the masked value goes through an empty asm statement: the compiler cannot see through it, so the AND
+// is materialised, at no instruction's cost.  tests/test_codegen_masks.py disassembles the built library and fails if a
+// freshly loaded word ever reaches such a multiply-add unmasked again.
+__device__ __forceinline__ int key_index(unsigned long long key) {
+    int p = (int)((unsigned)key & 0xFFFFFFu);
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------
 // voxel hash lookups
 // ------------------------------------------------------------------------------------------
@@ -843,7 +862,7 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
         double x[U], y[U], z[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const double *q = P + 3 * pos[u];
+            const double *q = P + 3 * KICP_IDX((BoundsRec *)nullptr, (int *)nullptr, pos[u], tile.cap_points, 9);
             x[u] = q[0];
             y[u] = q[1];
             z[u] = q[2];

@@ -79,8 +79,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_LIB_PATH)
+    # KISS_ORACLE_LIB: another build of the same restatement (oracle/Makefile `sanitize`: ASan + UBSan)
+    alt = os.environ.get("KISS_ORACLE_LIB")
+    if not alt:
+        build()
+    L = C.CDLL(alt or _LIB_PATH)
     vp, sz, d, i = C.c_void_p, C.c_size_t, C.c_double, C.c_int
     sig = {
         "ko_se3_from_matrix": (i, [_dp, vp]),
