@@ -422,11 +422,14 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
  *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
  *                     iterations.  Results are bitwise the same either way.
- *   "icp_group_prune"  1 (default): the 32-lane-group form of the association skips cells of the 27 whose box lies strictly farther
+ *   "icp_group_prune"  1: the 32-lane-group form of the association skips cells of the 27 whose box lies strictly farther
  *                     than a candidate already in hand (first the last iteration's neighbour, then the best of every trip) and
- *                     spreads the points of the cells it does read over the lanes; 0: every point of the 27 cells is read
- *                     (scan lists / a lane per cell, rounds 2-4).  Exact: a skipped cell loses every comparison of
- *                     VoxelHashMap.cpp:58-63 anyway; pose, iteration count and examined count are bitwise the same.
+ *                     spreads the points of the cells it does read over the lanes; 0 (default): every point of the 27 cells is
+ *                     read (scan lists / a lane per cell).  Exact: a skipped cell loses every comparison of
+ *                     VoxelHashMap.cpp:58-63 anyway; pose, iteration count and examined count are bitwise the same
+ *                     (tests/test_gpu_paths.py).  Off because it measured slower on the bench scene (2455 against 2885 scans/s,
+ *                     profiles/r05_j_*): with ~20 points per workgroup a search costs its fixed instruction stream, not its
+ *                     ~240 candidates.
  *   "icp_schur_solve"  1 (default): the 6 x 6 normal equations of a Gauss-Newton step, whose top-left block is (sum w) I, are solved
  *                     through their 3 x 3 Schur complement when that is well conditioned (pivots above 1e-9 of the diagonal);
  *                     0: always by the pivoted 6 x 6 LDLT of Eigen that the reference calls (Registration.cpp:156).  The two

@@ -17,8 +17,13 @@ struct Registration {
     explicit Registration(int max_num_iteration, double convergence_criterion, int max_num_threads);
     Registration(int max_num_iteration, double convergence_criterion, int max_num_threads, int device_id);
     ~Registration();
-    Registration(const Registration &) = delete;
-    Registration &operator=(const Registration &) = delete;
+    // The reference's Registration is an implicitly copyable struct of three parameters (core/Registration.hpp:33-45).  A
+    // copy here is a second registration with the same parameters on the same device (its own stream and scratch buffers;
+    // the statistics of the last call travel with it); moving hands the handle over.
+    Registration(const Registration &other);
+    Registration &operator=(const Registration &other);
+    Registration(Registration &&other) noexcept;
+    Registration &operator=(Registration &&other) noexcept;
 
     Sophus::SE3d AlignPointsToMap(const std::vector<Eigen::Vector3d> &frame,
                                   const VoxelHashMap &voxel_map,
@@ -42,5 +47,6 @@ struct Registration {
     unsigned long long last_points_examined_ = 0;
 
     kicp_registration *handle_ = nullptr;
+    int device_id_ = 0;
 };
 }  // namespace kiss_icp

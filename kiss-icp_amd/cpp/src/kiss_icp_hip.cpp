@@ -163,12 +163,50 @@ Registration::Registration(int max_num_iteration, double convergence_criterion, 
 Registration::Registration(int max_num_iteration, double convergence_criterion, int max_num_threads, int device_id)
     : max_num_iterations_(max_num_iteration),
       convergence_criterion_(convergence_criterion),
-      max_num_threads_(max_num_threads) {
+      max_num_threads_(max_num_threads),
+      device_id_(device_id) {
     check(kicp_registration_create(max_num_iteration, convergence_criterion, max_num_threads, device_id, &handle_),
           "Registration");
 }
 Registration::~Registration() {
     if (handle_) kicp_registration_destroy(handle_);
+}
+Registration::Registration(const Registration &o)
+    : Registration(o.max_num_iterations_, o.convergence_criterion_, o.max_num_threads_, o.device_id_) {
+    last_iterations_ = o.last_iterations_;
+    last_converged_ = o.last_converged_;
+    last_points_examined_ = o.last_points_examined_;
+}
+Registration &Registration::operator=(const Registration &o) {
+    if (this == &o) return *this;
+    Registration fresh(o);  // (the public parameter fields may have been edited since construction: a new handle from what they say now)
+    *this = std::move(fresh);
+    return *this;
+}
+Registration::Registration(Registration &&o) noexcept
+    : max_num_iterations_(o.max_num_iterations_),
+      convergence_criterion_(o.convergence_criterion_),
+      max_num_threads_(o.max_num_threads_),
+      last_iterations_(o.last_iterations_),
+      last_converged_(o.last_converged_),
+      last_points_examined_(o.last_points_examined_),
+      handle_(o.handle_),
+      device_id_(o.device_id_) {
+    o.handle_ = nullptr;
+}
+Registration &Registration::operator=(Registration &&o) noexcept {
+    if (this == &o) return *this;
+    if (handle_) kicp_registration_destroy(handle_);
+    max_num_iterations_ = o.max_num_iterations_;
+    convergence_criterion_ = o.convergence_criterion_;
+    max_num_threads_ = o.max_num_threads_;
+    last_iterations_ = o.last_iterations_;
+    last_converged_ = o.last_converged_;
+    last_points_examined_ = o.last_points_examined_;
+    handle_ = o.handle_;
+    device_id_ = o.device_id_;
+    o.handle_ = nullptr;
+    return *this;
 }
 
 Sophus::SE3d Registration::AlignPointsToMap(const std::vector<Eigen::Vector3d> &frame, const VoxelHashMap &voxel_map,

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <immintrin.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
@@ -137,10 +138,8 @@ int wait_device(int device_id, const char *what) {
     }
     // (a stream destroyed by another thread between the copy and the query: the query fails, which ends the wait --
     // handles are not destroyed under other threads' calls by contract)
-    // (the NULL stream is not polled: the library queues nothing on it -- its blocking copies are over when they return.
-    // A first version zero-filled new buffers on the null stream and polled hipStreamQuery(nullptr): the first process of
-    // a fresh box died of a memory fault in its first kernels, profiles/README.md r05_e; with a stream of the library's own
-    // the polling is the same mechanism as everywhere else)
+    // (the NULL stream is not polled: the library queues nothing on it -- new buffers are zero-filled on a stream of its
+    // own, util_stream, and its blocking copies are over when they return)
     for (hipStream_t s : mine) KICP_TRY(wait_stream(s, what));
     return KICP_OK;
 }
@@ -517,6 +516,28 @@ private:
     std::atomic<unsigned long> gen_hint_{0};  // copy of gen_ the helpers may read without the lock
     bool quit_ = false;
 };
+
+// CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota (containers on GPU boxes: 16 of 256)
+static long available_cpus() {
+    long n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (long)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0) {
+                const long c = (quota + period - 1) / period;
+                if (c < n || n <= 0) n = c;
+            }
+        }
+        fclose(f);
+    }
+    return n > 0 ? n : 1;
+}
+static std::atomic<int> g_live_pipelines{0};  // pipelines of this process (all devices): they share the host's cores
 
 // f64 -> f32 narrowing of a block of coordinates; true iff every value survives the round trip, i.e. the
 // data came from a float32 sensor file (datasets/kitti.py:66, ROS PointCloud2) and nothing is lost
@@ -1545,9 +1566,14 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
     }
     p->stage_points = p->cap_points;
     if (!p->pool) {
+        // Helper threads only as far as the host has cores for them: every pipeline of the process has a caller (or a batch
+        // worker) that stages too, and the cores are the container's, not the box's -- 8 streams x (1 + 3) threads on the 16
+        // CPUs a GPU box's container gets would fight each other (round 4's review).  Each pipeline's share of the usable
+        // CPUs, minus one for its caller and one to spare, caps its helpers: 1 stream on 16 CPUs -> the option's 3, 8 -> 0.
         long helpers = options().staging_threads;
-        const long hw = (long)std::thread::hardware_concurrency();
-        if (hw > 0 && helpers > hw - 1) helpers = hw - 1;
+        const int live = g_live_pipelines.load(std::memory_order_relaxed);
+        const long share = available_cpus() / (live > 0 ? live : 1) - 2;
+        if (helpers > share) helpers = share;
         if (helpers < 0) helpers = 0;
         p->pool = new (std::nothrow) StagePool((int)helpers);
         if (!p->pool) return KICP_ERR_OOM;
@@ -2026,6 +2052,7 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     if (!p) return KICP_ERR_OOM;
     p->device = device_id;
     p->cfg = *cfg;
+    g_live_pipelines.fetch_add(1, std::memory_order_relaxed);
     p->inject_timeouts = (int)options().icp_inject_timeout;
     p->inject_skip = (int)options().icp_inject_timeout_skip;
     p->ds_order = options().downsample_order != 0 ? 1 : 0;
@@ -2105,6 +2132,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
         if (s && idle == KICP_OK) idle = wait_stream(s, "pipeline teardown");
     if (idle == KICP_OK) idle = wait_device(p->device, "pipeline teardown");  // (hipHostFree below waits for the whole device)
     const bool gone = idle == KICP_OK;  // nothing of this pipeline is in flight any more
+    g_live_pipelines.fetch_sub(1, std::memory_order_relaxed);
     delete p->pool;
     p->pool = nullptr;
     if (p->map) {  // (the map lives on the pipeline's stream: the wait above was its wait too)

@@ -771,6 +771,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     }
     const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, WIDE ? kWideChunk : kIcpMaxMeta) : 0;
     const bool use_lists = !WIDE && !P.group_prune && n_meta > 0 && n_local <= kIcpListRunMax;  // (the pruned search keeps no lists: the region is all points)
+    // the pruned search's cell tables (128 bytes each: the table values of a query's 27 cells), at the very end of LDS: one
+    // per group as scratch, and -- for short runs -- one per query, kept while the query stays in its voxel
+    const bool query_tabs = !WIDE && P.group_prune && n_meta > 0 && n_local <= kIcpListRunMax;
+    const int cell_tabs = (!WIDE && P.group_prune && n_meta > 0) ? kIcpGroupsPerBlock + (query_tabs ? n_meta : 0) : 0;
+    unsigned *cell_mem = reinterpret_cast<unsigned *>(smem + P.lds_bytes - cell_tabs * 128);
     // LDS behind the fixed part: only as many point slots of a chunk as the run can fill (a run of 16 points leaves
     // 9 KiB of the 128 to the tile), then the query records, the table, and the region of points and lists
     // (WIDE: all of sh.pts stays -- the slow-path queue and, with sh.terms, phase C's rows; 20-byte query records)
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         tile.vals = tile.keys + slots;
         q += (size_t)2 * slots * sizeof(unsigned);
         tile.points = reinterpret_cast<double *>(q);
-        const long room = (long)P.lds_bytes - (long)(q - smem);
+        const long room = (long)P.lds_bytes - (long)(q - smem) - (long)cell_tabs * 128;
         tile.region_bytes = n_meta > 0 && room > 0 ? (unsigned)min(room, (long)0xFFFF * 24) & ~15u : 0u;
         tile.cap_points = (int)(tile.region_bytes / 24u);
         tile.lists = use_lists ? reinterpret_cast<unsigned short *>(q) : nullptr;
@@ -1575,7 +1580,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     // the query is in the voxel it was found from (meta: lv = that voxel, list_base = its position in the
                     // store, list_state 2) --, else the correspondence threshold.
                     double limit0 = (max_dist * max_dist) * (1.0 + 0x1p-40);  // sqrt(d) < max_dist (Registration.cpp:72) implies d below this
-                    if (meta->list_state == 2 && meta->list_base >= 0 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz) {
+                    const bool same = meta->list_state == 2 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz;
+                    if (same && meta->list_base >= 0) {
                         const double *q = tile.points + 3 * meta->list_base;
                         const double ex = q[0] - s[0], ey = q[1] - s[1], ez = q[2] - s[2];
                         const double dp = (ex * ex + ey * ey) + ez * ez;
@@ -1583,7 +1589,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                     const int vv[3] = {vx, vy, vz};
                     int bad, npos;
-                    d2 = group_scan_pruned(m, tile, s, vv, limit0, lane, nn, E, bad, npos);
+                    const bool cached = same && query_tabs;  // the cells' entries (and the examined count) are those of the last search
+                    unsigned *tab = cell_mem + 32 * (query_tabs ? kIcpGroupsPerBlock + base + t : grp);
+                    E = cached ? (int)meta->list_n : 0;
+                    d2 = group_scan_pruned(m, tile, s, vv, limit0, lane, nn, E, bad, npos, tab, cached);
                     listed = true;
                     path = 2;
                     if (bad) {
@@ -1595,6 +1604,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         meta->lv[1] = vy;
                         meta->lv[2] = vz;
                         meta->list_base = npos;
+                        meta->list_n = (unsigned short)E;
                         meta->list_state = 2;
                     }
                 }

@@ -828,13 +828,17 @@ __device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &
 // cell read from the map, or none) for the next iteration's limit; bad as tile_scan.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double group_scan_pruned(const MapView &m, const Tile &tile, const double s[3], const int v[3], double limit0, int lane, double nn[3],
-                                                    int &examined, int &bad, int &nn_pos) {
+                                                    int &examined, int &bad, int &nn_pos, unsigned *tab, bool cached) {
+    // tab: 32 words of LDS, one per cell of the 27 (the cell's table value: first point in the store | count << 24 | flags; 0: empty).
+    // cached: they are this query's, looked up when it entered its voxel (a cell's entry never changes once it is ready, and
+    // every occupied cell of a query's window is in the tile): no lookup, and `examined` comes in as the count kept with them.
     constexpr int U = 4;
     const double sx = s[0], sy = s[1], sz = s[2];
     int ref = 0, cnt = 0;
     int mybad = 0;
     bool glob = false;
     double bd = DBL_MAX;  // lower bound of the distance to any point of this lane's cell
+    const int half_shift = threadIdx.x & 32;
     if (lane < 27) {
         const int cx = (int)((kShift.x >> (2 * lane)) & 3), cy = (int)((kShift.y >> (2 * lane)) & 3), cz = (int)((kShift.z >> (2 * lane)) & 3);
         const WideGaps gaps = wide_gaps(s, v, m.voxel_size);
@@ -842,32 +846,41 @@ __device__ __forceinline__ double group_scan_pruned(const MapView &m, const Tile
         const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
         const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
         bd = (bx + by) + bz;
-        unsigned rkey;
-        if (tile_rel(tile, v[0] + cx - 1, v[1] + cy - 1, v[2] + cz - 1, rkey)) {
-            const int slot = tile_find(tile, rkey);
-            if (slot >= 0) {
-                const unsigned val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (val == kTileOverflow) {
-                    mybad = 2;
-                } else if (!(val & kTileReady)) {
-                    mybad = 1;
-                } else {
-                    ref = tile_ref(val);
-                    cnt = tile_cnt(val);
-                    glob = (val & kTileGlobal) != 0u;
-                }
-            }
+        unsigned val = 0u;
+        if (cached) {
+            val = tab[lane];
         } else {
-            mybad = 2;
+            unsigned rkey;
+            if (tile_rel(tile, v[0] + cx - 1, v[1] + cy - 1, v[2] + cz - 1, rkey)) {
+                const int slot = tile_find(tile, rkey);
+                if (slot >= 0) {
+                    val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (val == kTileOverflow) {
+                        mybad = 2;
+                    } else if (!(val & kTileReady)) {
+                        mybad = 1;
+                    }
+                }
+            } else {
+                mybad = 2;
+            }
+            if (mybad) val = 0u;
+            tab[lane] = val;
         }
+        ref = tile_ref(val);
+        cnt = tile_cnt(val);
+        glob = (val & kTileGlobal) != 0u;
     }
-    const int half_shift = threadIdx.x & 32;
-    bad = (unsigned)(__ballot(mybad == 2) >> half_shift) != 0u ? 2 : ((unsigned)(__ballot(mybad == 1) >> half_shift) != 0u ? 1 : 0);
-    if (bad) cnt = 0;
-    int tot = cnt;
+    bad = 0;
+    if (!cached) {
+        bad = (unsigned)(__ballot(mybad == 2) >> half_shift) != 0u ? 2 : ((unsigned)(__ballot(mybad == 1) >> half_shift) != 0u ? 1 : 0);
+        if (bad) cnt = 0;
+        int tot = cnt;
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
-    examined = tot;
+        for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
+        examined = tot;
+        group_lds_sync();  // (the table is read across lanes below)
+    }
     double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
     int key = 0x7FFFFFFF, pos = -1;
     double limit = limit0;
@@ -881,8 +894,8 @@ __device__ __forceinline__ double group_scan_pruned(const MapView &m, const Tile
         for (int u = 0; u < U; ++u) {
             const int j = kl ? (__ffs(kl) - 1) : -1;
             kl &= kl - 1;  // (0 & -1) == 0
-            const int rj = __shfl(ref, j & 31, 32);
-            const int cj = __shfl(cnt, j & 31, 32);
+            const unsigned ej = tab[j & 31];  // (one LDS read; two shuffles would be two trips through the same unit)
+            const int rj = tile_ref(ej), cj = tile_cnt(ej);
             kj[u] = j;
             ld[u] = (j >= 0) && (lane < cj);
             pj[u] = rj + lane;

@@ -310,7 +310,9 @@ struct Options {
     long icp_points_per_group = 1;
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
-    long icp_group_prune = 1;    // group form of the association: skip cells by their box bounds (exact; 0: every point of the 27 cells is read)
+    long icp_group_prune = 0;    // group form of the association: 1 = skip cells by their box bounds (exact).  Measured SLOWER on the bench scene
+                                 // (2455 against 2885 scans/s, profiles/r05_j): at ~20 points per workgroup a search is bound by its fixed
+                                 // instruction stream, not by the ~240 candidates it reads -- off, kept as the record and for dense maps
     long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)

@@ -141,6 +141,15 @@ int main() {
         CHECK(pose_diff(Tg, To) < 1e-7);
         CHECK(reg.last_iterations_ == st.iterations);
         CHECK(std::fabs(Tg[3] - 0.3) < 0.05 && std::fabs(Tg[7] + 0.2) < 0.05);
+        // the reference's Registration is a copyable struct (core/Registration.hpp:33-45): a copy registers like the original
+        kiss_icp::Registration reg2 = reg;
+        kiss_icp::Registration reg3(1, 1.0, 0);
+        reg3 = reg;
+        double T2[16], T3[16];
+        rowmajor(reg2.AlignPointsToMap(frame, map, guess, 3.0, 1.0), T2);
+        rowmajor(reg3.AlignPointsToMap(frame, map, guess, 3.0, 1.0), T3);
+        CHECK(pose_diff(T2, Tg) == 0.0 && pose_diff(T3, Tg) == 0.0);
+        CHECK(reg2.max_num_iterations_ == 500 && reg3.convergence_criterion_ == 1e-4);
         // empty map -> the guess comes back (Registration.cpp:143)
         kiss_icp::VoxelHashMap empty(1.0, 100.0, 20);
         double Te[16];

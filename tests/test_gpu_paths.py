@@ -350,6 +350,80 @@ def test_first_iteration_window_phase_is_bitwise_neutral(gpu, O, blocks):
     assert dt < TIGHT and dr < TIGHT
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [0, 1, 16])
+def test_pruned_group_search_is_bitwise_neutral(gpu, O, blocks):
+    """icp_group_prune: the 32-lane-group form skips the cells of the 27 whose box lies strictly farther than a candidate in
+    hand (first the last iteration's neighbour) and spreads the points of the cells it reads over the lanes.  A skipped cell
+    loses every comparison of VoxelHashMap.cpp:58-63 anyway: pose bit for bit, iteration count, correspondences and the
+    examined count (all 27 cells, as the reference counts them) equal those of reading every point -- with the default
+    partition, one workgroup over all points (chunks, a full tile, cells read from the map) and 16 -- and the oracle's."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(73)
+    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
+    world = random_cloud(rng, 30000, extent=25.0, z_extent=3.0)
+    g.add_points(world)
+    o.add_points(world)
+    src = world[rng.choice(len(world), 2500, replace=False)] + rng.normal(0, 0.03, (2500, 3))
+    guess = make_pose((0.2, -0.1, 0.02), (0.002, -0.001, 0.01))
+    out = {}
+    try:
+        _cabi.set_option("icp_wide", 0)  # (one workgroup over 2500 points would otherwise take the thread-per-query form)
+        _cabi.set_option("icp_blocks", blocks)
+        for prune in (1, 0):
+            _cabi.set_option("icp_group_prune", prune)
+            r = Registration(500, 1e-4)
+            out[prune] = (r.align_points_to_map(src, g, guess, 3.0, 1.0), dict(r.last_stats))
+    finally:
+        _cabi.set_option("icp_group_prune", 0)
+        _cabi.set_option("icp_blocks", 0)
+        _cabi.set_option("icp_wide", -1)
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
+        assert out[0][1][k] == out[1][1][k], k
+    ro = O.Registration(500, 1e-4)
+    To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
+    dt, dr = pose_error(To, out[1][0])
+    assert dt < TIGHT and dr < TIGHT
+    assert out[1][1]["points_examined"] == ro.last_stats["points_examined"] and out[1][1]["iterations"] == ro.last_stats["iterations"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prune", [0, 1])
+def test_pruned_group_search_keeps_the_references_tie_order(gpu, O, prune):
+    """exact ties across cells (a lattice map, queries exactly between lattice points): the pruned search must keep the
+    candidate the reference's nested strict-'<' loops keep -- a cell whose bound EQUALS the distance in hand is still read"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
+    ax = np.arange(-6.0, 6.0, 0.25)
+    lattice = np.stack(np.meshgrid(ax, ax, np.arange(-1.0, 1.0, 0.25), indexing="ij"), axis=-1).reshape(-1, 3)
+    lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]
+    g.add_points(lattice)
+    o.add_points(lattice)
+    qa = np.arange(-4.0, 4.0, 0.5)
+    try:
+        _cabi.set_option("icp_group_prune", prune)
+        for offset in ((0.125, 0.125, 0.125), (0.0, 0.125, 0.125), (0.9375, 0.125, 0.0625), (0.5, 0.5, 0.0)):
+            src = np.stack(np.meshgrid(qa, qa, np.array([-0.5, 0.0]), indexing="ij"), axis=-1).reshape(-1, 3) + np.array(offset)
+            for guess in (np.eye(4), make_pose((0.5, -0.25, 0.0))):
+                for iters in (1, 2, 5):
+                    rg, ro = Registration(iters, 1e-12), O.Registration(iters, 1e-12)
+                    Tg = rg.align_points_to_map(src, g, guess, 3.0, 1.0)
+                    To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
+                    dt, dr = pose_error(To, Tg)
+                    assert dt < 1e-10 and dr < 1e-10, (offset, iters, dt, dr)
+                    assert rg.last_stats["n_corr_last"] == ro.last_stats["n_corr_last"]
+                    assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
+    finally:
+        _cabi.set_option("icp_group_prune", 0)
+
+
 def _wide_scene(kind, rng):
     """(map points, source points, voxel size, guess) for the two regimes of the association"""
     if kind == "full_voxels":  # 1 m voxels, up to 20 points each: long neighbourhoods, few queries per workgroup
