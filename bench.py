@@ -107,6 +107,18 @@ def visible_devices():
         return 0
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup's quota (a GPU box's container: 16 of 256)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, -(-int(quota) // int(period)))
+    except Exception:  # noqa: BLE001 -- no cgroup v2 file: the affinity count stands
+        pass
+    return max(1, n)
+
+
 def pmc_traffic(name):
     """HBM bytes per k_icp launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
     passes over this same command, corrected as calibrated on a known-size copy; scripts/pmc_to_json.py
@@ -220,10 +232,12 @@ def main_in_process(args, devices, exchange):
 
     drive(0, W)  # untimed warm-up
     sync_devices()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     drive(W, W + K)
     sync_devices()
     elapsed = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
     poses = [batch.poses(r) for r in range(S)]
     assert all(len(p) == K for p in poses), [len(p) for p in poses]
     out = {
@@ -239,6 +253,9 @@ def main_in_process(args, devices, exchange):
             "frames_driven": W + K,
         },
         "rccl_ranks": S if exchange == "rccl" else 0,
+        # what the HOST spent on the timed frames (all threads of this process: callers, staging helpers, batch workers, the
+        # runtime's own) against the CPUs it may use -- whether N streams fit a box's cores is decided here, not on the GPUs
+        "host_cpu": {"process_cpu_s": cpu_s, "cpu_s_per_frame": cpu_s / (S * K), "cpu_busy": cpu_s / elapsed, "usable_cpus": usable_cpus()},
         "pose_gather_s": batch.gather_seconds(),
         "scan_generation_s": t_gen,
     }
@@ -300,11 +317,13 @@ def main():
     # ---- timed region: exactly K frames, barrier + synchronize on both sides -------------------
     multistream.barrier(dist)
     torch.cuda.synchronize()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     local_poses, all_poses = multistream.run_batch_host(pipe, host[W:W + K], dist, comm_device)
     torch.cuda.synchronize()
     multistream.barrier(dist)
     elapsed = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
     elapsed = multistream.max_over_ranks(elapsed, dist, comm_device)
     icp = pipe.icp_timing()
     stats = pipe.last_stats()
@@ -353,6 +372,9 @@ def main():
                      "launcher": "torch.distributed.run, one rank per GPU" if "WORLD_SIZE" in os.environ else "single process"},
         # what the host side of the K timed calls did (kicp_pipeline_host_stats): waits must be zero in steady state
         "host_side": host_side,
+        # this rank's host cost of the timed frames (all threads of the process) against the CPUs it may use: N ranks on a box
+        # share them, so cpu_busy x N against usable_cpus says whether the hosts or the GPUs bound an N-GPU run
+        "host_cpu": {"process_cpu_s": cpu_s, "cpu_s_per_frame": cpu_s / K, "cpu_busy": cpu_s / elapsed, "usable_cpus": usable_cpus()},
         "scan_generation_s": t_gen,
     }
     cyc, tk = pipe.icp_clock()

@@ -413,6 +413,10 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "staging_f32"     1 = narrow float64 host scans to float32 for the upload when lossless (default 1)
  *   "staging_zero_copy"  1 (default) = no upload call: the two kernels that read the raw scan fetch it over PCIe from
  *                     the pinned, device-mapped staging slot themselves; 0 = hipMemcpyAsync into HBM first
+ *   "stage_in"        1 (default): a frame that DESKEWS has its scan and timestamps copied from the staging slot into HBM by a kernel
+ *                     queued in front of the wait for the previous pose -- with deskewing the front stages sit on the frame's
+ *                     serial chain, and reading the scan over PCIe there cost 30 us per frame; 0 = they read the slot themselves.
+ *                     Same points, same poses.
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
  *   "downsample_order"  order in which VoxelDownsample emits its survivors: 1 (default) = the reference's, i.e. the bucket
@@ -422,14 +426,6 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_bulk_fill"   1 (default): in a registration's first iteration the workgroup establishes all its queries' windows
  *                     together (distinct cells, one wave of map lookups, one of point fetches); 0: query by query, as in later
  *                     iterations.  Results are bitwise the same either way.
- *   "icp_group_prune"  1: the 32-lane-group form of the association skips cells of the 27 whose box lies strictly farther
- *                     than a candidate already in hand (first the last iteration's neighbour, then the best of every trip) and
- *                     spreads the points of the cells it does read over the lanes; 0 (default): every point of the 27 cells is
- *                     read (scan lists / a lane per cell).  Exact: a skipped cell loses every comparison of
- *                     VoxelHashMap.cpp:58-63 anyway; pose, iteration count and examined count are bitwise the same
- *                     (tests/test_gpu_paths.py).  Off because it measured slower on the bench scene (2455 against 2885 scans/s,
- *                     profiles/r05_j_*): with ~20 points per workgroup a search costs its fixed instruction stream, not its
- *                     ~240 candidates.
  *   "icp_schur_solve"  1 (default): the 6 x 6 normal equations of a Gauss-Newton step, whose top-left block is (sum w) I, are solved
  *                     through their 3 x 3 Schur complement when that is well conditioned (pivots above 1e-9 of the diagonal);
  *                     0: always by the pivoted 6 x 6 LDLT of Eigen that the reference calls (Registration.cpp:156).  The two

@@ -316,7 +316,8 @@ static int err_bits_to_status(int bits) {
 constexpr int kIcpMaxLanes = 8;
 struct IcpDeviceGate {
     std::mutex mu;
-    int lanes = 1;  // the largest share count a handle of this device was created with
+    int lanes = 1;  // the largest share count among the LIVE handles of this device (recomputed when one is created or destroyed)
+    int share_live[kIcpMaxLanes + 1] = {0};  // live handles by share
     struct Lane {
         hipStream_t stream = nullptr;  // stream of the most recent k_icp launch through this lane
         unsigned long stamp = 0;       // (least recently used lane is taken over first)
@@ -353,16 +354,47 @@ static int icp_max_blocks(int device_id, int lds_bytes) {
     g.max_blocks[free_slot].blocks = (int)(b < kIcpMaxBlocks ? b : kIcpMaxBlocks);
     return g.max_blocks[free_slot].blocks;
 }
-// a handle that shares its device with share - 1 others is being created
-static void icp_gate_declare_share(int device_id, int share) {
+// a handle that shares its device with share - 1 others is being created (+1) / destroyed (-1)
+static void icp_gate_count_share(int device_id, int share, int delta) {
     IcpDeviceGate &g = icp_gate(device_id);
     std::lock_guard<std::mutex> lk(g.mu);
-    if (share > g.lanes) g.lanes = share < kIcpMaxLanes ? share : kIcpMaxLanes;
+    share = share < 1 ? 1 : (share > kIcpMaxLanes ? kIcpMaxLanes : share);
+    g.share_live[share] += delta;
+    if (g.share_live[share] < 0) g.share_live[share] = 0;
+    g.lanes = 1;
+    for (int k = kIcpMaxLanes; k >= 1; --k)
+        if (g.share_live[k] > 0) {
+            g.lanes = k;
+            break;
+        }
 }
-// launch k_icp on `s` through the device's gate
-static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+// launch k_icp on `s` through the device's gate.  share: the part of the co-resident grid the launch was sized for (1 / share
+// of it).  A launch with the lanes' own share takes ONE lane; a launch that takes more of the device than a lane stands for
+// (a whole-grid registration while pipelines with shares exist: kicp_align_points_to_map, a pipeline created before them)
+// takes ALL lanes -- it is ordered behind whatever any lane last launched and everything is ordered behind it: two grids
+// that together exceed what the device holds are never in flight at once (round 4's review: the gate did not look at the
+// launch's own share, and the lane count was never lowered).
+static int icp_launch_ordered(int device_id, IcpParams &P, int grid, bool profile, hipStream_t s, int share, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     IcpDeviceGate &g = icp_gate(device_id);
     std::lock_guard<std::mutex> lk(g.mu);
+    if (share < g.lanes) {  // more than a lane's worth of the device
+        for (int i = 0; i < kIcpMaxLanes; ++i) {
+            if (!g.lane[i].stream || g.lane[i].stream == s) continue;
+            bool seen = false;  // (several lanes may hold the same stream: one wait)
+            for (int k = 0; k < i; ++k) seen = seen || g.lane[k].stream == g.lane[i].stream;
+            if (seen) continue;
+            if (!g.ev) KICP_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+            KICP_HIP(hipEventRecord(g.ev, g.lane[i].stream));
+            KICP_HIP(hipStreamWaitEvent(s, g.ev, 0));
+        }
+        launch_icp(P, grid, profile, P.use_wide != 0, s, start, stop);
+        ++g.clock;
+        for (int i = 0; i < kIcpMaxLanes; ++i) {
+            g.lane[i].stream = i < g.lanes ? s : nullptr;
+            g.lane[i].stamp = g.clock;
+        }
+        return KICP_OK;
+    }
     int mine = -1, pick = 0;
     for (int i = 0; i < g.lanes; ++i) {
         if (g.lane[i].stream == s) mine = i;
@@ -419,7 +451,6 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
     P.use_wide = options().icp_wide >= 0 ? (options().icp_wide != 0) : (per_wg > kIcpListRunMax);
     P.wide_prune = (int)options().icp_wide_prune;
     P.schur_solve = (int)options().icp_schur_solve;
-    P.group_prune = (int)options().icp_group_prune;
     P.wide_prefill = (int)options().icp_wide_prefill;
     P.wide_per_round = (int)options().icp_wide_per_round;
     P.wide_flat = (int)options().icp_wide_flat;
@@ -1160,7 +1191,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         P.granules = r->granules.as<unsigned long long>();
         P.spin_limit = kSpinLimit;
         KICP_HIP(hipEventRecord(r->ev0, r->stream));
-        KICP_TRY(icp_launch_ordered(r->device, P, G, options().icp_profile != 0, r->stream));
+        KICP_TRY(icp_launch_ordered(r->device, P, G, options().icp_profile != 0, r->stream, 1));
         KICP_HIP(hipGetLastError());
         KICP_HIP(hipEventRecord(r->ev1, r->stream));
         // (the result is fetched only once the launch is known to have ended: `h` is a local, and a wait that gives up must
@@ -1416,6 +1447,7 @@ constexpr int kRecWords = (int)((sizeof(int) * C_COUNT + sizeof(PipeState)) / si
 // what was enqueued last (enough to run the frame again after a registration that gave up)
 struct FrameInput {
     bool valid = false;
+    bool host_mapped = false;  // d_xyz / d_ts are device addresses of pinned HOST memory (the zero-copy staging slot)
     const void *d_xyz = nullptr;
     int xyz_f32 = 0;
     size_t n = 0;
@@ -1480,6 +1512,7 @@ struct kicp_pipeline {
     // registration replay (timeout): co-residency cap for the ICP grid, the last frame's inputs
     int icp_cap = 0;
     int icp_share = 1;  // streams this device's persistent grid is divided among (option "icp_device_streams" when the pipeline was created)
+    bool share_counted = false;  // ... and the device's gate knows about it
     int inject_timeouts = 0;  // test hook ("icp_inject_timeout" option, read at create)
     int inject_skip = 0;      // ... after this many untouched registrations ("icp_inject_timeout_skip")
     FrameInput last_in;
@@ -1646,7 +1679,7 @@ static int pipe_rehash_in_stream(kicp_pipeline *p) {
 
 // queue one frame whose scan is (or will be, in prep_stream order) in HBM at d_xyz: float64 xyz
 // triples, or float32 ones when xyz_f32 is set
-static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t n, const double *d_ts, size_t n_ts) {
+static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t n, const double *d_ts, size_t n_ts, bool host_mapped = false) {
     const kicp_config &c = p->cfg;
     const bool do_deskew = c.deskew && n_ts > 0 && d_ts;  // Preprocessing.cpp:59
     if (do_deskew && n_ts < n) {
@@ -1705,14 +1738,25 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     // are done anyway: the host synchronised on them).  The pose of frame k-1 is only needed to
     // deskew; without timestamps the front stages run under frame k-1's registration.
     if (p->in_flight >= 2) KICP_HIP(hipStreamWaitEvent(sp, pipe_frame_done_event(p, p->in_flight - 2), 0));
+    // What depends on no pose comes BEFORE the wait for the previous frame's: with deskewing the rest of this stream is on the
+    // frame's serial chain.  A scan that lies in the host's staging slot is brought into HBM here (raw / ts of this parity:
+    // last read by frame k-2's front stages), and the timestamps' minimum and maximum are taken.
+    const void *xyz_in = d_xyz;
+    const double *ts_in = d_ts;
+    if (do_deskew && host_mapped && options().stage_in != 0 && n) {
+        launch_stage_in(d_xyz, p->raw[par].p, n * 3 * (xyz_f32 ? sizeof(float) : sizeof(double)), sp);
+        launch_stage_in(d_ts, p->ts[par].p, n_ts * sizeof(double), sp);
+        xyz_in = p->raw[par].p;
+        ts_in = p->ts[par].as<double>();
+    }
+    if (do_deskew) launch_ts_minmax(ts_in, (int)n_ts, prep, sp);
     if (do_deskew && p->icp_done_event) KICP_HIP(hipStreamWaitEvent(sp, p->icp_done_event, 0));
     // --- Preprocess (KissICP.cpp:38) + first VoxelDownsample claim -----------------------------
-    if (do_deskew) launch_ts_minmax(d_ts, (int)n_ts, prep, sp);
     PreParams P;
     memset(&P, 0, sizeof P);
-    P.xyz = d_xyz;
+    P.xyz = xyz_in;
     P.xyz_f32 = xyz_f32;
-    P.ts = do_deskew ? d_ts : nullptr;
+    P.ts = do_deskew ? ts_in : nullptr;
     P.n = n_i;
     P.deskew = do_deskew ? 1 : 0;
     P.use_state_motion = 1;
@@ -1851,12 +1895,12 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     const bool want_done = options().icp_timing != 0 || c.deskew;
     p->icp_done_event = nullptr;
     if (p->ext_events) {
-        KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s, options().icp_timing != 0 ? p->ev[slot][0] : nullptr,
+        KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s, p->icp_share, options().icp_timing != 0 ? p->ev[slot][0] : nullptr,
                                     want_done ? p->ev[slot][1] : nullptr));
         if (want_done) p->icp_done_event = p->ev[slot][1];
     } else {
         KICP_HIP(hipEventRecord(p->ev[slot][0], s));
-        KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s));
+        KICP_TRY(icp_launch_ordered(p->device, I, G, options().icp_profile != 0, s, p->icp_share));
         if (want_done) {
             p->icp_done_event = p->ev[slot][1];
             KICP_HIP(hipEventRecord(p->icp_done_event, s));
@@ -1882,6 +1926,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     p->frames_enqueued++;
     p->hs.frames++;
     p->last_in.valid = true;
+    p->last_in.host_mapped = host_mapped;
     p->last_in.d_xyz = d_xyz;
     p->last_in.xyz_f32 = xyz_f32;
     p->last_in.n = n;
@@ -1997,7 +2042,7 @@ static int pipe_stage_and_enqueue(kicp_pipeline *p, const double *xyz64, const f
         KICP_HIP(hipHostGetDevicePointer(&d_h, h, 0));
         const double *d_hts = reinterpret_cast<const double *>(static_cast<char *>(d_h) + p->stage_points * 3 * sizeof(double));
         t_enq = now_ms();
-        st = pipe_enqueue(p, d_h, as_f32 ? 1 : 0, n, n_ts ? d_hts : nullptr, n_ts);
+        st = pipe_enqueue(p, d_h, as_f32 ? 1 : 0, n, n_ts ? d_hts : nullptr, n_ts, true);
         KICP_HIP(hipEventRecord(p->ev_h2d[slot], sp));  // behind the front stages of this frame: the slot is free again
     } else {
         // upload on the stream that consumes it.  raw[par] / ts[par] were last read by the front stages of
@@ -2041,6 +2086,15 @@ int kicp_config_default(kicp_config *c) {
 }
 
 int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **out) {
+    return kicp::pipeline_create_shared(cfg, device_id, 0, out);
+}
+
+}  // extern "C"
+
+// share > 0: the pipeline's part of its device's persistent grid (1 / share), whatever option "icp_device_streams" says -- the
+// batch entry knows how many of its streams sit on each device and says so per pipeline (round 4's review: it used to
+// overwrite the process-wide option around the creation of its pipelines)
+int kicp::pipeline_create_shared(const kicp_config *cfg, int device_id, int share, kicp_pipeline **out) {
     if (!cfg || !out) return KICP_ERR_INVALID_ARG;
     *out = nullptr;
     if (!(cfg->voxel_size > 0.0) || cfg->max_points_per_voxel <= 0 || cfg->max_num_iterations < 0) {
@@ -2056,8 +2110,10 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     p->inject_timeouts = (int)options().icp_inject_timeout;
     p->inject_skip = (int)options().icp_inject_timeout_skip;
     p->ds_order = options().downsample_order != 0 ? 1 : 0;
-    p->icp_share = (int)(options().icp_device_streams > 1 ? options().icp_device_streams : 1);
-    icp_gate_declare_share(device_id, p->icp_share);
+    p->icp_share = share > 0 ? share : (int)(options().icp_device_streams > 1 ? options().icp_device_streams : 1);
+    if (p->icp_share > kIcpMaxLanes) p->icp_share = kIcpMaxLanes;
+    icp_gate_count_share(device_id, p->icp_share, +1);
+    p->share_counted = true;
     int s = KICP_OK;
     // The two streams of a pipeline must sit on DIFFERENT hardware queues: the registration is one persistent launch, and a
     // front-stage kernel queued behind it on the same queue waits for it to end.  The runtime hands streams of one priority
@@ -2121,6 +2177,8 @@ int kicp_pipeline_create(const kicp_config *cfg, int device_id, kicp_pipeline **
     return KICP_OK;
 }
 
+extern "C" {
+
 int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (!p) return KICP_OK;
     (void)hipSetDevice(p->device);
@@ -2133,6 +2191,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     if (idle == KICP_OK) idle = wait_device(p->device, "pipeline teardown");  // (hipHostFree below waits for the whole device)
     const bool gone = idle == KICP_OK;  // nothing of this pipeline is in flight any more
     g_live_pipelines.fetch_sub(1, std::memory_order_relaxed);
+    if (p->share_counted) icp_gate_count_share(p->device, p->icp_share, -1);
     delete p->pool;
     p->pool = nullptr;
     if (p->map) {  // (the map lives on the pipeline's stream: the wait above was its wait too)
@@ -2281,7 +2340,7 @@ static int pipe_sync_impl(kicp_pipeline *p) {
             if (queued - good == 1 && p->last_in.valid && attempt < 3 && !(err_bits & ~E_TIMEOUT)) {
                 // exactly the last frame is missing and its scan is still where it was: run it again
                 const FrameInput in = p->last_in;
-                KICP_TRY(pipe_enqueue(p, in.d_xyz, in.xyz_f32, in.n, in.d_ts, in.n_ts));
+                KICP_TRY(pipe_enqueue(p, in.d_xyz, in.xyz_f32, in.n, in.d_ts, in.n_ts, in.host_mapped));
                 continue;
             }
             set_error("registration gave up waiting for its workgroups (%d frame(s) not processed; re-submit them)", queued - good);
@@ -2805,8 +2864,6 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "icp_wide_prefill")) {
         if (value < 0 || value > 8) return KICP_ERR_INVALID_ARG;
         options().icp_wide_prefill = value;
-    } else if (!strcmp(name, "icp_group_prune")) {
-        options().icp_group_prune = value != 0;
     } else if (!strcmp(name, "icp_schur_solve")) {
         options().icp_schur_solve = value != 0;
     } else if (!strcmp(name, "icp_wide_prune")) {
@@ -2832,6 +2889,8 @@ int kicp_set_option(const char *name, long value) {
         options().downsample_order = value;
     } else if (!strcmp(name, "staging_zero_copy")) {
         options().staging_zero_copy = value;
+    } else if (!strcmp(name, "stage_in")) {
+        options().stage_in = value != 0;
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (a weight is a 32-bit granule; the prefix sums are 64-bit)
         options().icp_weight_base = value;

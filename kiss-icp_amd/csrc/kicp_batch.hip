@@ -19,6 +19,7 @@ struct HipPipe {
     kicp_config cfg;
     kicp_pipeline *pipe = nullptr;
     int device = -1;
+    int share = 1;  // streams of this batch on the pipeline's device
     void *d_send = nullptr, *d_recv = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned
     size_t block_bytes = 0;
@@ -39,7 +40,7 @@ struct HipPipe {
         device = dev;
         block_bytes = bytes;
         n_total = total;
-        int rc = note(kicp_pipeline_create(&cfg, dev, &pipe));
+        int rc = note(kicp::pipeline_create_shared(&cfg, dev, share, &pipe));
         if (rc != KICP_OK) return rc;
         if ((rc = hip(hipSetDevice(dev), "hipSetDevice")) != KICP_OK) return rc;
         if ((rc = hip(hipStreamCreateWithFlags(&xchg, hipStreamNonBlocking), "hipStreamCreate")) != KICP_OK) return rc;
@@ -268,20 +269,14 @@ int kicp_batch_create(const kicp_config *cfg, const int *devices, int n_local, i
     const kicp_config c = *cfg;
     // streams that share a GPU share its persistent registration grid: each pipeline is created with 1 / n of it, and
     // the device's gate lets n registrations run side by side (option "icp_device_streams", kicp_api.hip)
-    int share = 1;
-    for (int i = 0; i < n_local; ++i) {
-        int same = 0;
-        for (int j = 0; j < n_local; ++j) same += devices[j] == devices[i];
-        share = same > share ? same : share;
-    }
-    const long share_before = options().icp_device_streams;
-    if (share > share_before) options().icp_device_streams = share < 8 ? share : 8;
-    int rc = b->driver->start(devices, [&](int) {
+    int rc = b->driver->start(devices, [&](int i) {
         auto p = std::make_unique<HipPipe>();
         p->cfg = c;
+        int same = 0;  // per device: a device that carries one stream of this batch gives it its whole grid
+        for (int j = 0; j < n_local; ++j) same += devices[j] == devices[i];
+        p->share = same < 8 ? same : 8;
         return p;
     });
-    options().icp_device_streams = share_before;  // (start() returns when every stream's pipeline exists)
     if (rc != KICP_OK) {
         set_error("%s", b->driver->last_error().c_str());
         delete b;

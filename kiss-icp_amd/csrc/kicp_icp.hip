@@ -55,6 +55,7 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     double range_sum[kIcpSumRows][kIcpSums];  // leader: its members' partials; every workgroup: the leaders' group sums
     double tot[kIcpSums];
     double est[8];  // q[4], t[3], |dx|
+    double far_point[4];  // a point so far away that its squared distance to anything overflows to +inf (tile_scan_list's tail)
     // kept by ONE thread (kIcpBookThread of workgroup 0), off the critical path and out of registers:
     double T_icp[7];  // accumulated update, q[4] t[3]
     double guess[7];
@@ -495,7 +496,8 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     const int quad = P.weight_quad >= 0 ? P.weight_quad : (long_runs ? 0 : 10);
     const int w_base = long_runs ? P.weight_long_base : P.weight_base;
     const int dense_min = long_runs ? 0 : P.dense_min, dense_div = long_runs ? 1 : P.dense_div;
-    long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 1] exclusive prefix of the slice sums (608 doubles of room)
+    long long *x_pref = reinterpret_cast<long long *>(sh.range_sum);  // [G + 2]: exclusive prefix of the slice sums, then the delta
+    static_assert((kIcpMaxBlocks + 2) * sizeof(long long) <= sizeof(IcpShared::range_sum), "x_pref lives in range_sum");
     long long my_sum = 0;
     const int lane = tid & (kIcpGroup - 1);
     // Long runs (hundreds of points per slice): a THREAD per point, its 27 lookups nine at a time (the registers are there: the kernel's allocation is the iterations') -- served 16 points at a
@@ -770,12 +772,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         n_local = max(0, min(n_run, n - q0));
     }
     const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, WIDE ? kWideChunk : kIcpMaxMeta) : 0;
-    const bool use_lists = !WIDE && !P.group_prune && n_meta > 0 && n_local <= kIcpListRunMax;  // (the pruned search keeps no lists: the region is all points)
-    // the pruned search's cell tables (128 bytes each: the table values of a query's 27 cells), at the very end of LDS: one
-    // per group as scratch, and -- for short runs -- one per query, kept while the query stays in its voxel
-    const bool query_tabs = !WIDE && P.group_prune && n_meta > 0 && n_local <= kIcpListRunMax;
-    const int cell_tabs = (!WIDE && P.group_prune && n_meta > 0) ? kIcpGroupsPerBlock + (query_tabs ? n_meta : 0) : 0;
-    unsigned *cell_mem = reinterpret_cast<unsigned *>(smem + P.lds_bytes - cell_tabs * 128);
+    const bool use_lists = !WIDE && n_meta > 0 && n_local <= kIcpListRunMax;
     // LDS behind the fixed part: only as many point slots of a chunk as the run can fill (a run of 16 points leaves
     // 9 KiB of the 128 to the tile), then the query records, the table, and the region of points and lists
     // (WIDE: all of sh.pts stays -- the slow-path queue and, with sh.terms, phase C's rows; 20-byte query records)
@@ -796,7 +793,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         tile.vals = tile.keys + slots;
         q += (size_t)2 * slots * sizeof(unsigned);
         tile.points = reinterpret_cast<double *>(q);
-        const long room = (long)P.lds_bytes - (long)(q - smem) - (long)cell_tabs * 128;
+        const long room = (long)P.lds_bytes - (long)(q - smem);
         tile.region_bytes = n_meta > 0 && room > 0 ? (unsigned)min(room, (long)0xFFFF * 24) & ~15u : 0u;
         tile.cap_points = (int)(tile.region_bytes / 24u);
         tile.lists = use_lists ? reinterpret_cast<unsigned short *>(q) : nullptr;
@@ -806,6 +803,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         tile.stored = &sh.tile_stored;
         tile.entries = &sh.tile_entries;
         tile.ox = tile.oy = tile.oz = 0;  // set once the first point's voxel is known
+        tile.far = sh.far_point;
     }
     double(*terms)[kIcpTerms] = sh.terms;
     unsigned t_assoc = 0, t_publish = 0, t_gather = 0, t_solve = 0;
@@ -815,6 +813,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 
     if (tid == 0) {
         sh.fail = 0;
+        sh.far_point[0] = sh.far_point[1] = sh.far_point[2] = 1e200;
         sh.tile_points = 0;
         sh.tile_stored = 0;
         sh.tile_entries = 0;
@@ -986,8 +985,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 // The slow paths: the queries that need one file themselves in a queue (sh.pts), the 32-lane groups serve it
                 // with the routines of the first form, the owners read the verdicts back.  mode 1: establish the window
                 // (tile_fill); mode 2: search the map directly (closest_neighbor_any).
+                bool tie_redo = false;  // this iteration's search may have met a tie in NORM (kicp_search.hpp): the map-direct search settles it
                 auto serve = [&](int mode, int *counter) -> int {
-                    bool pending = active && wq.flag == mode;
+                    bool pending = active && (wq.flag == mode || (mode == 2 && tie_redo));
                     int served = 0;
                     // (every round serves up to kWideQueue of the at most kWideChunk pending queries: the trip count is bounded)
                     for (int round = 0; round < kWideChunk / kWideQueue + 2; ++round) {
@@ -1407,6 +1407,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                             wq.nn[1] = wb.by;
                             wq.nn[2] = wb.bz;
                         }
+                        // The reference compares NORMS (kicp_search.hpp): if anything else can be as close as the neighbour to
+                        // within a few units in the last place -- Lr bounds every other point from below, shaved by 2^-30 -- the
+                        // squared distances may have picked another candidate than the rounded roots would: the map-direct
+                        // search, which settles such ties the reference's way, answers this query in this iteration.
+                        if (wq.have_nn && job.Lr <= sqrt(job.d2) * (1.0 + 0x1p-28)) {
+                            tie_redo = true;
+                            sh.cell_count = 1;
+                        }
                     }
                 }
                 if (compact || n_full > 0) __syncthreads();  // (sh.cell_count; the records' memory is the exchange's)
@@ -1574,54 +1582,21 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 double d2 = DBL_MAX;
                 int E = 0;
                 bool listed = false;
-                if (flag == 0 && P.group_prune) {
-                    // cells skipped by their box bounds (group_scan_pruned, kicp_icp_wide.hpp).  First limit: the last
-                    // neighbour's distance, as the scan itself would compute it -- it is a point of these 27 cells as long as
-                    // the query is in the voxel it was found from (meta: lv = that voxel, list_base = its position in the
-                    // store, list_state 2) --, else the correspondence threshold.
-                    double limit0 = (max_dist * max_dist) * (1.0 + 0x1p-40);  // sqrt(d) < max_dist (Registration.cpp:72) implies d below this
-                    const bool same = meta->list_state == 2 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz;
-                    if (same && meta->list_base >= 0) {
-                        const double *q = tile.points + 3 * meta->list_base;
-                        const double ex = q[0] - s[0], ey = q[1] - s[1], ez = q[2] - s[2];
-                        const double dp = (ex * ex + ey * ey) + ez * ez;
-                        limit0 = dp < limit0 ? dp : limit0;
-                    }
-                    const int vv[3] = {vx, vy, vz};
-                    int bad, npos;
-                    const bool cached = same && query_tabs;  // the cells' entries (and the examined count) are those of the last search
-                    unsigned *tab = cell_mem + 32 * (query_tabs ? kIcpGroupsPerBlock + base + t : grp);
-                    E = cached ? (int)meta->list_n : 0;
-                    d2 = group_scan_pruned(m, tile, s, vv, limit0, lane, nn, E, bad, npos, tab, cached);
-                    listed = true;
-                    path = 2;
-                    if (bad) {
-                        if (bad == 2 && lane == 0) meta->valid = -1;
-                        flag = 2;
-                        path = 3;
-                    } else if (lane == 0) {
-                        meta->lv[0] = vx;
-                        meta->lv[1] = vy;
-                        meta->lv[2] = vz;
-                        meta->list_base = npos;
-                        meta->list_n = (unsigned short)E;
-                        meta->list_state = 2;
-                    }
-                }
+                bool tie = false;  // the fast search's answer may not be the reference's: a tie in NORM (kicp_search.hpp) -- settled below
                 if (flag == 0 && !listed && use_lists && meta->list_state >= 0) {
                     // the scan list belongs to the voxel the query was in when it was built
                     if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz)
                         tile_list_build(tile, vx, vy, vz, lane, meta);
                     if (meta->list_state == 1) {
                         E = meta->list_n;
-                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn);
+                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, &tie);
                         listed = true;
                         path = 1;
                     }
                 }
                 if (flag == 0 && !listed) {
                     int bad;
-                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad);
+                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, &tie);
                     if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is
                                 // being fetched by another group this very moment -> HBM this once
                         if (bad == 2 && lane == 0) meta->valid = -1;
@@ -1630,10 +1605,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     }
                 }
                 if (flag != 0) {
-                    const Probe pr = probe27(m, s[0], s[1], s[2], lane, range_err);
-                    E = pr.E;
-                    d2 = (m.max_points > 32) ? scan_hits_wide(m, pr, s[0], s[1], s[2], lane, nn)
-                                             : scan_hits<false>(m, pr, s[0], s[1], s[2], lane, nn);
+                    d2 = closest_neighbor_any(m, s[0], s[1], s[2], lane, nn, E, range_err);  // (settles ties in norm itself)
+                } else if (__builtin_expect(tie, 0)) {
+                    int e2;  // (the tile's count stands: the same 27 cells)
+                    d2 = closest_neighbor_exact(m, s[0], s[1], s[2], lane, nn, e2, range_err);
                 }
                 if (lane == 0) {
                     pt.nn[0] = nn[0];

@@ -143,7 +143,8 @@ __device__ __forceinline__ WideGaps wide_gaps(const double s[3], const int v[3],
     }
     return g;
 }
-// which of the 27 cells can still matter: bound <= limit (sums of three of the nine squared gaps, picked at compile time)
+// which of the 27 cells can still matter: bound <= limit (sums of three of the nine squared gaps, picked at compile time).
+// The reference compares norms (kicp_search.hpp): a cell is given up only when its bound lies beyond kNormTie of the limit.
 __device__ __forceinline__ unsigned wide_keep_mask(const WideGaps &gaps, double limit) {
     unsigned keep = 0u;
 #pragma unroll
@@ -152,7 +153,7 @@ __device__ __forceinline__ unsigned wide_keep_mask(const WideGaps &gaps, double 
         const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
         const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
         const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
-        if (!((bx + by) + bz > limit)) keep |= 1u << j;
+        if (!((bx + by) + bz > limit * kNormTie)) keep |= 1u << j;  // (kNormTie: a cell just beyond the limit may still hold a point of the same NORM)
     }
     return keep;
 }
@@ -694,7 +695,7 @@ __device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &
     // beyond the correspondence threshold, or farther than the last neighbour, which is still there)
     double best = DBL_MAX, sec = DBL_MAX;
     int bk = 0;
-    bool read = !glob && cnt > 0 && !(bd > limit0);
+    bool read = !glob && cnt > 0 && !(bd > limit0 * kNormTie);
     {
         const double *P = tile.points + 3 * (read ? ref : 0);
         const int c = read ? cnt : 0;
@@ -740,7 +741,7 @@ __device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &
         group_fmin_step<4>(g);
         limit = g < limit ? g : limit;
     }
-    unsigned gl = (unsigned)(__ballot(glob && cnt > 0 && !(bd > limit)) >> half_shift);
+    unsigned gl = (unsigned)(__ballot(glob && cnt > 0 && !(bd > limit * kNormTie)) >> half_shift);
     while (__ballot(gl != 0) != 0ull) {  // wave-uniform trip count
         double2 xy[kChunk];
         double zz[kChunk];
@@ -786,7 +787,7 @@ __device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &
             group_fmin_step<3>(g);
             group_fmin_step<4>(g);
             limit = g < limit ? g : limit;
-            gl &= (unsigned)(__ballot(!(bd > limit)) >> half_shift);
+            gl &= (unsigned)(__ballot(!(bd > limit * kNormTie)) >> half_shift);
         }
     }
     if (best == DBL_MAX) key = 0x7FFFFFFF;
@@ -808,192 +809,6 @@ __device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &
     group_fmin_step<3>(g2);
     group_fmin_step<4>(g2);
     second = g2;
-    return best;
-}
-
-// ------------------------------------------------------------------------------------------
-// The group form's search with cells skipped by their box bounds (option "icp_group_prune"): what wide_group_scan does
-// for the thread-per-query form, for the 32-lane groups of the first form -- and with the points of the cells that ARE
-// read spread over the lanes: lane i takes point i of a cell, four cells per trip, instead of lane j walking cell j's up
-// to 20 points one after the other.  The reference examines every point of the 27 cells (VoxelHashMap.cpp:46-70); its
-// answer is the first minimum in (shift, index) order.  A point stored in cell c cannot be closer than the cell's box
-// bound (wide_gaps: exact under rounding, tests/test_wide_bounds.py), so a cell whose bound is STRICTLY above a distance
-// that some candidate is known to reach can neither hold the minimum nor tie with it: skipping it changes nothing.  The
-// first limit is the distance of the last iteration's neighbour (it is a map point of these 27 cells as long as the
-// query has not left its voxel) or the correspondence threshold; after every trip the cells left are held against the
-// best in hand.  With the last neighbour as limit a query reads its own cell and a face neighbour or two: ~40 points
-// instead of the 300 - 500 of a full neighbourhood next to the sensor.
-// Returns the squared distance (DBL_MAX: nothing within the limit), the neighbour, the examined count the reference
-// would report (all 27 cells: from the table, no point is read for it), the winner's position in the LDS store (-1: a
-// cell read from the map, or none) for the next iteration's limit; bad as tile_scan.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double group_scan_pruned(const MapView &m, const Tile &tile, const double s[3], const int v[3], double limit0, int lane, double nn[3],
-                                                    int &examined, int &bad, int &nn_pos, unsigned *tab, bool cached) {
-    // tab: 32 words of LDS, one per cell of the 27 (the cell's table value: first point in the store | count << 24 | flags; 0: empty).
-    // cached: they are this query's, looked up when it entered its voxel (a cell's entry never changes once it is ready, and
-    // every occupied cell of a query's window is in the tile): no lookup, and `examined` comes in as the count kept with them.
-    constexpr int U = 4;
-    const double sx = s[0], sy = s[1], sz = s[2];
-    int ref = 0, cnt = 0;
-    int mybad = 0;
-    bool glob = false;
-    double bd = DBL_MAX;  // lower bound of the distance to any point of this lane's cell
-    const int half_shift = threadIdx.x & 32;
-    if (lane < 27) {
-        const int cx = (int)((kShift.x >> (2 * lane)) & 3), cy = (int)((kShift.y >> (2 * lane)) & 3), cz = (int)((kShift.z >> (2 * lane)) & 3);
-        const WideGaps gaps = wide_gaps(s, v, m.voxel_size);
-        const double bx = cx == 0 ? gaps.m2[0] : (cx == 2 ? gaps.p2[0] : 0.0);
-        const double by = cy == 0 ? gaps.m2[1] : (cy == 2 ? gaps.p2[1] : 0.0);
-        const double bz = cz == 0 ? gaps.m2[2] : (cz == 2 ? gaps.p2[2] : 0.0);
-        bd = (bx + by) + bz;
-        unsigned val = 0u;
-        if (cached) {
-            val = tab[lane];
-        } else {
-            unsigned rkey;
-            if (tile_rel(tile, v[0] + cx - 1, v[1] + cy - 1, v[2] + cz - 1, rkey)) {
-                const int slot = tile_find(tile, rkey);
-                if (slot >= 0) {
-                    val = __hip_atomic_load(&tile.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (val == kTileOverflow) {
-                        mybad = 2;
-                    } else if (!(val & kTileReady)) {
-                        mybad = 1;
-                    }
-                }
-            } else {
-                mybad = 2;
-            }
-            if (mybad) val = 0u;
-            tab[lane] = val;
-        }
-        ref = tile_ref(val);
-        cnt = tile_cnt(val);
-        glob = (val & kTileGlobal) != 0u;
-    }
-    bad = 0;
-    if (!cached) {
-        bad = (unsigned)(__ballot(mybad == 2) >> half_shift) != 0u ? 2 : ((unsigned)(__ballot(mybad == 1) >> half_shift) != 0u ? 1 : 0);
-        if (bad) cnt = 0;
-        int tot = cnt;
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 32);
-        examined = tot;
-        group_lds_sync();  // (the table is read across lanes below)
-    }
-    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
-    int key = 0x7FFFFFFF, pos = -1;
-    double limit = limit0;
-    // ---- cells whose points are in the LDS store, in shift order, U per trip: lane i reads point i of each
-    unsigned kl = (unsigned)(__ballot(!glob && cnt > 0 && !(bd > limit)) >> half_shift);
-    while (__ballot(kl != 0) != 0ull) {  // wave-uniform trip count
-        double x[U], y[U], z[U];
-        int kj[U], pj[U];
-        bool ld[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = kl ? (__ffs(kl) - 1) : -1;
-            kl &= kl - 1;  // (0 & -1) == 0
-            const unsigned ej = tab[j & 31];  // (one LDS read; two shuffles would be two trips through the same unit)
-            const int rj = tile_ref(ej), cj = tile_cnt(ej);
-            kj[u] = j;
-            ld[u] = (j >= 0) && (lane < cj);
-            pj[u] = rj + lane;
-            const double *q = tile.points + 3 * (ld[u] ? pj[u] : 0);
-            x[u] = q[0];
-            y[u] = q[1];
-            z[u] = q[2];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
-            const double d = (ex * ex + ey * ey) + ez * ez;
-            const int k = (kj[u] << 5) | lane;  // {shift position of the cell, index inside it}: the reference's order
-            const bool take = ld[u] && (d < best || (d == best && k < key));
-            best = take ? d : best;
-            key = take ? k : key;
-            pos = take ? pj[u] : pos;
-            bx = take ? x[u] : bx;
-            by = take ? y[u] : by;
-            bz = take ? z[u] : bz;
-        }
-        if (__ballot(kl != 0) != 0ull) {  // (more to come: what of it can still matter)
-            double g = best;
-            group_fmin_step<0>(g);
-            group_fmin_step<1>(g);
-            group_fmin_step<2>(g);
-            group_fmin_step<3>(g);
-            group_fmin_step<4>(g);
-            limit = g < limit ? g : limit;
-            kl &= (unsigned)(__ballot(!(bd > limit)) >> half_shift);
-        }
-    }
-    // ---- cells whose points are in the map (the store was full): read by the group together, kChunk per trip
-    {
-        double g = best;
-        group_fmin_step<0>(g);
-        group_fmin_step<1>(g);
-        group_fmin_step<2>(g);
-        group_fmin_step<3>(g);
-        group_fmin_step<4>(g);
-        limit = g < limit ? g : limit;
-    }
-    unsigned gl = (unsigned)(__ballot(glob && cnt > 0 && !(bd > limit)) >> half_shift);
-    while (__ballot(gl != 0) != 0ull) {  // wave-uniform trip count
-        double2 xy[kChunk];
-        double zz[kChunk];
-        int kj[kChunk];
-        bool ld[kChunk];
-#pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
-            const int j = gl ? (__ffs(gl) - 1) : -1;
-            gl &= gl - 1;
-            const int bj = __shfl(ref, j & 31, 32);
-            const int cj = __shfl(cnt, j & 31, 32);
-            kj[u] = j;
-            ld[u] = (j >= 0) && (lane < cj);
-            if (ld[u]) {
-                xy[u] = block_xy(m, bj)[lane];
-                zz[u] = block_z(m, bj)[lane];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kChunk; ++u) {
-            if (ld[u]) {
-                const double ex = xy[u].x - sx, ey = xy[u].y - sy, ez = zz[u] - sz;
-                const double d = (ex * ex + ey * ey) + ez * ez;
-                const int k = (kj[u] << 5) | lane;
-                if (d < best || (d == best && k < key)) {
-                    best = d;
-                    key = k;
-                    pos = -1;
-                    bx = xy[u].x;
-                    by = xy[u].y;
-                    bz = zz[u];
-                }
-            }
-        }
-        if (__ballot(gl != 0) != 0ull) {
-            double g = best;
-            group_fmin_step<0>(g);
-            group_fmin_step<1>(g);
-            group_fmin_step<2>(g);
-            group_fmin_step<3>(g);
-            group_fmin_step<4>(g);
-            limit = g < limit ? g : limit;
-            gl &= (unsigned)(__ballot(!(bd > limit)) >> half_shift);
-        }
-    }
-    if (best == DBL_MAX) key = 0x7FFFFFFF;
-    const int mykey = key;
-    group_min_dist_key(best, key);
-    const bool found = key != 0x7FFFFFFF;
-    const unsigned who = (unsigned)(__ballot(found && mykey == key) >> half_shift);
-    const int wl = who ? (__ffs(who) - 1) : 0;
-    nn[0] = __shfl(bx, wl, 32);
-    nn[1] = __shfl(by, wl, 32);
-    nn[2] = __shfl(bz, wl, 32);
-    nn_pos = found ? __shfl(pos, wl, 32) : -1;
     return best;
 }
 

@@ -267,7 +267,6 @@ struct IcpParams {
     int bulk_fill;         // first iteration: establish all windows of a chunk workgroup-wide (tile_fill_bulk) instead of query by query
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int schur_solve;       // solve well-conditioned normal equations through their 3 x 3 Schur complement (kicp_math.hpp: schur3_solve)
-    int group_prune;       // group form: searches skip cells by their box bounds, the last neighbour's distance as first limit (group_scan_pruned)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
@@ -310,9 +309,6 @@ struct Options {
     long icp_points_per_group = 1;
     long icp_use_lds = 1;        // stage candidate voxels in LDS and reuse them across iterations
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
-    long icp_group_prune = 0;    // group form of the association: 1 = skip cells by their box bounds (exact).  Measured SLOWER on the bench scene
-                                 // (2455 against 2885 scans/s, profiles/r05_j): at ~20 points per workgroup a search is bound by its fixed
-                                 // instruction stream, not by the ~240 candidates it reads -- off, kept as the record and for dense maps
     long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
@@ -335,6 +331,7 @@ struct Options {
     long staging_threads = 3;    // helper threads (besides the caller) for host-side staging copies
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
+    long stage_in = 1;           // ... unless the frame deskews: then a copy kernel brings the scan into HBM under the previous registration
     long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + emul * E)
     long icp_weight_long_emul = 1;    // ... and the multiplier of E there
@@ -383,6 +380,12 @@ struct DevBuf {
 int check_device(int device_id);
 BoundsRec *bounds_rec(int device_id);  // the device's BoundsRec (allocated on first use, zeroed), or nullptr
 
+}  // namespace kicp
+
+struct kicp_pipeline;
+namespace kicp {
+// kicp_pipeline_create with the pipeline's share of its device's persistent grid given explicitly (0: option "icp_device_streams")
+int pipeline_create_shared(const kicp_config *cfg, int device_id, int share, kicp_pipeline **out);
 }  // namespace kicp
 
 // The opaque handles of the C-ABI

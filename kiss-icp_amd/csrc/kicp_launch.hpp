@@ -78,6 +78,7 @@ void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s, hipE
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s);
 void launch_ts_minmax(const double *ts, int n_ts, PrepState *prep, hipStream_t s);
+void launch_stage_in(const void *src, void *dst, size_t bytes, hipStream_t s);  // device-mapped host memory -> HBM
 void launch_pre_flags(const PreParams &P, hipStream_t s);
 void launch_pre_scatter(const PreParams &P, hipStream_t s);
 void launch_ds_claim(const DsParams &P, hipStream_t s);

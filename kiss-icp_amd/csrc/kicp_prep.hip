@@ -510,6 +510,22 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter_rb(DsParams P) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.n_out = grand;
 }
 
+// Stage-in of a scan that lies in pinned, device-mapped HOST memory (the zero-copy staging slot): a plain copy into HBM.
+// With deskewing the front stages of a frame wait for the previous frame's pose -- they are on the frame's serial chain --
+// and k_pre_flags then read the scan over PCIe (30 us of the ~160 us chain, profiles/r03_ac_timeline.txt).  The scan itself
+// depends on no pose: this copy runs under the previous registration, and the chain reads HBM.
+__global__ __launch_bounds__(256) void k_stage_in(const char *src, char *dst, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d16[i] = s16[i];
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) dst[n16 * 16 + threadIdx.x] = src[n16 * 16 + threadIdx.x];
+}
+void launch_stage_in(const void *src, void *dst, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    hipLaunchKernelGGL(k_stage_in, dim3(grid_for((long)(bytes / 16 + 1), 256, 512)), dim3(256), 0, s, static_cast<const char *>(src),
+                       static_cast<char *>(dst), bytes);
+}
 void launch_ts_minmax(const double *ts, int n_ts, PrepState *st, hipStream_t s) {
     hipLaunchKernelGGL(k_ts_minmax, dim3(grid_for(n_ts, 256, 512)), dim3(256), 0, s, ts, n_ts, st);
 }

@@ -266,18 +266,52 @@ __device__ __forceinline__ double group_argmin(double best, int bkey, double bx,
     return gbest;
 }
 
+// ------------------------------------------------------------------------------------------
+// NORMS, not squared distances.  The reference compares (p - q).norm() with strict '<', inside a voxel (std::min_element)
+// and across voxels (VoxelHashMap.cpp:58-63): of all candidates whose ROUNDED SQUARE ROOTS are equal the earliest in
+// (shift, index) order wins.  The searches here compare squared distances -- a square root per candidate would double their
+// arithmetic --, which picks the same candidate unless two squared distances differ and their roots round to the same
+// double: values within a unit or two in the last place of each other (the root halves relative differences), once in
+// ~1e10 searches on real clouds.  So every fast search DETECTS that case -- a candidate it dropped, or another lane's best,
+// within kNormTie of the minimum (2^-50 relative: squared distances farther apart than that have different roots) -- and
+// the query is then searched again by closest_neighbor_exact: the map-direct search below with the reference's own
+// comparison, sqrt included.  Cells are skipped by their box bounds only when the bound is beyond kNormTie of the limit.
+// ------------------------------------------------------------------------------------------
+constexpr double kNormTie = 0x1.0000000000004p+0;  // 1 + 2^-50
+
+template <int STEP>
+__device__ __forceinline__ void group_fmin_step(double &v) {
+    const double o = group_xchg<STEP>(v);
+    v = o < v ? o : v;
+}
+template <int STEP>
+__device__ __forceinline__ void group_imin_step(int &v) {
+    const int o = group_xchg<STEP>(v);
+    v = o < v ? o : v;
+}
+// sec: a lower bound of the squared distances of this lane's candidates OTHER than its best (DBL_MAX: none, or not tracked).
+// Returns true when the minimum may not be the reference's choice: another lane's best, or a candidate a lane did not keep,
+// within kNormTie of the group's minimum g (and not equal to it across lanes: equal squares are settled by the key).
+__device__ __forceinline__ bool group_norm_tie(double best, double g, double sec) {
+    const double lim = g * kNormTie;
+    const bool mine = g < DBL_MAX && (sec <= lim || (best <= lim && best != g));
+    return (unsigned)(__ballot(mine) >> (threadIdx.x & 32)) != 0u;
+}
+
 //   FILL: additionally stage the candidates, packed in (shift, index) order, into an LDS region
 //   {x[stride], y[stride], z[stride]} so later ICP iterations of the same query never leave the CU.
 // Returns the squared distance (DBL_MAX when the neighbourhood is empty) and the neighbour.
+// tie (when given): set when the answer may differ from the reference's because of a tie in NORM (see above)
 template <bool FILL>
 __device__ __forceinline__ double scan_hits(const MapView &m, const Probe &pr, double sx, double sy, double sz,
-                                            int lane, double nn[3], double *cand = nullptr, int stride = 0) {
+                                            int lane, double nn[3], double *cand = nullptr, int stride = 0, bool *tie = nullptr) {
     // hit mask of this group (the wave holds two groups)
     const unsigned long long ball = __ballot(pr.blk >= 0);
     unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
     double best = DBL_MAX;
     double bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
+    double prev = DBL_MAX;  // what this lane's best replaced last (its candidates arrive in the reference's order)
     while (__ballot(hits != 0) != 0ull) {  // wave-uniform trip count
         double2 xy[kChunk];
         double zz[kChunk];
@@ -303,6 +337,7 @@ __device__ __forceinline__ double scan_hits(const MapView &m, const Probe &pr, d
                 const double d = (dx * dx + dy * dy) + dz * dz;
                 const int c = cb[u] + lane;
                 if (d < best) {  // voxels arrive in shift order: strict '<' keeps the earliest
+                    prev = best;  // (the candidate given up came first: if its norm is the same, the reference keeps it)
                     best = d;
                     bx = xy[u].x;
                     by = xy[u].y;
@@ -317,23 +352,88 @@ __device__ __forceinline__ double scan_hits(const MapView &m, const Probe &pr, d
             }
         }
     }
+    if (tie) {
+        double g = best;
+        group_fmin_step<0>(g);
+        group_fmin_step<1>(g);
+        group_fmin_step<2>(g);
+        group_fmin_step<3>(g);
+        group_fmin_step<4>(g);
+        *tie = group_norm_tie(best, g, prev);
+    }
     return group_argmin(best, bkey, bx, by, bz, lane, nn);
+}
+
+// The same search with the REFERENCE'S OWN comparison: norms (sqrt of the squared distance, correctly rounded like
+// Eigen's), strict '<' in (shift, index) order -- every lane meets its candidates in that order, the lanes are merged by
+// (norm, candidate number).  Twice the arithmetic of scan_hits; run for the queries a fast search has flagged, and by the
+// stand-alone GetClosestNeighbor.  Returns the SQUARED distance of the chosen neighbour.
+__device__ __forceinline__ double scan_hits_exact(const MapView &m, const Probe &pr, double sx, double sy, double sz, int lane, double nn[3]) {
+    const unsigned long long ball = __ballot(pr.blk >= 0);
+    unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
+    double bestn = DBL_MAX, best2 = DBL_MAX;
+    double bx = 0.0, by = 0.0, bz = 0.0;
+    int bkey = 0x7FFFFFFF;
+    while (__ballot(hits != 0) != 0ull) {  // wave-uniform trip count
+        double2 xy[kChunk];
+        double zz[kChunk];
+        int cb[kChunk];
+        bool ld[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            const int j = hits ? (__ffs(hits) - 1) : -1;
+            hits &= hits - 1;
+            const int bj = __shfl(pr.blk, j & 31, 32);
+            const int cj = __shfl(pr.cnt, j & 31, 32);
+            cb[u] = __shfl(pr.offs, j & 31, 32);
+            ld[u] = (j >= 0) && (lane < cj);
+            if (ld[u]) {
+                xy[u] = block_xy(m, bj)[lane];
+                zz[u] = block_z(m, bj)[lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+            if (ld[u]) {
+                const double dx = xy[u].x - sx, dy = xy[u].y - sy, dz = zz[u] - sz;
+                const double d = (dx * dx + dy * dy) + dz * dz;
+                const double nr = sqrt(d);  // (p - q).norm()
+                if (nr < bestn) {
+                    bestn = nr;
+                    best2 = d;
+                    bx = xy[u].x;
+                    by = xy[u].y;
+                    bz = zz[u];
+                    bkey = cb[u] + lane;
+                }
+            }
+        }
+    }
+    double gn = bestn;
+    int gkey = bkey, glane = lane;
+    group_min(gn, gkey, glane);  // lexicographic (norm, candidate number)
+    nn[0] = __shfl(bx, glane, 32);
+    nn[1] = __shfl(by, glane, 32);
+    nn[2] = __shfl(bz, glane, 32);
+    return __shfl(best2, glane, 32);
 }
 
 // Same search for voxels that hold more than 32 points (max_points_per_voxel > 32): every probe
 // lane strides over its voxel's points.  Rare configuration, kept simple.
 __device__ __forceinline__ double scan_hits_wide(const MapView &m, const Probe &pr, double sx, double sy,
                                                  double sz, int lane, double nn[3]) {
-    double best = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
+    double best = DBL_MAX, best2 = DBL_MAX, bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
     if (pr.blk >= 0) {
         const double2 *xy = block_xy(m, pr.blk);
         const double *z = block_z(m, pr.blk);
-        for (int k = 0; k < pr.cnt; ++k) {
+        for (int k = 0; k < pr.cnt; ++k) {  // (the reference's comparison itself -- norms: see scan_hits_exact)
             const double dx = xy[k].x - sx, dy = xy[k].y - sy, dz = z[k] - sz;
             const double d = (dx * dx + dy * dy) + dz * dz;
-            if (d < best) {
-                best = d;
+            const double nr = sqrt(d);
+            if (nr < best) {
+                best = nr;
+                best2 = d;
                 bx = xy[k].x;
                 by = xy[k].y;
                 bz = z[k];
@@ -341,7 +441,12 @@ __device__ __forceinline__ double scan_hits_wide(const MapView &m, const Probe &
         }
         bkey = lane;
     }
-    return group_argmin(best, bkey, bx, by, bz, lane, nn);
+    int glane = lane;
+    group_min(best, bkey, glane);
+    nn[0] = __shfl(bx, glane, 32);
+    nn[1] = __shfl(by, glane, 32);
+    nn[2] = __shfl(bz, glane, 32);
+    return __shfl(best2, glane, 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -392,6 +497,7 @@ struct Tile {
     int list_top;            // region_bytes / 2
     int *list_count;         // list entries handed out so far
     int ox, oy, oz;          // voxel with relative coordinates (0, 0, 0)
+    const double *far;       // a point at infinity in LDS (what a list's tail reads: tile_scan_list)
 };
 __device__ __forceinline__ int tile_ref(unsigned val) { return (int)(val & 0xFFFFFFu); }
 __device__ __forceinline__ int tile_cnt(unsigned val) { return (int)((val >> 24) & 63u); }
@@ -451,23 +557,14 @@ __device__ __forceinline__ void group_lds_sync() {
 // minimum of (distance, key) over the 32 lanes of a group, lexicographic; every lane ends with the winner.
 // Two all-reduces (DPP row operations + one swizzle each): the distance first, then the key among the lanes
 // that hold that distance.
-template <int STEP>
-__device__ __forceinline__ void group_fmin_step(double &v) {
-    const double o = group_xchg<STEP>(v);
-    v = o < v ? o : v;
-}
-template <int STEP>
-__device__ __forceinline__ void group_imin_step(int &v) {
-    const int o = group_xchg<STEP>(v);
-    v = o < v ? o : v;
-}
-__device__ __forceinline__ void group_min_dist_key(double &best, int &key) {
+__device__ __forceinline__ void group_min_dist_key(double &best, int &key, double sec = DBL_MAX, bool *tie = nullptr) {
     double g = best;
     group_fmin_step<0>(g);
     group_fmin_step<1>(g);
     group_fmin_step<2>(g);
     group_fmin_step<3>(g);
     group_fmin_step<4>(g);
+    if (tie) *tie = group_norm_tie(best, g, sec);
     int k = (best == g) ? key : 0x7FFFFFFF;
     group_imin_step<0>(k);
     group_imin_step<1>(k);
@@ -650,8 +747,9 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 // Returns the squared distance (DBL_MAX: no candidate), the neighbour, the number of points examined;
 // bad = the tile cannot answer: 1 a voxel is still being fetched by a concurrent fill, 2 one did not fit.
 __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz,
-                                            int lane, double nn[3], int &examined, int &bad) {
+                                            int lane, double nn[3], int &examined, int &bad, bool *tie = nullptr) {
     constexpr int U = 4;
+    double prev = DBL_MAX;  // the smallest squared distance this lane has met and not kept (kNormTie: it may have the best's norm and come first)
     int ref = 0, cnt = 0;
     int mybad = 0;
     bool glob = false;
@@ -705,6 +803,7 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
                 const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
                 const double d = (ex * ex + ey * ey) + ez * ez;
                 const bool take = (k0 + u < c) & (d < best);
+                prev = take ? best : prev;
                 best = take ? d : best;
                 bk = take ? k0 + u : bk;
             }
@@ -746,18 +845,21 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
                 const double d = (ex * ex + ey * ey) + ez * ez;
                 const int k = (kj[u] << 5) | lane;  // {shift position of the voxel, index inside it}
                 if (d < best || (d == best && k < key)) {
+                    prev = (d < best && best < prev) ? best : prev;
                     best = d;
                     key = k;
                     bx = xy[u].x;
                     by = xy[u].y;
                     bz = zz[u];
+                } else if (k < key && d < prev) {
+                    prev = d;  // (it comes before the best in the reference's order: if its norm is the best's, it should have won)
                 }
             }
         }
     }
     if (best == DBL_MAX) key = 0x7FFFFFFF;
     const int mykey = key;
-    group_min_dist_key(best, key);
+    group_min_dist_key(best, key, prev, tie);
     const bool found = key != 0x7FFFFFFF;
     // the lane that holds the winner hands its coordinates to the group
     const unsigned who = (unsigned)(__ballot(found && mykey == key) >> half_shift);
@@ -847,10 +949,14 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
 // GetClosestNeighbor over a scan list: 32 lanes stride over it, four candidates per lane in flight per trip,
 // no divergent control flow.  Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
 __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigned short *I, int n, double sx, double sy, double sz,
-                                                 int lane, double nn[3]) {
+                                                 int lane, double nn[3], bool *tie = nullptr) {
     constexpr int U = 4;
     const double *P = tile.points;
-    double best = DBL_MAX;
+    // A lane keeps its smallest squared distance AND its second smallest (every candidate that is not kept goes into it): the
+    // second is what tells a tie in norm (kicp_search.hpp, kNormTie) -- and costs nothing: v_min / v_max / v_min instead of
+    // the two selects of a conditional move, once the list's tail reads a point at infinity (tile.far) instead of being
+    // masked out of the comparison.
+    double best = DBL_MAX, sec = DBL_MAX;
     int bi = 0x7FFFFFFF;
     for (int i0 = lane; __ballot(i0 < n) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
         int pos[U];
@@ -862,7 +968,8 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
         double x[U], y[U], z[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const double *q = P + 3 * KICP_IDX((BoundsRec *)nullptr, (int *)nullptr, pos[u], tile.cap_points, 9);
+            const int i = i0 + 32 * u;
+            const double *q = i < n ? P + 3 * KICP_IDX((BoundsRec *)nullptr, (int *)nullptr, pos[u], tile.cap_points, 9) : tile.far;
             x[u] = q[0];
             y[u] = q[1];
             z[u] = q[2];
@@ -871,13 +978,13 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
         for (int u = 0; u < U; ++u) {
             const int i = i0 + 32 * u;
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
-            const double d = (ex * ex + ey * ey) + ez * ez;
-            const bool take = (i < n) & (d < best);
-            best = take ? d : best;
-            bi = take ? i : bi;
+            const double d = (ex * ex + ey * ey) + ez * ez;  // (+inf past the end of the list)
+            bi = d < best ? i : bi;                           // strict: a lane meets its candidates in list order and keeps the first
+            sec = __builtin_fmin(sec, __builtin_fmax(best, d));
+            best = __builtin_fmin(best, d);
         }
     }
-    group_min_dist_key(best, bi);
+    group_min_dist_key(best, bi, sec, tie);
     const bool found = bi != 0x7FFFFFFF;
     const int p = (int)I[found ? bi : 0];
     nn[0] = found ? P[3 * p] : 0.0;
@@ -890,8 +997,19 @@ __device__ __forceinline__ double closest_neighbor_any(const MapView &m, double 
                                                        int lane, double nn[3], int &examined, int &range_err) {
     const Probe pr = probe27(m, sx, sy, sz, lane, range_err);
     examined = pr.E;
-    if (m.max_points <= 32) return scan_hits<false>(m, pr, sx, sy, sz, lane, nn);
-    return scan_hits_wide(m, pr, sx, sy, sz, lane, nn);
+    if (m.max_points > 32) return scan_hits_wide(m, pr, sx, sy, sz, lane, nn);
+    bool tie = false;
+    const double d2 = scan_hits<false>(m, pr, sx, sy, sz, lane, nn, nullptr, 0, &tie);
+    if (!tie) return d2;
+    return scan_hits_exact(m, pr, sx, sy, sz, lane, nn);  // (a tie in norm: the reference's own comparison decides)
+}
+// ... with the reference's comparison throughout
+__device__ __forceinline__ double closest_neighbor_exact(const MapView &m, double sx, double sy, double sz, int lane, double nn[3], int &examined,
+                                                         int &range_err) {
+    const Probe pr = probe27(m, sx, sy, sz, lane, range_err);
+    examined = pr.E;
+    if (m.max_points > 32) return scan_hits_wide(m, pr, sx, sy, sz, lane, nn);
+    return scan_hits_exact(m, pr, sx, sy, sz, lane, nn);
 }
 
 }  // namespace kicp

@@ -2,7 +2,7 @@
 set -u
 T="${TAG:-r05_ab}"; O=gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 OPT="${OPT:-icp_group_prune}"
-( timeout 600 python -m pytest tests -x -q -m gpu -k "${KEXPR:-prune or ties or align or pipeline_kitti or vegetated}" 2>&1 | tail -8 ) > $O/${T}_pytest_subset.log
+( timeout 600 python -m pytest tests -x -q -m gpu -k "${KEXPR:-pair or norm or ties or align or pipeline or vegetated or closest or thread_per_query or stability or flat}" 2>&1 | tail -8 ) > $O/${T}_pytest_subset.log
 for rep in 1 2; do
   for v in 1 0; do
     timeout 300 python bench.py --gpus 1 --steps 200 --warmup 10 --no-cpu-baseline --no-extras --opt $OPT=$v > $O/${T}_bench_${OPT}${v}_r${rep}.json 2> $O/${T}_bench_${OPT}${v}_r${rep}.err

@@ -276,6 +276,57 @@ def test_closest_neighbor_exact(gpu, O):
     assert np.array_equal(nn[0], np.zeros(3)) and dist[0] == np.finfo(np.float64).max
 
 
+def test_closest_neighbor_compares_norms_like_the_reference(gpu, O):
+    """The reference's strict '<' is on (p - q).norm() (core/VoxelHashMap.cpp:58-63): among candidates whose ROUNDED ROOTS are
+    equal the earliest in (shift, index) order wins -- also when its squared distance is the larger one.  tests/norm_ties.py
+    constructs exactly that (squared distances one unit in the last place apart, equal roots, the later candidate the
+    smaller): in every cluster a comparison of squared distances would return the other point.  GetClosestNeighbor must
+    return the reference's, bit for bit (the searches detect such near ties and settle them with the reference's own
+    comparison: kicp_search.hpp, kNormTie)."""
+    from norm_ties import make_near_tie_scene
+
+    pts, qs, want = make_near_tie_scene(150, seed=1)
+    g, o = _maps(O, max_dist=1000.0)
+    g.add_points(pts)
+    o.add_points(pts)
+    assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(pts))  # (nothing fell to the spacing rule: the construction stands)
+    nn, dist = g.closest_neighbor(qs)
+    for i in range(len(qs)):
+        onn, od = o.closest_neighbor(qs[i])
+        assert np.array_equal(onn, pts[want[i]]), i  # the construction: the oracle keeps the EARLY candidate
+        assert np.array_equal(nn[i], onn), (i, nn[i], onn)
+        assert dist[i] == od, i
+
+
+@pytest.mark.parametrize("form", ["group", "group_one_workgroup", "thread_per_query"])
+def test_registration_compares_norms_like_the_reference(gpu, O, form):
+    """the same near ties inside AlignPointsToMap, in every form of the association: queries = source points under the
+    identity guess.  The two candidates of a cluster lie in different directions, so the other choice flips residuals: one
+    iteration's pose would be millimetres off.  Pose, correspondences and examined counts must be the oracle's."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.registration import Registration
+    from norm_ties import make_near_tie_scene
+
+    pts, qs, want = make_near_tie_scene(150, seed=2)
+    g, o = _maps(O, max_dist=1000.0)
+    g.add_points(pts)
+    o.add_points(pts)
+    try:
+        _cabi.set_option("icp_wide", 1 if form == "thread_per_query" else 0)
+        _cabi.set_option("icp_blocks", 1 if form == "group_one_workgroup" else 0)  # one workgroup: no scan lists, a lane per cell
+        for iters in (1, 3):
+            rg, ro = Registration(iters, 1e-12), O.Registration(iters, 1e-12)
+            Tg = rg.align_points_to_map(qs, g, np.eye(4), 3.0, 1.0)
+            To = ro.align_points_to_map(qs, o, np.eye(4), 3.0, 1.0)
+            dt, dr = pose_error(To, Tg)
+            assert dt < 1e-11 and dr < 1e-11, (form, iters, dt, dr)
+            assert rg.last_stats["n_corr_last"] == ro.last_stats["n_corr_last"]
+            assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
+    finally:
+        _cabi.set_option("icp_wide", -1)
+        _cabi.set_option("icp_blocks", 0)
+
+
 # ---- Registration ------------------------------------------------------------------------------------
 def _scene(rng, n=12000):
     floor = np.stack([rng.uniform(-25, 25, n), rng.uniform(-25, 25, n), rng.normal(0, 0.01, n)], axis=1)

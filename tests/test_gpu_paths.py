@@ -90,6 +90,42 @@ def test_async_host_input_is_bitwise_the_sync_path(gpu, O, deskew):
     assert dt < TIGHT and dr < TIGHT
 
 
+def test_stage_in_of_deskewing_frames_is_bitwise_neutral(gpu, O):
+    """option stage_in: a frame that deskews has its scan and timestamps copied from the staging slot into HBM in FRONT of the
+    wait for the previous pose (under the previous registration) instead of being read over PCIe on the frame's serial chain.
+    Same points either way: same trajectory bit for bit, queued or one frame at a time, float32-exact or genuinely float64
+    scans -- and the oracle's."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import mulran_like
+
+    ds = mulran_like(seed=6, n_frames=8, beams=32, azimuth_steps=512)
+    frames = [ds[i] for i in range(8)]
+    frames64 = [(p + 1e-9, t) for p, t in frames]  # not float32-exact: staged as float64
+    for data in (frames, frames64):
+        poses = {}
+        for stage_in in (1, 0):
+            _cabi.set_option("stage_in", stage_in)
+            try:
+                k = _pipe(deskew=True)
+                for p, t in data:
+                    k.register_frame_async(p, t)
+                k.sync()
+                poses[stage_in] = np.array(k.synced_poses())
+                if stage_in:
+                    k1 = _pipe(deskew=True)
+                    for p, t in data:
+                        k1.register_frame(p, t)
+                    assert np.array_equal(k1.last_pose, poses[1][-1])
+            finally:
+                _cabi.set_option("stage_in", 1)
+        assert np.array_equal(poses[0], poses[1])
+        ko = O.KissICP(deskew=1)
+        for p, t in data:
+            ko.register_frame(p, t)
+        dt, dr = pose_error(ko.last_pose, poses[1][-1])
+        assert dt < TIGHT and dr < TIGHT
+
+
 def test_async_many_more_frames_than_the_ring(gpu, O):
     """300 tiny frames queued without a sync: the library waits on its own when its 256-slot ring is full and
     the caller still gets every pose"""
@@ -178,7 +214,9 @@ def test_vegetated_scene_of_the_bench(gpu, O):
     points per group) for a few frames"""
     from kiss_icp_amd.datasets import generate_scans, kitti_like_vegetated
 
-    scans = generate_scans(kitti_like_vegetated, dict(seed=0, n_frames=8), range(8), processes=4)
+    # (generated in THIS process: a pool would fork a process that holds a HIP runtime and its threads -- a child can
+    # inherit a lock mid-flight and never return, and pool.map would wait for it for ever)
+    scans = generate_scans(kitti_like_vegetated, dict(seed=0, n_frames=8), range(8), processes=1)
     kg, ko = _pipe(deskew=False), O.KissICP(deskew=0)
     for i, (pts, ts) in enumerate(scans):
         kg.register_frame_async(pts, ts)
@@ -348,80 +386,6 @@ def test_first_iteration_window_phase_is_bitwise_neutral(gpu, O, blocks):
     To = O.Registration(500, 1e-4).align_points_to_map(src, o, guess, 3.0, 1.0)
     dt, dr = pose_error(To, out[1][0])
     assert dt < TIGHT and dr < TIGHT
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("blocks", [0, 1, 16])
-def test_pruned_group_search_is_bitwise_neutral(gpu, O, blocks):
-    """icp_group_prune: the 32-lane-group form skips the cells of the 27 whose box lies strictly farther than a candidate in
-    hand (first the last iteration's neighbour) and spreads the points of the cells it reads over the lanes.  A skipped cell
-    loses every comparison of VoxelHashMap.cpp:58-63 anyway: pose bit for bit, iteration count, correspondences and the
-    examined count (all 27 cells, as the reference counts them) equal those of reading every point -- with the default
-    partition, one workgroup over all points (chunks, a full tile, cells read from the map) and 16 -- and the oracle's."""
-    from kiss_icp_amd import _cabi
-    from kiss_icp_amd.mapping import VoxelHashMap
-    from kiss_icp_amd.registration import Registration
-
-    rng = np.random.default_rng(73)
-    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
-    world = random_cloud(rng, 30000, extent=25.0, z_extent=3.0)
-    g.add_points(world)
-    o.add_points(world)
-    src = world[rng.choice(len(world), 2500, replace=False)] + rng.normal(0, 0.03, (2500, 3))
-    guess = make_pose((0.2, -0.1, 0.02), (0.002, -0.001, 0.01))
-    out = {}
-    try:
-        _cabi.set_option("icp_wide", 0)  # (one workgroup over 2500 points would otherwise take the thread-per-query form)
-        _cabi.set_option("icp_blocks", blocks)
-        for prune in (1, 0):
-            _cabi.set_option("icp_group_prune", prune)
-            r = Registration(500, 1e-4)
-            out[prune] = (r.align_points_to_map(src, g, guess, 3.0, 1.0), dict(r.last_stats))
-    finally:
-        _cabi.set_option("icp_group_prune", 0)
-        _cabi.set_option("icp_blocks", 0)
-        _cabi.set_option("icp_wide", -1)
-    assert np.array_equal(out[0][0], out[1][0])
-    for k in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
-        assert out[0][1][k] == out[1][1][k], k
-    ro = O.Registration(500, 1e-4)
-    To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
-    dt, dr = pose_error(To, out[1][0])
-    assert dt < TIGHT and dr < TIGHT
-    assert out[1][1]["points_examined"] == ro.last_stats["points_examined"] and out[1][1]["iterations"] == ro.last_stats["iterations"]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("prune", [0, 1])
-def test_pruned_group_search_keeps_the_references_tie_order(gpu, O, prune):
-    """exact ties across cells (a lattice map, queries exactly between lattice points): the pruned search must keep the
-    candidate the reference's nested strict-'<' loops keep -- a cell whose bound EQUALS the distance in hand is still read"""
-    from kiss_icp_amd import _cabi
-    from kiss_icp_amd.mapping import VoxelHashMap
-    from kiss_icp_amd.registration import Registration
-
-    g, o = VoxelHashMap(1.0, 100.0, 20), O.VoxelHashMap(1.0, 100.0, 20)
-    ax = np.arange(-6.0, 6.0, 0.25)
-    lattice = np.stack(np.meshgrid(ax, ax, np.arange(-1.0, 1.0, 0.25), indexing="ij"), axis=-1).reshape(-1, 3)
-    lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]
-    g.add_points(lattice)
-    o.add_points(lattice)
-    qa = np.arange(-4.0, 4.0, 0.5)
-    try:
-        _cabi.set_option("icp_group_prune", prune)
-        for offset in ((0.125, 0.125, 0.125), (0.0, 0.125, 0.125), (0.9375, 0.125, 0.0625), (0.5, 0.5, 0.0)):
-            src = np.stack(np.meshgrid(qa, qa, np.array([-0.5, 0.0]), indexing="ij"), axis=-1).reshape(-1, 3) + np.array(offset)
-            for guess in (np.eye(4), make_pose((0.5, -0.25, 0.0))):
-                for iters in (1, 2, 5):
-                    rg, ro = Registration(iters, 1e-12), O.Registration(iters, 1e-12)
-                    Tg = rg.align_points_to_map(src, g, guess, 3.0, 1.0)
-                    To = ro.align_points_to_map(src, o, guess, 3.0, 1.0)
-                    dt, dr = pose_error(To, Tg)
-                    assert dt < 1e-10 and dr < 1e-10, (offset, iters, dt, dr)
-                    assert rg.last_stats["n_corr_last"] == ro.last_stats["n_corr_last"]
-                    assert rg.last_stats["points_examined"] == ro.last_stats["points_examined"]
-    finally:
-        _cabi.set_option("icp_group_prune", 0)
 
 
 def _wide_scene(kind, rng):
@@ -707,6 +671,70 @@ def test_two_pipelines_on_one_gpu_from_two_threads(gpu, O):
     assert not errors, errors
     for j in range(2):
         assert np.array_equal(results[j], alone[j]), j
+
+
+def test_whole_grid_launches_stay_ordered_after_a_shared_pipeline(gpu, O):
+    """the device's launch gate accounts for shares (round 4's review): a pipeline created with half the grid
+    (icp_device_streams = 2) is created, used and DESTROYED -- the lane count goes back to one with it --, then two whole-grid
+    pipelines and a stand-alone whole-grid registration run concurrently from three threads on the one device: their
+    persistent launches must still be ordered one behind the other (two whole grids side by side would wait for each
+    other's workgroups until the bounded spins give up: KICP_ERR_TIMEOUT or a replay with another summation tree), so every
+    trajectory is bit for bit the one the same work gives alone.  Then the mixed case while a shared pipeline is ALIVE: a
+    whole-grid launch takes every lane."""
+    import threading
+
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    n_frames = 8
+    data = [[kitti_like(seed=s, n_frames=n_frames)[i][0] for i in range(n_frames)] for s in (30, 31)]
+    world = random_cloud(np.random.default_rng(7), 30000, extent=25.0, z_extent=3.0)
+    src = world[::12] + np.array([0.05, -0.02, 0.01])
+
+    def run_pipe(scans):
+        k = _pipe(deskew=False)
+        for s in scans:
+            k.register_frame_async(s)
+        k.sync()
+        return k.synced_poses()
+
+    def run_reg(reps=12):
+        m = VoxelHashMap(1.0, 100.0, 20)
+        m.add_points(world)
+        r = Registration(500, 1e-4)
+        return [r.align_points_to_map(src, m, np.eye(4), 3.0, 1.0) for _ in range(reps)]
+
+    alone = [run_pipe(data[0]), run_pipe(data[1]), run_reg()]
+
+    def concurrently():
+        results, errors = [None, None, None], []
+
+        def drive(j):
+            try:
+                results[j] = run_pipe(data[j]) if j < 2 else run_reg()
+            except Exception as e:  # noqa: BLE001
+                errors.append((j, repr(e)))
+
+        threads = [threading.Thread(target=drive, args=(j,)) for j in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for j in range(3):
+            assert np.array_equal(np.asarray(results[j]), np.asarray(alone[j])), j
+
+    _cabi.set_option("icp_device_streams", 2)
+    try:
+        shared = _pipe(deskew=False)  # half the grid; the gate has two lanes while it lives
+    finally:
+        _cabi.set_option("icp_device_streams", 1)
+    shared.register_frame(data[0][0])
+    concurrently()  # whole-grid launches beside a live shared pipeline: each takes all lanes
+    del shared
+    concurrently()  # ... and after it is gone: one lane again
 
 
 def test_a_registration_that_gives_up_is_replayed(gpu, O):

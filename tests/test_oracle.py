@@ -490,3 +490,29 @@ def test_golden_sequence(O):
         k.register_frame(pts, ts)
         np.testing.assert_allclose(k.last_pose, g["poses"][i], rtol=0, atol=1e-11)
         assert k.last_stats()["iterations"] == int(g["iterations"][i])
+
+
+def test_near_tie_construction_and_the_oracles_norm_comparison(O):
+    """tests/norm_ties.py builds candidates whose squared distances differ by one unit in the last place while their norms
+    are equal, the LATER one (in the reference's order) the smaller.  The reference compares norms with strict '<'
+    (core/VoxelHashMap.cpp:58-63), so it keeps the earlier one: the oracle must (it uses sqrt like the reference), a
+    brute-force restatement of the loops must, and an argmin over squared distances must NOT -- else the GPU test built on
+    this scene would prove nothing."""
+    from norm_ties import brute_reference_choice, d2, make_near_tie_scene
+
+    pts, qs, want = make_near_tie_scene(90, seed=3)
+    assert len(qs) == 90
+    vox = {}
+    for i, p in enumerate(pts):
+        vox.setdefault(tuple(np.floor(p).astype(int)), []).append(i)
+    m = O.VoxelHashMap(1.0, 1000.0, 20)
+    m.add_points(pts)
+    assert len(m.point_cloud()) == len(pts)
+    differs = 0
+    for q, w in zip(qs, want):
+        nn, d = m.closest_neighbor(q)
+        assert brute_reference_choice(pts, vox, q) == w
+        assert np.array_equal(nn, pts[w]) and d == np.sqrt(d2(pts[w], q))
+        cands = [i for k, v in vox.items() for i in v if max(abs(np.array(k) - np.floor(q))) <= 1]
+        differs += min(cands, key=lambda i: (d2(pts[i], q), i)) != w
+    assert differs == len(qs)
