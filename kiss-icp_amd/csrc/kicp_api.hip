@@ -1605,7 +1605,13 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
         // CPUs, minus one for its caller and one to spare, caps its helpers: 1 stream on 16 CPUs -> the option's 3, 8 -> 0.
         long helpers = options().staging_threads;
         const int live = g_live_pipelines.load(std::memory_order_relaxed);
-        const long share = available_cpus() / (live > 0 ? live : 1) - 2;
+        long peers = 1;  // processes of one job on this box (torch.distributed.run / MPI launchers say how many): they share the cores too
+        for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"})
+            if (const char *e = getenv(name)) {
+                const long v = atol(e);
+                if (v > peers && v <= 1024) peers = v;
+            }
+        const long share = available_cpus() / ((live > 0 ? live : 1) * peers) - 2;
         if (helpers > share) helpers = share;
         if (helpers < 0) helpers = 0;
         p->pool = new (std::nothrow) StagePool((int)helpers);
