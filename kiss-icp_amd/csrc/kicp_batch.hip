@@ -2,6 +2,8 @@
 // kicp_batch.hpp over HIP pipelines, with the pose exchange done by RCCL called directly (librccl resolved with
 // dlopen, so libkicp.so itself does not depend on it) or by a communicator the host supplies.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -113,6 +115,21 @@ struct RcclApi {
     int (*GetVersion)(int *) = nullptr;
     std::string err;
 
+    // librccl.so is 570 MB of code objects, and a machine that has just booted from an image faults them in page by page
+    // while ncclCommInitRank walks them: 70 s and 290 s measured for the first process of two fresh MI355X boxes
+    // (profiles/r05_fresh_lease_loop.txt, run r), against 12 s for the same bytes read front to back.  So: read it front to
+    // back once before the loader maps it (0.1 s when it is cached already; KICP_NO_PREFETCH=1 skips this).
+    static void stream_into_page_cache(const char *path) {
+        if (getenv("KICP_NO_PREFETCH")) return;
+        const int fd = open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return;
+        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+        std::vector<char> buf((size_t)4 << 20);
+        while (read(fd, buf.data(), buf.size()) > 0) {
+        }
+        close(fd);
+    }
+
     bool load() {
         if (lib) return true;
         // The ROCm installation's own library, by PATH, before the bare name: a process that has imported torch
@@ -125,6 +142,7 @@ struct RcclApi {
         names.push_back("librccl.so.1");
         names.push_back("librccl.so");
         for (const std::string &name : names) {
+            if (name[0] == '/') stream_into_page_cache(name.c_str());
             lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
         }

@@ -1,11 +1,10 @@
 #!/bin/bash
 # The round's closing GPU call: everything the documentation quotes, in one box session, every piece under its own timeout.
-# Usage (through gpurun): TAG=r04_final bash scripts/gpu_final.sh
+# Usage (through gpurun): TAG=r05_final bash scripts/gpu_final.sh
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export KICP_BENCH_SUPERVISE=0  # (bench.py measures in this process: rocprofv3 and the tails below look at one process)
-T="${TAG:-r04_final}"
+T="${TAG:-r05_final}"
 O=gpurun_out
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 ) > $O/${T}_smoke.log
 ( timeout 900 python -m pytest tests -m gpu -q --timeout 300 --durations=8 --tb=short 2>&1 | tail -${PYTEST_TAIL:-30} ) > $O/${T}_pytest_gpu.log
@@ -53,13 +52,15 @@ timeout 300 python3 bench.py --workload mulran --steps 60 --warmup 10 --no-extra
 timeout 300 python3 bench.py --workload kitti-street --steps 100 --warmup 10 --no-extras > $O/${T}_bench_street.json 2> $O/${T}_bench_street.err
 timeout 500 python3 bench.py --workload livox --steps 100 --warmup 4 --no-extras > $O/${T}_bench_livox100.json 2> $O/${T}_bench_livox100.err
 timeout 300 python3 bench.py --gpus 2 --device 0 --steps 20 --warmup 5 > $O/${T}_bench_2streams_1gpu.json 2> $O/${T}_bench_2streams_1gpu.err
+# eight streams stacked on the one GPU through the host communicator: plumbing of the N = 8 path, and what it costs the HOST (host_cpu in the line)
+timeout 400 python3 bench.py --gpus 8 --device 0 --steps 20 --warmup 5 > $O/${T}_bench_8streams_1gpu.json 2> $O/${T}_bench_8streams_1gpu.err
 timeout 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --device 0 > $O/${T}_bench_2rank_gloo.json 2> $O/${T}_bench_2rank_gloo.err
 # in-kernel phase timers and the kernel timeline of two frames
 timeout 300 python scripts/icp_probe.py frames=160 > $O/${T}_icp_probe_steady.txt 2>&1
 timeout 400 python scripts/icp_probe.py livox=1 frames=100 > $O/${T}_icp_probe_livox100.txt 2>&1
 ( cd /tmp; cd $GRAFT_REPO_ROOT; STEPS=40 timeout 200 bash scripts/timeline.sh > $O/${T}_timeline.txt 2>&1 )
 for f in $O/${T}_smoke.log $O/${T}_pytest_gpu.log; do echo "== $f"; tail -6 $f; done
-for f in 20_5 200_10 mulran street livox100 2streams_1gpu 2rank_gloo; do python3 - <<PY
+for f in 20_5 200_10 mulran street livox100 2streams_1gpu 8streams_1gpu 2rank_gloo; do python3 - <<PY
 import json
 try:
     d = json.loads(open("$O/${T}_bench_$f.json").read().strip().splitlines()[-1])

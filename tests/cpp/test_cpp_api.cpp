@@ -3,6 +3,7 @@
 // kiss_icp::Registration::AlignPointsToMap, kiss_icp::VoxelHashMap, VoxelDownsample, Preprocessor --
 // compiled unchanged, running on the HIP path, checked against the CPU oracle (oracle/kiss_oracle.h;
 // test infrastructure, linked only into this test).  Run by tests/test_cpp_api.py on the GPU box.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,14 @@ static int g_fail = 0;
             ++g_fail;                                                      \
         }                                                                  \
     } while (0)
+
+// elapsed time at every section (a fresh box pages the ROCm libraries in from its image: the first process can spend
+// minutes in one of them -- this says in which)
+static void lap(const char *what) {
+    static const auto t0 = std::chrono::steady_clock::now();
+    std::printf("[%8.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+    std::fflush(stdout);
+}
 
 static unsigned long long g_seed = 88172645463325252ull;
 static double urand() {  // xorshift64*, deterministic everywhere
@@ -62,6 +71,7 @@ static double pose_diff(const double a[16], const double b[16]) {
 
 int main() {
     const double *X;
+    lap("start");
     // ---- VoxelDownsample / VoxelHashMap -------------------------------------------------------------
     Points world = scene(20000);
     X = reinterpret_cast<const double *>(world.data());
@@ -122,6 +132,7 @@ int main() {
         CHECK(snapshot.Empty() && !map.Empty());
     }
 
+    lap("VoxelDownsample / VoxelHashMap done");
     // ---- Registration::AlignPointsToMap ---------------------------------------------------------------
     {
         const Sophus::SE3d T_true = pose_of(0.3, -0.2, 0.02);
@@ -157,6 +168,7 @@ int main() {
         CHECK(pose_diff(Te, G) < 1e-15);
     }
 
+    lap("AlignPointsToMap done");
     // ---- pipeline::KissICP::RegisterFrame over a short drive ---------------------------------------------
     {
         kiss_icp::pipeline::KISSConfig cfg;
@@ -192,6 +204,7 @@ int main() {
         ko_pipeline_destroy(op);
     }
 
+    lap("RegisterFrame drive done");
     // ---- error conventions ---------------------------------------------------------------------------------
     {
         bool threw = false;
@@ -221,6 +234,7 @@ int main() {
             ko_preprocess(reinterpret_cast<const double *>(f.data()), f.size(), nullptr, 0, I, 20.0, 1.0, 0, 1, ref.data());
         CHECK(pre.Preprocess(f, {}, Sophus::SE3d()).size() == n);
     }
+    lap("error conventions done");
     // ---- multi-stream batch entry of the C-ABI from C++ (no Python, no torch): one stream on GPU 0, poses exchanged by
     // RCCL called directly by the library; frames queued four deep, poses against the oracle's --------------------------
     {
@@ -271,6 +285,7 @@ int main() {
         }
     }
     ko_map_destroy(omap);
+    lap("batch entry (RCCL) done");
     std::printf(g_fail ? "test_cpp_api: %d FAILED\n" : "test_cpp_api: all checks passed\n", g_fail);
     return g_fail ? 1 : 0;
 }

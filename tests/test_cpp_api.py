@@ -92,9 +92,14 @@ def test_no_gpu_is_a_loud_error_in_cpp_too(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1000)  # the FIRST GPU process of a fresh box pages the ROCm libraries in from its image (6 s .. 5 min seen for this program)
 def test_cpp_program_against_oracle(gpu, built):
-    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_cpp_api")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_cpp_api")], capture_output=True, text=True, timeout=900)
     print(r.stdout, r.stderr)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):  # (the program prints the elapsed time at every section: kept for the slow first runs)
+        with open(os.path.join(out_dir, "test_cpp_api_last.log"), "w") as f:
+            f.write(r.stdout + r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
 
