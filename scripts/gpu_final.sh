@@ -6,8 +6,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 T="${TAG:-r05_final}"
 O=gpurun_out
+# the driver's exact suite command as the FIRST process of the box (one more fresh-lease run), then the smoke
+( timeout 1150 python -m pytest tests/ -x -q -m gpu --durations=8 2>&1 | tail -${PYTEST_TAIL:-30} ) > $O/${T}_pytest_gpu.log
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 ) > $O/${T}_smoke.log
-( timeout 900 python -m pytest tests -m gpu -q --timeout 300 --durations=8 --tb=short 2>&1 | tail -${PYTEST_TAIL:-30} ) > $O/${T}_pytest_gpu.log
 # STOP_ON_FAIL=1: a red suite ends the call here (GPU minutes are for the fix, not for profiles of a wrong kernel)
 if [ "${STOP_ON_FAIL:-0}" = 1 ] && ! grep -q " passed" $O/${T}_pytest_gpu.log; then cat $O/${T}_pytest_gpu.log; exit 1; fi
 if [ "${STOP_ON_FAIL:-0}" = 1 ] && grep -q " failed" $O/${T}_pytest_gpu.log; then cat $O/${T}_pytest_gpu.log; exit 1; fi
