@@ -298,6 +298,11 @@ typedef struct kicp_host_stats {
                                    of the next registration; a starved device shows up here) */
     double max_device_gap_ms;   /* ... the largest single one */
     double max_call_ms;         /* the longest single call of an asynchronous entry */
+    /* placement of the host side (not counters: never reset).  -1 = unknown / not allocated yet */
+    int32_t device_numa_node;   /* NUMA node of the pipeline's GPU (sysfs, by PCI address) */
+    int32_t staging_numa_node;  /* node the pinned staging slots lie on */
+    int32_t staging_helpers;    /* helper threads of this pipeline ("staging_threads", capped by the usable CPUs) */
+    int32_t helpers_bound;      /* ... of which run restricted to the GPU's node */
 } kicp_host_stats;
 int kicp_pipeline_host_stats(kicp_pipeline *p, kicp_host_stats *stats, int reset);
 /* the HIP stream (hipStream_t) the pipeline launches on, as an opaque pointer */
@@ -417,6 +422,11 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     queued in front of the wait for the previous pose -- with deskewing the front stages sit on the frame's
  *                     serial chain, and reading the scan over PCIe there cost 30 us per frame; 0 = they read the slot themselves.
  *                     Same points, same poses.
+ *   "staging_numa"    1 (default): the pinned staging slots lie on the NUMA node the GPU hangs off -- the runtime's allocation is
+ *                     checked (move_pages) and, on another node, replaced by node-bound pages registered with the runtime --
+ *                     and the helper threads (and a batch's worker threads) run on that node's CPUs; 0 = wherever the
+ *                     runtime and the scheduler put them.  Without NUMA information (one node, a container that hides it)
+ *                     nothing changes.  kicp_host_stats says where things ended up.
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
  *   "downsample_order"  order in which VoxelDownsample emits its survivors: 1 (default) = the reference's, i.e. the bucket

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kicp_launch.hpp"
+#include "kicp_numa.hpp"
 
 namespace kicp {
 
@@ -467,9 +468,18 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
 // helper threads (plus the caller) split the copy into pinned staging memory.
 class StagePool {
 public:
-    explicit StagePool(int helpers) {
-        for (int i = 0; i < helpers; ++i) threads_.emplace_back([this] { loop(); });
+    // node >= 0: the helpers run on the CPUs of that NUMA node (the GPU's: what they write is read from there)
+    explicit StagePool(int helpers, int node = -1) {
+        for (int i = 0; i < helpers; ++i)
+            threads_.emplace_back([this, node] {
+                if (node >= 0 && numa::bind_thread_to_node(pthread_self(), node)) bound_.fetch_add(1, std::memory_order_relaxed);
+                started_.fetch_add(1, std::memory_order_release);
+                loop();
+            });
+        while (started_.load(std::memory_order_acquire) < helpers) std::this_thread::yield();
     }
+    int helpers() const { return (int)threads_.size(); }
+    int bound() const { return bound_.load(std::memory_order_relaxed); }
     ~StagePool() {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -545,8 +555,25 @@ private:
     Job *cur_ = nullptr;
     unsigned long gen_ = 0;
     std::atomic<unsigned long> gen_hint_{0};  // copy of gen_ the helpers may read without the lock
+    std::atomic<int> started_{0}, bound_{0};
     bool quit_ = false;
 };
+
+// the NUMA node a device hangs off (sysfs, by its PCI address); -1: unknown, or the platform has one node
+int device_numa_node(int device) {
+    static std::mutex mu;
+    static int cache[64];
+    static bool have[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    const int k = device & 63;
+    if (!have[k]) {
+        char bdf[64] = {0};
+        cache[k] = hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) == hipSuccess ? numa::pci_numa_node(bdf) : -1;
+        (void)hipGetLastError();
+        have[k] = true;
+    }
+    return cache[k];
+}
 
 // CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota (containers on GPU boxes: 16 of 256)
 static long available_cpus() {
@@ -1507,6 +1534,9 @@ struct kicp_pipeline {
     uint64_t staged = 0;
     int f32_skip = 0;  // frames for which the lossless-narrowing attempt is skipped (the last attempt failed)
     StagePool *pool = nullptr;
+    size_t stage_bytes = 0;
+    bool stage_registered = false;  // the slots are node-bound pages of our own, registered with the runtime (else: hipHostMalloc)
+    int stage_node = -1;            // NUMA node the slots lie on (-1: unknown)
     char *out_stage = nullptr;  // pinned bounce buffer of kicp_pipeline_output
     size_t out_stage_bytes = 0;
     // registration replay (timeout): co-residency cap for the ICP grid, the last frame's inputs
@@ -1578,6 +1608,18 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     return KICP_OK;
 }
 
+// (the caller has made sure the device no longer reads the slot)
+static void pipe_free_stage_slot(kicp_pipeline *p, int i) {
+    if (!p->stage[i]) return;
+    if (p->stage_registered) {
+        (void)hipHostUnregister(p->stage[i]);
+        numa::free_on_node(p->stage[i], p->stage_bytes);
+    } else {
+        (void)hipHostFree(p->stage[i]);
+    }
+    p->stage[i] = nullptr;
+}
+
 // pinned staging slots of the host-input path: [cap x 3 doubles | cap timestamps] each
 static int pipe_reserve_staging(kicp_pipeline *p) {
     if (p->stage_points >= p->cap_points && p->stage[0]) return KICP_OK;
@@ -1586,17 +1628,60 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
         p->stage_busy[i] = false;
         if (p->stage[i]) {
             KICP_TRY(wait_device(p->device, "staging slot release"));  // (hipHostFree waits for the whole device)
-            KICP_HIP(hipHostFree(p->stage[i]));
+            pipe_free_stage_slot(p, i);
         }
-        p->stage[i] = nullptr;
     }
+    // Where the slots lie: the runtime's pinned allocation first -- ROCm places it near the current device -- and a look at
+    // the node its first page really landed on (move_pages).  On another node than the GPU's (a two-socket 8-GPU box; a
+    // runtime that placed by the calling thread instead): pages of our own, bound to the GPU's node, registered with the
+    // runtime.  Wherever a step is refused (no NUMA information in the container, mbind not permitted, a registered
+    // range whose device address differs from the host's), the runtime's allocation stays.
+    const size_t bytes = ((p->cap_points * 4 * sizeof(double)) + 4095) & ~(size_t)4095;
+    const int want_node = options().staging_numa != 0 ? device_numa_node(p->device) : -1;
+    p->stage_registered = false;
+    p->stage_node = -1;
     for (int i = 0; i < kicp_pipeline::kStage; ++i) {
-        if (hipHostMalloc((void **)&p->stage[i], p->cap_points * 4 * sizeof(double)) != hipSuccess) {
-            set_error("pinned staging allocation of %zu bytes failed", p->cap_points * 4 * sizeof(double));
-            return KICP_ERR_OOM;
+        if (!p->stage_registered) {
+            if (hipHostMalloc((void **)&p->stage[i], bytes) != hipSuccess) {
+                set_error("pinned staging allocation of %zu bytes failed", bytes);
+                return KICP_ERR_OOM;
+            }
+            if (i == 0) {
+                memset(p->stage[0], 0, 4096);
+                p->stage_node = numa::node_of_address(p->stage[0]);
+                if (want_node >= 0 && p->stage_node >= 0 && p->stage_node != want_node) {
+                    void *own = numa::alloc_on_node(bytes, want_node), *dev = nullptr;
+                    if (own && hipHostRegister(own, bytes, hipHostRegisterDefault) == hipSuccess) {
+                        if (hipHostGetDevicePointer(&dev, own, 0) == hipSuccess && dev == own) {
+                            (void)hipHostFree(p->stage[0]);
+                            p->stage[0] = (char *)own;
+                            p->stage_registered = true;
+                            p->stage_node = numa::node_of_address(own);
+                            own = nullptr;
+                        } else {
+                            (void)hipHostUnregister(own);
+                        }
+                    }
+                    (void)hipGetLastError();
+                    if (own) numa::free_on_node(own, bytes);
+                }
+            }
+        } else {
+            void *own = numa::alloc_on_node(bytes, want_node), *dev = nullptr;
+            const bool ok = own && hipHostRegister(own, bytes, hipHostRegisterDefault) == hipSuccess;
+            if (!ok || hipHostGetDevicePointer(&dev, own, 0) != hipSuccess || dev != own) {
+                if (ok) (void)hipHostUnregister(own);
+                if (own) numa::free_on_node(own, bytes);
+                (void)hipGetLastError();
+                set_error("pinned staging allocation of %zu bytes on NUMA node %d failed", bytes, want_node);
+                p->stage_bytes = bytes;  // (what the slots already made are freed by)
+                return KICP_ERR_OOM;
+            }
+            p->stage[i] = (char *)own;
         }
         if (!p->ev_h2d[i]) KICP_HIP(hipEventCreateWithFlags(&p->ev_h2d[i], hipEventDisableTiming));
     }
+    p->stage_bytes = bytes;
     p->stage_points = p->cap_points;
     if (!p->pool) {
         // Helper threads only as far as the host has cores for them: every pipeline of the process has a caller (or a batch
@@ -1614,7 +1699,7 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
         const long share = available_cpus() / ((live > 0 ? live : 1) * peers) - 2;
         if (helpers > share) helpers = share;
         if (helpers < 0) helpers = 0;
-        p->pool = new (std::nothrow) StagePool((int)helpers);
+        p->pool = new (std::nothrow) StagePool((int)helpers, options().staging_numa != 0 ? device_numa_node(p->device) : -1);
         if (!p->pool) return KICP_ERR_OOM;
     }
     return KICP_OK;
@@ -2217,7 +2302,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
             if (p->ev_prep_done[i]) (void)hipEventDestroy(p->ev_prep_done[i]);
         for (int i = 0; i < kicp_pipeline::kStage; ++i) {
             if (p->ev_h2d[i]) (void)hipEventDestroy(p->ev_h2d[i]);
-            if (p->stage[i]) (void)hipHostFree(p->stage[i]);
+            pipe_free_stage_slot(p, i);
         }
         if (p->out_stage) (void)hipHostFree(p->out_stage);
         if (p->ev_ok)
@@ -2682,6 +2767,10 @@ int kicp_pipeline_host_stats(kicp_pipeline *p, kicp_host_stats *out, int reset) 
         out->map_grows = m->n_grow - p->map_grow0;
         out->map_rehashes = m->n_rehash - p->map_rehash0;
         out->wait_ms += m->wait_ms - p->map_wait0;
+        out->device_numa_node = device_numa_node(p->device);
+        out->staging_numa_node = p->stage[0] ? p->stage_node : -1;
+        out->staging_helpers = p->pool ? p->pool->helpers() : -1;
+        out->helpers_bound = p->pool ? p->pool->bound() : 0;
     }
     if (reset) {
         memset(&p->hs, 0, sizeof p->hs);
@@ -2897,6 +2986,8 @@ int kicp_set_option(const char *name, long value) {
         options().staging_zero_copy = value;
     } else if (!strcmp(name, "stage_in")) {
         options().stage_in = value != 0;
+    } else if (!strcmp(name, "staging_numa")) {
+        options().staging_numa = value != 0;
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (a weight is a 32-bit granule; the prefix sums are 64-bit)
         options().icp_weight_base = value;

@@ -332,6 +332,7 @@ struct Options {
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
     long stage_in = 1;           // ... unless the frame deskews: then a copy kernel brings the scan into HBM under the previous registration
+    long staging_numa = 1;       // staging slots and helper threads on the GPU's NUMA node (kicp_numa.hpp); 0 = wherever the runtime / the scheduler puts them
     long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + emul * E)
     long icp_weight_long_emul = 1;    // ... and the multiplier of E there
@@ -386,6 +387,7 @@ struct kicp_pipeline;
 namespace kicp {
 // kicp_pipeline_create with the pipeline's share of its device's persistent grid given explicitly (0: option "icp_device_streams")
 int pipeline_create_shared(const kicp_config *cfg, int device_id, int share, kicp_pipeline **out);
+int device_numa_node(int device);  // the NUMA node a device hangs off (sysfs); -1: unknown
 }  // namespace kicp
 
 // The opaque handles of the C-ABI

@@ -63,6 +63,7 @@ class HostStats(C.Structure):
         ("ring_syncs", C.c_uint64), ("counter_refreshes", C.c_uint64), ("map_grows", C.c_uint64), ("map_rehashes", C.c_uint64),
         ("buffer_grows", C.c_uint64), ("stage_ms", C.c_double), ("enqueue_ms", C.c_double), ("backpressure_ms", C.c_double),
         ("wait_ms", C.c_double), ("device_gap_ms", C.c_double), ("max_device_gap_ms", C.c_double), ("max_call_ms", C.c_double),
+        ("device_numa_node", C.c_int32), ("staging_numa_node", C.c_int32), ("staging_helpers", C.c_int32), ("helpers_bound", C.c_int32),
     ]
 
     def asdict(self):

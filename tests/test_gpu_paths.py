@@ -845,6 +845,34 @@ def test_async_entry_never_starves_the_device(gpu):
     # the serial chain between two registrations is ~0.1 ms (map update + run weights); a starved device shows ms
     assert h["max_device_gap_ms"] < 0.5, h
     assert len(k.synced_poses()) == 20
+    # where the host side lives (kicp_numa.hpp): wherever the platform says which node the GPU hangs off AND where a page
+    # lies, the staging slots are on the GPU's node; helper threads exist only as far as the usable CPUs allow
+    assert h["device_numa_node"] >= -1 and h["staging_numa_node"] >= -1, h
+    if h["device_numa_node"] >= 0 and h["staging_numa_node"] >= 0:
+        assert h["staging_numa_node"] == h["device_numa_node"], h
+    assert 0 <= h["helpers_bound"] <= h["staging_helpers"] <= 3, h
+
+
+def test_host_placement_can_be_left_to_the_runtime(gpu):
+    """option "staging_numa" = 0: no thread is bound, the slots stay where hipHostMalloc put them; same poses either way"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=5, n_frames=4, beams=32, azimuth_steps=512)
+    poses = {}
+    for flag in (1, 0):
+        _cabi.set_option("staging_numa", flag)
+        try:
+            k = _pipe(deskew=False)
+            for i in range(4):
+                k.register_frame(*ds[i])
+            poses[flag] = k.last_pose.copy()
+            h = k.host_stats()
+            if flag == 0:
+                assert h["helpers_bound"] == 0, h
+        finally:
+            _cabi.set_option("staging_numa", 1)
+    assert np.array_equal(poses[0], poses[1])
 
 
 def test_slot_array_rebuilt_in_stream_order(gpu, O):
