@@ -429,6 +429,9 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     nothing changes.  kicp_host_stats says where things ended up.
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
+ *   "relaxed_backpressure"  1 (default): that wait sleeps between its polls (40 us at a time) -- the caller is frames ahead of the
+ *                     device, nobody waits for a result, and a polling loop costs a core per stream; 0 = poll closely, as the waits
+ *                     for a RESULT do (kicp_pipeline_sync, the blocking entries)
  *   "downsample_order"  order in which VoxelDownsample emits its survivors: 1 (default) = the reference's, i.e. the bucket
  *                     order of the tsl::robin_map 1.4.0 it collects them in (VoxelUtils.cpp:7-21); 0 = ascending point index
  *                     (rounds 1-2).  The order decides which points AddPoints' first-come rule and the second downsample
@@ -440,6 +443,9 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     through their 3 x 3 Schur complement when that is well conditioned (pivots above 1e-9 of the diagonal);
  *                     0: always by the pivoted 6 x 6 LDLT of Eigen that the reference calls (Registration.cpp:156).  The two
  *                     differ by rounding (poses ~1e-13 apart); rank-deficient systems always take the LDLT and its zero-pivot rule.
+ *                     The default is a DELIBERATE departure from the reference's arithmetic (it can move the |dx| < 1e-4 stopping
+ *                     test by one iteration on a borderline frame); set 0 where the reference's own solve is wanted -- the test suite
+ *                     holds that path to the CPU oracle (tests/test_gpu_parity.py::test_registration_with_the_references_own_solve).
  *   "icp_wide"        form of the registration's association phase: 0 = a 32-lane group per source point (a few dozen points
  *                     per workgroup, neighbourhoods of hundreds of map points: full-size voxels); 1 = a thread per source
  *                     point (hundreds of points per workgroup: small voxels, large clouds); -1 (default) = by the size of

@@ -52,8 +52,12 @@ static bool host_trace_on() {
 // ---- bounded waits --------------------------------------------------------------------------------------------------
 // (declared in kicp_internal.hpp, which says why)
 static thread_local bool t_gave_up = false;  // this thread's most recent wait ended in KICP_ERR_TIMEOUT
+// relaxed: nobody is waiting for the RESULT of what is waited for -- queue back-pressure: the caller is frames ahead of the
+// device -- so the wait goes to sleep at once instead of yielding in a loop: a yield loop is a whole core per stream, and eight
+// ranks of it on the 16 CPUs a GPU box's container gets run into the cgroup's quota (round 5's closing session: 2.4 cores
+// busy per stream, half of it this loop).
 template <class Query>
-static int wait_poll(Query query, const char *kind, const char *what) {
+static int wait_poll(Query query, const char *kind, const char *what, bool relaxed = false) {
     const double t0 = now_ms();
     const double limit = (double)options().wait_timeout_ms;
     for (;;) {
@@ -74,7 +78,9 @@ static int wait_poll(Query query, const char *kind, const char *what) {
             return KICP_ERR_TIMEOUT;
         }
         // a registration is a fraction of a millisecond: poll closely at first, then leave the core to others
-        if (dt < 0.05) {
+        if (relaxed) {
+            std::this_thread::sleep_for(std::chrono::microseconds(dt < 5.0 ? 40 : 500));
+        } else if (dt < 0.05) {
             for (int k = 0; k < 8; ++k) _mm_pause();
         } else if (dt < 2.0) {
             std::this_thread::yield();
@@ -97,12 +103,12 @@ int wait_stream(hipStream_t s, const char *what) {
     }
     return wait_poll([s] { return hipStreamQuery(s); }, "hipStreamQuery", what);
 }
-int wait_event(hipEvent_t e, const char *what) {
+int wait_event(hipEvent_t e, const char *what, bool relaxed) {
     if (wait_blocking()) {
         KICP_HIP(hipEventSynchronize(e));
         return KICP_OK;
     }
-    return wait_poll([e] { return hipEventQuery(e); }, "hipEventQuery", what);
+    return wait_poll([e] { return hipEventQuery(e); }, "hipEventQuery", what, relaxed && options().relaxed_backpressure != 0);
 }
 
 struct StreamRegistry {
@@ -1745,7 +1751,7 @@ static int pipe_backpressure(kicp_pipeline *p) {
     if (hipEventQuery(pipe_frame_done_event(p, k - 1)) != hipSuccess) {
         (void)hipGetLastError();
         const double t0 = now_ms();
-        KICP_TRY(wait_event(pipe_frame_done_event(p, k - 1), "queue back-pressure"));
+        KICP_TRY(wait_event(pipe_frame_done_event(p, k - 1), "queue back-pressure", true));
         p->hs.backpressure_waits++;
         p->hs.backpressure_ms += now_ms() - t0;
     }
@@ -2988,6 +2994,8 @@ int kicp_set_option(const char *name, long value) {
         options().stage_in = value != 0;
     } else if (!strcmp(name, "staging_numa")) {
         options().staging_numa = value != 0;
+    } else if (!strcmp(name, "relaxed_backpressure")) {
+        options().relaxed_backpressure = value != 0;
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (a weight is a 32-bit granule; the prefix sums are 64-bit)
         options().icp_weight_base = value;

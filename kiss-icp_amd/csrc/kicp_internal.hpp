@@ -333,6 +333,7 @@ struct Options {
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
     long stage_in = 1;           // ... unless the frame deskews: then a copy kernel brings the scan into HBM under the previous registration
     long staging_numa = 1;       // staging slots and helper threads on the GPU's NUMA node (kicp_numa.hpp); 0 = wherever the runtime / the scheduler puts them
+    long relaxed_backpressure = 1;  // a caller that is queue_depth frames ahead of the device sleeps between polls instead of yielding in a loop
     long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + emul * E)
     long icp_weight_long_emul = 1;    // ... and the multiplier of E there
@@ -357,7 +358,7 @@ Options &options();
 // behind such a wait, over every stream the library has created on the device; when that wait gives up the resource is
 // leaked, not freed -- a leak can be lived with, a process that never returns cannot.
 int wait_stream(hipStream_t s, const char *what);
-int wait_event(hipEvent_t e, const char *what);
+int wait_event(hipEvent_t e, const char *what, bool relaxed = false);
 int wait_device(int device_id, const char *what);  // every stream libkicp has created on the device
 hipStream_t util_stream(int device_id);            // the library's own stream for buffer initialisation (nullptr: creation failed)
 void stream_register(int device_id, hipStream_t s);

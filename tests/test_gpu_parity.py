@@ -369,6 +369,41 @@ def test_align_points_to_map_matches_oracle(gpu, O, blocks):
         _cabi.set_option("icp_blocks", 0)
 
 
+def test_registration_with_the_references_own_solve(gpu, O):
+    """Registration.cpp:156 solves every Gauss-Newton step with Eigen's pivoted 6 x 6 LDLT.  The library's default goes through the
+    3 x 3 Schur complement where that is well conditioned -- a DELIBERATE departure (same step within rounding, a third of the
+    dependent chain; include/kicp.h "icp_schur_solve") -- so this pins the LDLT path, option 0, against the oracle: same
+    iterations, same correspondences, pose at rounding level; and holds the default to it."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(21)
+    g, o = _maps(O)
+    world = _scene(rng)
+    g.add_points(world)
+    o.add_points(world)
+    T_true = make_pose((0.35, -0.2, 0.05), (0.004, -0.003, 0.02))
+    src_world = _scene(np.random.default_rng(22), 3000)
+    src = (np.linalg.inv(T_true) @ np.c_[src_world, np.ones(len(src_world))].T).T[:, :3]
+    guess = make_pose((0.1, 0.0, 0.0))
+    reg_o = O.Registration(500, 1e-4)
+    To = reg_o.align_points_to_map(src, o, guess, 3.0, 1.0)
+    got = {}
+    try:
+        for flag in (0, 1):
+            _cabi.set_option("icp_schur_solve", flag)
+            reg_g = Registration(500, 1e-4)
+            got[flag] = reg_g.align_points_to_map(src, g, guess, 3.0, 1.0)
+            dt, dr = pose_error(To, got[flag])
+            assert dt < TIGHT and dr < TIGHT, (flag, dt, dr)
+            assert reg_g.last_stats["iterations"] == reg_o.last_stats["iterations"], flag
+            assert reg_g.last_stats["n_corr_last"] == reg_o.last_stats["n_corr_last"], flag
+    finally:
+        _cabi.set_option("icp_schur_solve", 1)
+    dt, dr = pose_error(got[0], got[1])
+    assert dt < 1e-11 and dr < 1e-11, (dt, dr)  # the two solves differ by rounding only
+
+
 @pytest.mark.parametrize("offset", [(0.125, 0.125, 0.125), (0.0625, 0.125, 0.125), (0.9375, 0.125, 0.0625)])
 def test_align_exact_ties_follow_the_reference_order(gpu, O, offset):
     """lattice map, queries exactly between lattice points: several candidates at EXACTLY the same
