@@ -423,10 +423,12 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     serial chain, and reading the scan over PCIe there cost 30 us per frame; 0 = they read the slot themselves.
  *                     Same points, same poses.
  *   "staging_numa"    1 (default): the pinned staging slots lie on the NUMA node the GPU hangs off -- the runtime's allocation is
- *                     checked (move_pages) and, on another node, replaced by node-bound pages registered with the runtime --
- *                     and the helper threads (and a batch's worker threads) run on that node's CPUs; 0 = wherever the
- *                     runtime and the scheduler put them.  Without NUMA information (one node, a container that hides it)
- *                     nothing changes.  kicp_host_stats says where things ended up.
+ *                     checked (move_pages) and, on another node, replaced by node-bound pages registered with the runtime;
+ *                     2 = in addition the helper threads (and a batch's worker threads) are restricted to that node's CPUs
+ *                     (not the default: on a one-GPU box it measured the same, 2955 against 2958 scans/s, and a thread that
+ *                     may run anywhere gets out of a busy neighbour's way -- boxes are shared); 0 = wherever the runtime and
+ *                     the scheduler put things.  Without NUMA information (one node, a container that hides it) nothing
+ *                     changes.  kicp_host_stats says where things ended up.
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
  *   "relaxed_backpressure"  1 (default): that wait sleeps between its polls (40 us at a time) -- the caller is frames ahead of the

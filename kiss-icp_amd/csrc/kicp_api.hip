@@ -1705,7 +1705,7 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
         const long share = available_cpus() / ((live > 0 ? live : 1) * peers) - 2;
         if (helpers > share) helpers = share;
         if (helpers < 0) helpers = 0;
-        p->pool = new (std::nothrow) StagePool((int)helpers, options().staging_numa != 0 ? device_numa_node(p->device) : -1);
+        p->pool = new (std::nothrow) StagePool((int)helpers, options().staging_numa >= 2 ? device_numa_node(p->device) : -1);
         if (!p->pool) return KICP_ERR_OOM;
     }
     return KICP_OK;
@@ -2993,7 +2993,8 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "stage_in")) {
         options().stage_in = value != 0;
     } else if (!strcmp(name, "staging_numa")) {
-        options().staging_numa = value != 0;
+        if (value < 0 || value > 2) return KICP_ERR_INVALID_ARG;
+        options().staging_numa = value;
     } else if (!strcmp(name, "relaxed_backpressure")) {
         options().relaxed_backpressure = value != 0;
     } else if (!strcmp(name, "icp_weight_base")) {

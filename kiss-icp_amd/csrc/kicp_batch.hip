@@ -44,7 +44,7 @@ struct HipPipe {
         block_bytes = bytes;
         n_total = total;
         // (this is the stream's worker thread: it copies every scan of its stream into pinned memory -- on the CPUs next to its GPU)
-        if (options().staging_numa != 0) (void)numa::bind_thread_to_node(pthread_self(), device_numa_node(dev));
+        if (options().staging_numa >= 2) (void)numa::bind_thread_to_node(pthread_self(), device_numa_node(dev));
         int rc = note(kicp::pipeline_create_shared(&cfg, dev, share, &pipe));
         if (rc != KICP_OK) return rc;
         if ((rc = hip(hipSetDevice(dev), "hipSetDevice")) != KICP_OK) return rc;

@@ -332,7 +332,7 @@ struct Options {
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
     long stage_in = 1;           // ... unless the frame deskews: then a copy kernel brings the scan into HBM under the previous registration
-    long staging_numa = 1;       // staging slots and helper threads on the GPU's NUMA node (kicp_numa.hpp); 0 = wherever the runtime / the scheduler puts them
+    long staging_numa = 1;       // 1: staging slots on the GPU's NUMA node (kicp_numa.hpp); 2: helper threads and batch workers on its CPUs too; 0: neither
     long relaxed_backpressure = 1;  // a caller that is queue_depth frames ahead of the device sleeps between polls instead of yielding in a loop
     long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + emul * E)

@@ -853,14 +853,15 @@ def test_async_entry_never_starves_the_device(gpu):
     assert 0 <= h["helpers_bound"] <= h["staging_helpers"] <= 3, h
 
 
-def test_host_placement_can_be_left_to_the_runtime(gpu):
-    """option "staging_numa" = 0: no thread is bound, the slots stay where hipHostMalloc put them; same poses either way"""
+def test_host_placement_levels(gpu):
+    """option "staging_numa": 0 = nothing placed, 1 (default) = the staging slots on the GPU's node, 2 = the helper threads
+    on its CPUs too (all of them, wherever the platform says which node the GPU hangs off); same poses at every level"""
     from kiss_icp_amd import _cabi
     from kiss_icp_amd.datasets import kitti_like
 
     ds = kitti_like(seed=5, n_frames=4, beams=32, azimuth_steps=512)
     poses = {}
-    for flag in (1, 0):
+    for flag in (2, 1, 0):
         _cabi.set_option("staging_numa", flag)
         try:
             k = _pipe(deskew=False)
@@ -868,11 +869,13 @@ def test_host_placement_can_be_left_to_the_runtime(gpu):
                 k.register_frame(*ds[i])
             poses[flag] = k.last_pose.copy()
             h = k.host_stats()
-            if flag == 0:
+            if flag < 2:
                 assert h["helpers_bound"] == 0, h
+            elif h["device_numa_node"] >= 0:
+                assert h["helpers_bound"] == h["staging_helpers"], h
         finally:
             _cabi.set_option("staging_numa", 1)
-    assert np.array_equal(poses[0], poses[1])
+    assert np.array_equal(poses[0], poses[1]) and np.array_equal(poses[1], poses[2])
 
 
 def test_slot_array_rebuilt_in_stream_order(gpu, O):
