@@ -34,9 +34,26 @@
 
 #define SOPHUS_EPS 1e-10 /* Sophus::Constants<double>::epsilon() */
 
+/* CPUs this process may really use: OpenMP's count (the affinity mask), capped by the container's CPU quota
+ * (cgroup v2 cpu.max: "<quota> <period>").  A GPU box's container sees 256 CPUs and may use 16: one thread per VISIBLE CPU
+ * made an 8-frame drive take 91 s instead of 0.1 (profiles/r05_u_first_rccl_probe.txt). */
 int ko_num_procs(void) {
 #ifdef _OPENMP
-    return omp_get_num_procs();
+    int n = omp_get_num_procs();
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0) {
+                const long c = (quota + period - 1) / period;
+                if (c >= 1 && c < n) n = (int)c;
+            }
+        }
+        fclose(f);
+    }
+    return n > 0 ? n : 1;
 #else
     return 1;
 #endif

@@ -825,26 +825,35 @@ def test_async_entry_never_starves_the_device(gpu):
 
     ds = kitti_like(seed=3, n_frames=25)  # (generated in this process: a pool would fork a process that holds a HIP runtime)
     scans = [(np.ascontiguousarray(ds[i][0], dtype=np.float64), ds[i][1]) for i in range(25)]
-    k = _pipe(deskew=False)
-    for p, t in scans[:2]:
-        k.register_frame_async(p, t)
-    k.sync()
-    k.host_stats(reset=True)
-    for p, t in scans[2:5]:
-        k.register_frame_async(p, t)
-    k.sync()
-    for p, t in scans[5:]:
-        k.register_frame_async(p, t)
-    k.sync()
-    h = k.host_stats()
-    assert h["frames"] == 23
-    for key in ("capacity_waits", "staging_waits", "ring_syncs", "counter_refreshes", "map_grows", "buffer_grows"):
-        assert h[key] == 0, (key, h)
-    assert h["wait_ms"] == 0.0, h
-    assert h["max_call_ms"] < 2.0, h  # a call is a copy into pinned memory plus a dozen launches
-    # the serial chain between two registrations is ~0.1 ms (map update + run weights); a starved device shows ms
-    assert h["max_device_gap_ms"] < 0.5, h
-    assert len(k.synced_poses()) == 20
+    # The counts are exact and hold every time.  The two DURATIONS are the host's, and the GPU boxes are shared: a busy neighbour
+    # has been seen to hold one call of a run for 3 - 4 ms (profiles/r05_s_*: three of five bench runs on one box, none on the next)
+    # -- so they get three tries, and a device that starves for a reason of this library's own fails all three.
+    seen = []
+    for attempt in range(3):
+        k = _pipe(deskew=False)
+        for p, t in scans[:2]:
+            k.register_frame_async(p, t)
+        k.sync()
+        k.host_stats(reset=True)
+        for p, t in scans[2:5]:
+            k.register_frame_async(p, t)
+        k.sync()
+        for p, t in scans[5:]:
+            k.register_frame_async(p, t)
+        k.sync()
+        h = k.host_stats()
+        assert h["frames"] == 23
+        for key in ("capacity_waits", "staging_waits", "ring_syncs", "counter_refreshes", "map_grows", "buffer_grows"):
+            assert h[key] == 0, (key, h)
+        assert h["wait_ms"] == 0.0, h
+        assert len(k.synced_poses()) == 20
+        seen.append((h["max_call_ms"], h["max_device_gap_ms"]))
+        # a call is a copy into pinned memory plus a dozen launches; the serial chain between two registrations is ~0.1 ms
+        # (map update + run weights) -- a starved device shows milliseconds
+        if h["max_call_ms"] < 2.0 and h["max_device_gap_ms"] < 0.5:
+            break
+    else:
+        pytest.fail("the host side held the device up in three runs of three: (max_call_ms, max_device_gap_ms) = %s" % seen)
     # where the host side lives (kicp_numa.hpp): wherever the platform says which node the GPU hangs off AND where a page
     # lies, the staging slots are on the GPU's node; helper threads exist only as far as the usable CPUs allow
     assert h["device_numa_node"] >= -1 and h["staging_numa_node"] >= -1, h
