@@ -431,6 +431,13 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     changes.  kicp_host_stats says where things ended up.
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
+ *   "collective_timeout_ms"  kicp_batch_*: how long a step that waits for PEERS may take -- the communicator's rendezvous
+ *                     (ncclCommInitRank returns when ALL ranks have joined) and a pose all-gather through a host communicator --
+ *                     before kicp_batch_create / kicp_batch_sync return KICP_ERR_TIMEOUT (default 1800000 = 30 min: a box's first
+ *                     RCCL initialisation has been seen to take 5; 0 = never).  The batch is then broken -- the threads inside the
+ *                     exchange cannot be cancelled --: every later call says so, and kicp_batch_destroy shuts down what responds,
+ *                     LEAKS the handle and returns KICP_ERR_TIMEOUT.  (An all-gather through RCCL waits on the stream and has the
+ *                     device deadline, "wait_timeout_ms", like every other wait.)  Read when the batch is created.
  *   "relaxed_backpressure"  1 (default): that wait sleeps between its polls (40 us at a time) -- the caller is frames ahead of the
  *                     device, nobody waits for a result, and a polling loop costs a core per stream; 0 = poll closely, as the waits
  *                     for a RESULT do (kicp_pipeline_sync, the blocking entries)

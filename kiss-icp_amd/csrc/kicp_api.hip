@@ -2997,6 +2997,9 @@ int kicp_set_option(const char *name, long value) {
         options().staging_numa = value;
     } else if (!strcmp(name, "relaxed_backpressure")) {
         options().relaxed_backpressure = value != 0;
+    } else if (!strcmp(name, "collective_timeout_ms")) {
+        if (value < 0) return KICP_ERR_INVALID_ARG;
+        options().collective_timeout_ms = value;
     } else if (!strcmp(name, "icp_weight_base")) {
         if (value < 1 || value > 1024) return KICP_ERR_INVALID_ARG;  // (a weight is a 32-bit granule; the prefix sums are 64-bit)
         options().icp_weight_base = value;

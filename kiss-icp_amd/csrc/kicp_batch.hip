@@ -286,7 +286,7 @@ int kicp_batch_create(const kicp_config *cfg, const int *devices, int n_local, i
         b->own_comm = true;
     }
     b->frames.resize(n_local);
-    b->driver.reset(new kicp_mstream::Driver<HipPipe>(n_local, first_rank, n_total, frames_per_gather, table));
+    b->driver.reset(new kicp_mstream::Driver<HipPipe>(n_local, first_rank, n_total, frames_per_gather, table, options().collective_timeout_ms));
     const kicp_config c = *cfg;
     // streams that share a GPU share its persistent registration grid: each pipeline is created with 1 / n of it, and
     // the device's gate lets n registrations run side by side (option "icp_device_streams", kicp_api.hip)
@@ -300,6 +300,7 @@ int kicp_batch_create(const kicp_config *cfg, const int *devices, int n_local, i
     });
     if (rc != KICP_OK) {
         set_error("%s", b->driver->last_error().c_str());
+        if (b->driver->broken()) return rc;  // (a worker may still be inside the rendezvous and come back into *b: leaked)
         delete b;
         return rc;
     }
@@ -309,6 +310,13 @@ int kicp_batch_create(const kicp_config *cfg, const int *devices, int n_local, i
 
 int kicp_batch_destroy(kicp_batch *b) {
     if (!b) return KICP_OK;
+    if (b->driver && b->driver->broken()) {
+        // an exchange was given up (collective_timeout_ms): the workers that are still inside it cannot be cancelled and may return
+        // into the handle at any time -- the responsive ones are shut down, the handle itself is leaked
+        b->driver->stop();
+        set_error("kicp_batch_destroy: the batch had been given up inside an exchange; its handle is leaked");
+        return KICP_ERR_TIMEOUT;
+    }
     b->driver.reset();
     delete b;
     return KICP_OK;

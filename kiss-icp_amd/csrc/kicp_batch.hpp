@@ -59,9 +59,13 @@ inline size_t block_doubles(size_t cap) { return kBlockHeader + 16 * cap; }
 template <class Pipe>
 class Driver {
 public:
-    Driver(int n_local, int first_rank, int n_total, size_t frames_per_gather, const kicp_batch_comm &comm)
+    // collective_timeout_ms > 0: a step that waits for PEERS -- the communicator's rendezvous, an all-gather -- is given up
+    // after that long (KICP_ERR_TIMEOUT): a rank of another process that never arrives must not hold this one for ever.
+    // The handle is then `broken`: its stuck threads cannot be cancelled, every later call says so, stop() lets go of them
+    // and the OWNER must leak the object instead of deleting it (the threads may still return into it).
+    Driver(int n_local, int first_rank, int n_total, size_t frames_per_gather, const kicp_batch_comm &comm, long collective_timeout_ms = 0)
         : n_local_(n_local), first_rank_(first_rank), n_total_(n_total), cap_(frames_per_gather), comm_(comm),
-          workers_(n_local) {}
+          workers_(n_local), timeout_ms_(collective_timeout_ms) {}
 
     ~Driver() { stop(); }
 
@@ -92,6 +96,7 @@ public:
     // one frame (or none) per local stream; returns when every stream has taken its frame
     int register_frames(const Frame *frames) {
         if (!started_) return fail(KICP_ERR_INVALID_ARG, "batch not started");
+        if (broken_) return fail_broken();  // (nothing of a worker is touched any more: some are still inside the exchange)
         for (int i = 0; i < n_local_; ++i) workers_[i].frame = frames[i];
         return post_all(Cmd::Enqueue);
     }
@@ -100,6 +105,7 @@ public:
     // poses(rank) holds what global rank `rank` completed since the previous sync.
     int sync() {
         if (!started_) return fail(KICP_ERR_INVALID_ARG, "batch not started");
+        if (broken_) return fail_broken();
         // a stream whose pipeline fails here still goes through the exchange (an empty block carrying its status): its
         // peers -- possibly in other processes -- are already on their way into the collective
         const int rc_sync = post_all(Cmd::Sync);
@@ -153,17 +159,27 @@ public:
     const std::string &last_error() const { return error_; }
     double last_gather_seconds() const { return gather_seconds_; }
 
+    bool broken() const { return broken_; }
+
     void stop() {
         if (!started_) return;
-        post_all(Cmd::Close);
+        if (!broken_) post_all(Cmd::Close);
         for (auto &w : workers_) {
+            bool busy;
             {
                 std::lock_guard<std::mutex> lk(w.m);
-                w.cmd = Cmd::Exit;
-                w.pending = true;
+                busy = w.busy;
+                if (!busy) {
+                    w.cmd = Cmd::Exit;
+                    w.pending = true;
+                }
             }
             w.cv.notify_one();
-            if (w.thread.joinable()) w.thread.join();
+            if (!w.thread.joinable()) continue;
+            if (busy)
+                w.thread.detach();  // (broken: still inside a collective that may never return; the owner leaks *this)
+            else
+                w.thread.join();
         }
         started_ = false;
     }
@@ -179,6 +195,7 @@ private:
         std::condition_variable cv;
         Cmd cmd = Cmd::None;
         bool pending = false, done = false;
+        bool busy = false;             // between a command's post and its completion
         int rc = KICP_OK;
         std::string err;
         Frame frame;
@@ -194,21 +211,39 @@ private:
         error_ = what;
         return rc;
     }
+    int fail_broken() { return fail(KICP_ERR_TIMEOUT, "the batch was given up after an exchange that did not return (a peer never arrived): destroy it"); }
 
     int post_all(Cmd c) {
+        if (broken_) return fail_broken();
         for (auto &w : workers_) {
             {
                 std::lock_guard<std::mutex> lk(w.m);
                 w.cmd = c;
                 w.pending = true;
                 w.done = false;
+                w.busy = true;
             }
             w.cv.notify_one();
         }
+        // (only the steps that wait for peers: a pipeline's own waits have the library's deadline, wait_timeout_ms)
+        const bool bounded = timeout_ms_ > 0 && (c == Cmd::OpenComm || c == Cmd::Gather);
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(bounded ? timeout_ms_ : 0);
         int rc = KICP_OK;
         for (auto &w : workers_) {
             std::unique_lock<std::mutex> lk(w.m);
-            w.cv.wait(lk, [&] { return w.done; });
+            if (bounded) {
+                if (!w.cv.wait_until(lk, deadline, [&] { return w.done; })) {
+                    broken_ = true;
+                    if (rc == KICP_OK) {
+                        rc = KICP_ERR_TIMEOUT;
+                        error_ = "stream " + std::to_string(first_rank_ + w.index) + ": " + (c == Cmd::OpenComm ? "the communicator's rendezvous" : "the pose exchange") +
+                                 " did not return within " + std::to_string(timeout_ms_) + " ms (collective_timeout_ms): a peer has not arrived";
+                    }
+                    continue;
+                }
+            } else {
+                w.cv.wait(lk, [&] { return w.done; });
+            }
             if (w.rc != KICP_OK && rc == KICP_OK) {
                 rc = w.rc;
                 error_ = "stream " + std::to_string(first_rank_ + w.index) + ": " + w.err;
@@ -301,6 +336,7 @@ private:
                 std::lock_guard<std::mutex> lk(w.m);
                 w.rc = rc;
                 w.done = true;
+                w.busy = false;
             }
             w.cv.notify_all();
         }
@@ -313,6 +349,8 @@ private:
     std::vector<std::vector<double>> all_poses_;
     std::string error_;
     bool started_ = false;
+    long timeout_ms_ = 0;   // deadline of the steps that wait for peers (0: none)
+    bool broken_ = false;   // such a step was given up: some worker may never come back
     size_t syncs_ = 0;
     double gather_seconds_ = 0.0;
 };

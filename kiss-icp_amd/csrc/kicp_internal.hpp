@@ -334,6 +334,7 @@ struct Options {
     long stage_in = 1;           // ... unless the frame deskews: then a copy kernel brings the scan into HBM under the previous registration
     long staging_numa = 1;       // 1: staging slots on the GPU's NUMA node (kicp_numa.hpp); 2: helper threads and batch workers on its CPUs too; 0: neither
     long relaxed_backpressure = 1;  // a caller that is queue_depth frames ahead of the device sleeps between polls instead of yielding in a loop
+    long collective_timeout_ms = 1800000;  // kicp_batch_*: a step that waits for PEERS (communicator rendezvous, pose all-gather through a host communicator) is given up after this long; 0 = never
     long icp_weight_base = 128;  // run boundaries: a source point weighs this + the population of its voxel
     long icp_weight_long_base = 128;  // the base for clouds of more than 64 points per workgroup (weight = this + c + emul * E)
     long icp_weight_long_emul = 1;    // ... and the multiplier of E there

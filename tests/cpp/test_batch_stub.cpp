@@ -359,7 +359,53 @@ static void test_a_failing_pipeline_does_not_strand_its_peers() {
     s2.join();
 }
 
+// A peer that never arrives: two "processes" share a communicator, only one of them syncs.  With a deadline on the steps that wait
+// for peers its sync comes back with KICP_ERR_TIMEOUT in time, every later call says the batch is broken, stop() returns although
+// its workers are still inside the exchange (they are let go of, the object must outlive them: it is leaked here as the C-ABI
+// leaks the handle), and the late peer's arrival afterwards finds valid memory.
+static void test_a_peer_that_never_arrives() {
+    StubComm *comm = new StubComm();  // (outlives the abandoned workers)
+    const int dev_a[2] = {0, 1}, dev_b[1] = {0};
+    auto *a = new Driver<StubPipe>(2, 0, 3, 4, comm->table(), 300);  // 300 ms for the peers
+    Driver<StubPipe> b(1, 2, 3, 4, comm->table(), 0);
+    int rc_a = -1, rc_b = -1;
+    std::thread ta([&] { rc_a = a->start(dev_a, plain); }), tb([&] { rc_b = b.start(dev_b, plain); });
+    ta.join();
+    tb.join();
+    CHECK(rc_a == KICP_OK && rc_b == KICP_OK);
+    double scan[3] = {1, 2, 3};
+    std::vector<Frame> f(2);
+    for (auto &x : f) {
+        x.xyz = scan;
+        x.n = 1;
+    }
+    CHECK(a->register_frames(f.data()) == KICP_OK);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = a->sync();  // b never syncs: the gather's barrier never fills
+    const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(rc == KICP_ERR_TIMEOUT);
+    CHECK(took > 0.25 && took < 1.5);
+    CHECK(a->broken());
+    CHECK(a->last_error().find("collective_timeout_ms") != std::string::npos);
+    CHECK(a->register_frames(f.data()) == KICP_ERR_TIMEOUT && a->sync() == KICP_ERR_TIMEOUT);  // broken: says so, at once
+    const auto t1 = std::chrono::steady_clock::now();
+    a->stop();  // returns: the workers inside the exchange are let go of
+    CHECK(std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() < 1.0);
+    // the late peer arrives after all: the abandoned workers finish their gather into memory that still exists
+    std::vector<Frame> fb(1);
+    fb[0].xyz = scan;
+    fb[0].n = 1;
+    CHECK(b.register_frames(fb.data()) == KICP_OK);
+    CHECK(b.sync() == KICP_OK);
+    check_poses(b, 2, 0, 1);
+    check_poses(b, 0, 0, 1);  // (what a's streams had contributed before they were given up)
+    b.stop();
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));  // (a's workers come home and go to sleep)
+    // `a` and `comm` are leaked on purpose
+}
+
 int main() {
+    test_a_peer_that_never_arrives();
     test_a_failing_pipeline_does_not_strand_its_peers();
     test_one_process_four_streams();
     test_two_processes();

@@ -170,3 +170,58 @@ def test_batch_sync_gives_up_in_time(short_deadline):
         time.sleep(STALL_MS / 1000.0)
     finally:
         b.close()
+
+
+def test_batch_gives_up_on_a_peer_that_never_arrives(gpu):
+    """The one wait that is not for the device: the pose exchange waits for PEERS.  Rank 0 of a two-rank job whose other
+    rank never shows up, through a host communicator (the MPI hook, kicp_batch_comm) whose all-gather blocks until released:
+    kicp_batch_sync returns KICP_ERR_TIMEOUT within "collective_timeout_ms", every later call says the batch is broken,
+    kicp_batch_destroy returns (the handle is leaked: a thread is still inside the exchange) -- and the late release finds
+    valid memory."""
+    import threading
+
+    cabi = _batch_cabi()
+    from kiss_icp_amd.config import load_config
+    from kiss_icp_amd.datasets import kitti_like
+    from kiss_icp_amd.multistream import StreamBatch
+
+    release = threading.Event()
+    entered = []
+
+    def all_gather(ctx, rank, d_send, d_recv, nbytes, stream):
+        entered.append(rank)
+        release.wait(30.0)  # the peer "arrives" when the test says so
+        return 0
+
+    comm = cabi.BatchComm(None, cabi.BatchComm.INIT(0), cabi.BatchComm.ALL_GATHER(all_gather), cabi.BatchComm.FINALIZE(0))
+    ds = kitti_like(seed=13, n_frames=2, beams=32, azimuth_steps=512)
+    cabi.set_option("collective_timeout_ms", 400)
+    try:
+        b = StreamBatch(load_config(deskew=False), [0], first_rank=0, n_total=2, comm=comm)
+    finally:
+        cabi.set_option("collective_timeout_ms", 1800000)
+    try:
+        b.register_frames([ds[0][0]])
+        t0 = time.perf_counter()
+        with pytest.raises(cabi.KicpError) as e:
+            b.sync()
+        took = time.perf_counter() - t0
+        assert e.value.status == 6 and "collective_timeout_ms" in str(e.value), str(e.value)
+        assert 0.35 < took < 0.4 + SLACK_S, took
+        assert entered == [0]
+        with pytest.raises(cabi.KicpError) as e2:  # broken: every later call says so at once
+            b.register_frames([ds[1][0]])
+        assert e2.value.status == 6
+        t1 = time.perf_counter()
+        assert cabi.lib().kicp_batch_destroy(b._h) == 6  # returns; the handle is leaked on purpose
+        b._h = None
+        assert time.perf_counter() - t1 < SLACK_S
+    finally:
+        release.set()  # the abandoned worker comes home into memory that still exists
+        time.sleep(0.2)
+
+
+def _batch_cabi():
+    from kiss_icp_amd import _cabi
+
+    return _cabi
