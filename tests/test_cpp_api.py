@@ -91,15 +91,31 @@ def test_no_gpu_is_a_loud_error_in_cpp_too(built):
     assert "no CPU fallback" in str(e.value)
 
 
-@pytest.mark.gpu
-@pytest.mark.timeout(1000)  # the FIRST GPU process of a fresh box pages the ROCm libraries in from its image (6 s .. 5 min seen for this program)
-def test_cpp_program_against_oracle(gpu, built):
-    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_cpp_api")], capture_output=True, text=True, timeout=900)
+def _run_cpp_program(flag, log_name):
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_cpp_api"), flag], capture_output=True, text=True, timeout=900)
     print(r.stdout, r.stderr)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):  # (the program prints the elapsed time at every section: kept for the slow first runs)
-        with open(os.path.join(out_dir, "test_cpp_api_last.log"), "w") as f:
+        with open(os.path.join(out_dir, log_name), "w") as f:
             f.write(r.stdout + r.stderr)
+    return r
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1000)
+def test_cpp_program_against_oracle(gpu, built):
+    """tests/cpp/test_cpp_api.cpp, everything but its batch entry: the reference-named C++ classes on the HIP path vs the oracle"""
+    r = _run_cpp_program("--no-batch", "test_cpp_api_front.log")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.cold_libs
+@pytest.mark.timeout(1000)  # the first use of RCCL on a lease reads 570 MB from the box's image: 2 s .. 5 min seen (profiles/r05_x_first_rccl_probe.txt)
+def test_cpp_program_batch_entry(gpu, built):
+    """... and its batch entry: kicp_batch_* from C++ with RCCL called directly (one rank), poses against the oracle's"""
+    r = _run_cpp_program("--batch-only", "test_cpp_api_last.log")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
 
@@ -147,6 +163,7 @@ def test_reference_python_composition_on_pybind_module(gpu, built):
 
 
 @pytest.mark.gpu
+@pytest.mark.cold_libs
 def test_pybind_points_as_arrays_and_dlpack_tensors(gpu, built):
     """every points argument of the pybind classes takes, besides the reference's _Vector3dVector, an (N,3) numpy
     array and a DLPack tensor without the copy into a vector; _KissICP._register_frame also takes a tensor that
@@ -189,6 +206,7 @@ def test_pybind_points_as_arrays_and_dlpack_tensors(gpu, built):
 
 
 @pytest.mark.gpu
+@pytest.mark.cold_libs
 def test_pybind_register_frame_takes_a_tensor_in_hbm(gpu, built):
     """_KissICP._register_frame on a torch ROCm tensor (DLPack, kDLROCM): the scan never visits the host.  Run in a
     process of its own in which torch initialises its HIP runtime first (torch bundles its own ROCm libraries; the

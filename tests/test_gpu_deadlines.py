@@ -150,6 +150,8 @@ def test_pipeline_entries_give_up_in_time_and_the_frame_is_not_lost(short_deadli
     time.sleep(STALL_MS / 1000.0)
 
 
+@pytest.mark.cold_libs  # (a batch without a host communicator loads RCCL)
+@pytest.mark.timeout(1000)
 def test_batch_sync_gives_up_in_time(short_deadline):
     cabi = short_deadline
     from kiss_icp_amd.config import load_config

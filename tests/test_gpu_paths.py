@@ -958,6 +958,8 @@ def test_device_solve_is_bitwise_the_oracles(gpu, O):
 
 
 # ---- multi-stream batch entry of the C-ABI ----------------------------------------------------------------
+@pytest.mark.cold_libs
+@pytest.mark.timeout(1000)
 def test_batch_entry_direct_rccl_single_rank(gpu, O):
     """kicp_batch_* with its own communicator: RCCL called directly (ncclCommInitRank / ncclAllGather from
     librccl) -- one rank is all a 1-GPU box offers, which still runs the init, the device exchange buffers and
