@@ -3,12 +3,14 @@
 # and the steady-state one.  Usage (through gpurun): TAG=r05_v bash scripts/gpu_confirm.sh
 set -u
 T="${TAG:-r05_confirm}"; O=gpurun_out; mkdir -p $O; export TMPDIR=/tmp
-( timeout 1150 python -m pytest tests/ -x -q -m gpu --durations=6 2>&1 | tail -14 ) > $O/${T}_pytest_gpu.log
+( timeout 1150 python -m pytest tests/ -x -q -m gpu --durations=8 2>&1 | tail -14 ) > $O/${T}_pytest_gpu.log
 cp $O/test_cpp_api_last.log $O/${T}_test_cpp_api_laps.log 2>/dev/null
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 ) > $O/${T}_smoke.log
+if [ "${SKIP_BENCH:-0}" != 1 ]; then
 timeout 300 python3 bench.py > $O/${T}_bench_default.json 2> $O/${T}_bench_default.err
 timeout 400 python3 bench.py --gpus 1 --steps 200 --warmup 10 > $O/${T}_bench_200_10.json 2> $O/${T}_bench_200_10.err
-cat $O/${T}_pytest_gpu.log; grep "^\[" $O/${T}_test_cpp_api_laps.log; cat $O/${T}_smoke.log
+fi
+cat $O/${T}_pytest_gpu.log; grep "^\[" $O/test_cpp_api_front.log $O/${T}_test_cpp_api_laps.log; cat $O/${T}_smoke.log
 python3 - <<PY
 import json
 for f in ("default", "200_10"):
