@@ -298,6 +298,7 @@ static void run_batch() {
 // machine that reads its image at a few MB/s the first use of RCCL alone takes minutes)
 int main(int argc, char **argv) {
     const bool no_batch = argc > 1 && std::string(argv[1]) == "--no-batch", batch_only = argc > 1 && std::string(argv[1]) == "--batch-only";
+    if (batch_only) lap("start (batch entry only)");
     if (!batch_only) run_front();
     if (!no_batch) run_batch();
     std::printf(g_fail ? "test_cpp_api: %d FAILED\n" : "test_cpp_api: all checks passed\n", g_fail);
