@@ -422,13 +422,14 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     queued in front of the wait for the previous pose -- with deskewing the front stages sit on the frame's
  *                     serial chain, and reading the scan over PCIe there cost 30 us per frame; 0 = they read the slot themselves.
  *                     Same points, same poses.
- *   "staging_numa"    1 (default): the pinned staging slots lie on the NUMA node the GPU hangs off -- the runtime's allocation is
- *                     checked (move_pages) and, on another node, replaced by node-bound pages registered with the runtime;
- *                     2 = in addition the helper threads (and a batch's worker threads) are restricted to that node's CPUs
- *                     (not the default: on a one-GPU box it measured the same, 2955 against 2958 scans/s, and a thread that
- *                     may run anywhere gets out of a busy neighbour's way -- boxes are shared); 0 = wherever the runtime and
- *                     the scheduler put things.  Without NUMA information (one node, a container that hides it) nothing
- *                     changes.  kicp_host_stats says where things ended up.
+ *   "staging_numa"    placement of the host side on the NUMA node the GPU hangs off.  1 (default): the node the pinned staging slots
+ *                     landed on is looked up (move_pages) and reported next to the GPU's (kicp_host_stats) -- on every box this
+ *                     library has run on ROCm's pinned allocation was on the GPU's node already; 2 = slots that are NOT are
+ *                     replaced by node-bound pages registered with the runtime, and the helper threads (and a batch's worker
+ *                     threads) are restricted to that node's CPUs (opt-in: the replacement has never had a box to run on, and
+ *                     bound threads measured the same on one GPU, 2955 against 2958 scans/s, while a thread that may run anywhere
+ *                     gets out of a busy neighbour's way -- boxes are shared); 0 = nothing is looked up.  Without NUMA
+ *                     information (one node, a container that hides it) nothing changes.
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
  *   "collective_timeout_ms"  kicp_batch_*: how long a step that waits for PEERS may take -- the communicator's rendezvous

@@ -1638,9 +1638,9 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
         }
     }
     // Where the slots lie: the runtime's pinned allocation first -- ROCm places it near the current device -- and a look at
-    // the node its first page really landed on (move_pages).  On another node than the GPU's (a two-socket 8-GPU box; a
-    // runtime that placed by the calling thread instead): pages of our own, bound to the GPU's node, registered with the
-    // runtime.  Wherever a step is refused (no NUMA information in the container, mbind not permitted, a registered
+    // the node its first page really landed on (move_pages), reported in kicp_host_stats.  With "staging_numa" = 2, slots on another
+    // node than the GPU's (a two-socket 8-GPU box; a runtime that placed by the calling thread instead) are replaced by pages of
+    // our own, bound to the GPU's node, registered with the runtime.  Wherever a step is refused (no NUMA information in the container, mbind not permitted, a registered
     // range whose device address differs from the host's), the runtime's allocation stays.
     const size_t bytes = ((p->cap_points * 4 * sizeof(double)) + 4095) & ~(size_t)4095;
     const int want_node = options().staging_numa != 0 ? device_numa_node(p->device) : -1;
@@ -1655,7 +1655,9 @@ static int pipe_reserve_staging(kicp_pipeline *p) {
             if (i == 0) {
                 memset(p->stage[0], 0, 4096);
                 p->stage_node = numa::node_of_address(p->stage[0]);
-                if (want_node >= 0 && p->stage_node >= 0 && p->stage_node != want_node) {
+                // (level 2 only: on every box this library has run on the runtime's allocation WAS on the GPU's node, so the
+                // replacement below has never executed on a device -- it stays out of the default path until it has)
+                if (options().staging_numa >= 2 && want_node >= 0 && p->stage_node >= 0 && p->stage_node != want_node) {
                     void *own = numa::alloc_on_node(bytes, want_node), *dev = nullptr;
                     if (own && hipHostRegister(own, bytes, hipHostRegisterDefault) == hipSuccess) {
                         if (hipHostGetDevicePointer(&dev, own, 0) == hipSuccess && dev == own) {

@@ -863,8 +863,9 @@ def test_async_entry_never_starves_the_device(gpu):
 
 
 def test_host_placement_levels(gpu):
-    """option "staging_numa": 0 = nothing placed, 1 (default) = the staging slots on the GPU's node, 2 = the helper threads
-    on its CPUs too (all of them, wherever the platform says which node the GPU hangs off); same poses at every level"""
+    """option "staging_numa": 0 = nothing looked up, 1 (default) = where the staging slots lie is reported, 2 = slots on another
+    node are re-made on the GPU's and the helper threads run on its CPUs (all of them, wherever the platform says which node
+    the GPU hangs off); same poses at every level"""
     from kiss_icp_amd import _cabi
     from kiss_icp_amd.datasets import kitti_like
 
