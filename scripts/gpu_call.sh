@@ -4,7 +4,6 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export KICP_BENCH_SUPERVISE=0  # (bench.py measures in this process: rocprofv3 and the tails below look at one process)
 WHAT="${WHAT:-tests bench}"
 TAG="${TAG:-x}"
 has() { [[ " $WHAT " == *" $1 "* ]]; }

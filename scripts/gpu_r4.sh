@@ -3,7 +3,6 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export KICP_BENCH_SUPERVISE=0  # (bench.py measures in this process: rocprofv3 and the tails below look at one process)
 STEPS="${STEPS:-t_wide livox}"
 TAG="${TAG:-r04_x}"
 has() { [[ " $STEPS " == *" $1 "* ]]; }

@@ -1,7 +1,6 @@
 #!/bin/bash
 # kernel timeline of the last frames of a short bench run (rocprofv3 --kernel-trace): where a frame's time goes
 export TMPDIR=/tmp
-export KICP_BENCH_SUPERVISE=0  # (bench.py measures in this process: rocprofv3 and the tails below look at one process)
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o r -- python bench.py --no-cpu-baseline --no-extras --steps ${STEPS:-40} ${BENCH_ARGS:-} > /dev/null 2>&1
 f=$(find gpurun_out/tl -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
