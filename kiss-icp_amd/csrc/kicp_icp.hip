@@ -121,7 +121,7 @@ constexpr int kBulkSetBytes = kBulkSet * 6;                 // the set (u32) and
 constexpr int kBulkJobs = (int)(sizeof(double) * kIcpTermChunk * kIcpTerms / 8);  // jobs that fit into sh.terms (8 bytes each)
 __device__ __forceinline__ bool tile_fill_bulk(MapView m, Tile tile, IcpShared *shp, int cn, IcpQueryMeta *metas, int *range_err_out, bool prof) {
     IcpShared &sh = *shp;
-    const int tid = threadIdx.x;
+    const int tid = kicp_tid();
     unsigned tk = prof ? ticks32() : 0u;
     auto stamp = [&](int ph) {
         if (prof && tid == 0) {
@@ -511,17 +511,20 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
             se3_act(guess, pin, sp);
             const int vx = voxel_coord(sp[0], m.voxel_size), vy = voxel_coord(sp[1], m.voxel_size), vz = voxel_coord(sp[2], m.voxel_size);
             int c = 0, E = 0;
+            // (seven lookups in flight -- 4 slots of 16 bytes each: 112 registers; nine at a time were the last four registers
+            // this form of the kernel could not hold)
+            constexpr int kAhead = 7;
 #pragma unroll
-            for (int jb = 0; jb < 27; jb += 9) {
-                unsigned long long key[9];
-                uint32_t hs[9];
-                bool ok[9];
-                Slot a[9][kProbeAhead];
+            for (int jb = 0; jb < 27; jb += kAhead) {
+                unsigned long long key[kAhead];
+                uint32_t hs[kAhead];
+                bool ok[kAhead];
+                Slot a[kAhead][kProbeAhead];
 #pragma unroll
-                for (int u = 0; u < 9; ++u) {
-                    const int j = jb + u;
+                for (int u = 0; u < kAhead; ++u) {
+                    const int j = jb + u < 27 ? jb + u : 26;
                     const int qx = vx + (int)((kShift.x >> (2 * j)) & 3) - 1, qy = vy + (int)((kShift.y >> (2 * j)) & 3) - 1, qz = vz + (int)((kShift.z >> (2 * j)) & 3) - 1;
-                    ok[u] = voxel_in_range(qx, qy, qz);
+                    ok[u] = jb + u < 27 && voxel_in_range(qx, qy, qz);
                     key[u] = pack_voxel(qx, qy, qz);
                     hs[u] = hash_key(key[u], m.mask);
 #pragma unroll
@@ -533,10 +536,10 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 9; ++u) {
+                for (int u = 0; u < kAhead; ++u) {
                     int blk, cnt;
                     if (!probe_resolve(a[u], key[u], blk, cnt)) probe_tail(m, (hs[u] + kProbeAhead) & m.mask, key[u], blk, cnt);
-                    if (blk < 0) cnt = 0;
+                    if (blk < 0 || jb + u >= 27) cnt = 0;
                     E += cnt;
                     if (jb + u == 0) c = cnt;  // the point's own voxel (shift 0 of the table)
                 }
@@ -680,6 +683,64 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
 #include "kicp_icp_wide.hpp"
 namespace kicp {
 
+// The solve of one Gauss-Newton step (Registration.cpp:156-157) on the sixteen sums: dx = LDLT(JTJ).solve(-JTr) -- through the
+// 3 x 3 Schur complement when that is well conditioned (kicp_math.hpp), else the reference's pivoted LDLT --, est = SE3::exp(dx);
+// nrm2 = |dx|^2 (all six components, :163).
+__device__ __forceinline__ SE3 icp_solve_sums(const double *tot, int schur, double &nrm2) {
+    double S[kIcpSums];
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) S[k] = tot[k];
+    double dx[6];
+    // well-conditioned systems (the rule) through their 3 x 3 Schur complement; anything else the reference's way
+    if (!(schur && schur3_solve(S, dx))) {
+        double JTJ[36], nb[6];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
+        JTJ[0] = JTJ[7] = JTJ[14] = S[0];
+        // top-right block sum w * (-hat(s)) and its transpose
+        JTJ[0 * 6 + 4] = S[3];
+        JTJ[0 * 6 + 5] = -S[2];
+        JTJ[1 * 6 + 3] = -S[3];
+        JTJ[1 * 6 + 5] = S[1];
+        JTJ[2 * 6 + 3] = S[2];
+        JTJ[2 * 6 + 4] = -S[1];
+        JTJ[4 * 6 + 0] = S[3];
+        JTJ[5 * 6 + 0] = -S[2];
+        JTJ[3 * 6 + 1] = -S[3];
+        JTJ[5 * 6 + 1] = S[1];
+        JTJ[3 * 6 + 2] = S[2];
+        JTJ[4 * 6 + 2] = -S[1];
+        JTJ[3 * 6 + 3] = S[4];
+        JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
+        JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
+        JTJ[4 * 6 + 4] = S[7];
+        JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
+        JTJ[5 * 6 + 5] = S[9];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
+        ldlt6_solve(JTJ, nb, dx);
+    }
+    nrm2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
+    return se3_exp(dx);
+}
+// ... out of line, result {q[4], t[3], |dx|^2} into LDS: the thread-per-query form's (one wave calls it)
+__device__ __noinline__ void icp_solve_to_lds(const double *tot, double *est_out, int schur) {
+    double nrm2;
+    const SE3 est = icp_solve_sums(tot, schur, nrm2);
+    if (threadIdx.x == 0) {
+        est_out[0] = est.q[0];
+        est_out[1] = est.q[1];
+        est_out[2] = est.q[2];
+        est_out[3] = est.q[3];
+        est_out[4] = est.t[0];
+        est_out[5] = est.t[1];
+        est_out[6] = est.t[2];
+        est_out[7] = nrm2;
+    }
+}
+
 // WIDE: the association phases of kicp_icp_wide.hpp (a thread per source point) instead of the 32-lane groups below;
 // everything else -- runs, the order of additions, exchange, solve -- is shared, so both forms give the same pose bit for bit.
 template <bool PROF, bool WIDE>
@@ -689,9 +750,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     // shift its base off 8/16-byte alignment)
     IcpShared &sh = *reinterpret_cast<IcpShared *>(smem);
 
-    const int tid = threadIdx.x;
-    const int lane = tid & (kIcpGroup - 1);
-    const int grp = tid / kIcpGroup;
+    const int tid = threadIdx.x;  // (the iteration loop has its own, with lane and group: see there)
     const MapView &m = P.map;
     PipeState *st = P.state;
 
@@ -881,7 +940,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         //      then thread (g, k) adds term k of the points of group g in ascending local index -- the order
         //      in which a group's lane 0 used to accumulate them, so the sums are bit for bit what they were
         // A and C cost one instruction stream per WORKGROUP instead of one per point.
-        const int ck = tid % kIcpTerms, cg = tid / kIcpTerms;  // phase C: term and group of this thread
+        // (The thread index goes through an empty asm statement at the top of every iteration and shadows the kernel's: whatever
+        // is derived from it -- lane and group, the predicates "tid < 64", "lane >= o" of every prefix scan, LDS addresses, term and
+        // group of phase C, scalar and member of the exchange -- is then recomputed where it is used.  Left alone, the compiler
+        // hoists all of it out of the iteration loop: dozens of 64-bit predicate masks, which do not fit the scalar registers and
+        // are parked lane by lane in vector registers (a dozen of them), and as many addresses -- in the thread-per-query form a
+        // good part of the registers that did not fit.)
+        const int tidv = kicp_tid();
+        const int tid = tidv, lane = tidv & (kIcpGroup - 1), grp = tidv / kIcpGroup;
+        const int ck = tidv % kIcpTerms, cg = tidv / kIcpTerms;  // phase C: term and group of this thread
         double acc = 0.0;
         unsigned t_group = 0;
         unsigned prof_path = 0;
@@ -1731,8 +1798,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // leader: thread (k, j) fetches scalar k of the group's j-th member; 26 members per pass, all of a pass in flight
             const int members = (G - (int)blockIdx.x + ng - 1) / ng;  // <= kIcpMaxMembers
             if (tid < kIcpParts * kIcpSums) {
-                const int k = tid % kIcpSums;
-                for (int j = tid / kIcpSums; j < members; j += kIcpParts) {
+                const int k = tidv % kIcpSums;
+                for (int j = tidv / kIcpSums; j < members; j += kIcpParts) {
                     const int b = (int)blockIdx.x + ng * j;
                     double v = 0.0;
                     if (!poll_pair(gran_rsrc, (unsigned)(((size_t)b * kIcpSums + k) * 16), v)) sh.fail = 1;
@@ -1760,7 +1827,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpSums) * 16), dummy)) sh.fail = 1;
         }
         __syncthreads();
-        for (int e = tid; e < ng * kIcpSums && !sh.fail; e += kIcpThreads) {
+        for (int e = tidv; e < ng * kIcpSums && !sh.fail; e += kIcpThreads) {
             const int k = e % kIcpSums, g = e / kIcpSums;
             double v = 0.0;
             if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpSums + k) * 16), v)) sh.fail = 1;
@@ -1785,74 +1852,55 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // ---- waves 0..3 (one per SIMD) of EVERY workgroup solve the same system; the result goes through LDS -----
         const unsigned c3 = PROF ? ticks32() : 0u;
         double nrm2 = 0.0;
-        if (tid < kIcpSolveThreads) {
-            double S[kIcpSums];
-#pragma unroll
-            for (int k = 0; k < kIcpSums; ++k) S[k] = sh.tot[k];
-            double dx[6];
-            // well-conditioned systems (the rule) through their 3 x 3 Schur complement; anything else the reference's way
-            if (!(P.schur_solve && schur3_solve(S, dx))) {
-                double JTJ[36], nb[6];
-#pragma unroll
-                for (int i = 0; i < 36; ++i) JTJ[i] = 0.0;
-                JTJ[0] = JTJ[7] = JTJ[14] = S[0];
-                // top-right block sum w * (-hat(s)) and its transpose
-                JTJ[0 * 6 + 4] = S[3];
-                JTJ[0 * 6 + 5] = -S[2];
-                JTJ[1 * 6 + 3] = -S[3];
-                JTJ[1 * 6 + 5] = S[1];
-                JTJ[2 * 6 + 3] = S[2];
-                JTJ[2 * 6 + 4] = -S[1];
-                JTJ[4 * 6 + 0] = S[3];
-                JTJ[5 * 6 + 0] = -S[2];
-                JTJ[3 * 6 + 1] = -S[3];
-                JTJ[5 * 6 + 1] = S[1];
-                JTJ[3 * 6 + 2] = S[2];
-                JTJ[4 * 6 + 2] = -S[1];
-                JTJ[3 * 6 + 3] = S[4];
-                JTJ[3 * 6 + 4] = JTJ[4 * 6 + 3] = S[5];
-                JTJ[3 * 6 + 5] = JTJ[5 * 6 + 3] = S[6];
-                JTJ[4 * 6 + 4] = S[7];
-                JTJ[4 * 6 + 5] = JTJ[5 * 6 + 4] = S[8];
-                JTJ[5 * 6 + 5] = S[9];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) nb[i] = -S[10 + i];
-                ldlt6_solve(JTJ, nb, dx);
-            }
-            est = se3_exp(dx);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) nrm2 += dx[i] * dx[i];
-            if (tid == 0) {
-                sh.est[0] = est.q[0];
-                sh.est[1] = est.q[1];
-                sh.est[2] = est.q[2];
-                sh.est[3] = est.q[3];
-                sh.est[4] = est.t[0];
-                sh.est[5] = est.t[1];
-                sh.est[6] = est.t[2];
-                sh.est[7] = nrm2;
-            }
-        }
-        __syncthreads();
-        if (tid >= kIcpSolveThreads) {
-            est.q[0] = sh.est[0];
-            est.q[1] = sh.est[1];
-            est.q[2] = sh.est[2];
-            est.q[3] = sh.est[3];
-            est.t[0] = sh.est[4];
-            est.t[1] = sh.est[5];
-            est.t[2] = sh.est[6];
+        if constexpr (WIDE) {
+            // (thread-per-query form: ONE wave solves, out of line, and the update is read from LDS where it is used -- phase A, the
+            // bookkeeping thread.  Inlined on four waves like below, the solve's ~150 registers on top of every thread's query
+            // state were where this form's spills came from: 193 registers, 380 bytes of scratch per lane, 335 MB of writes per
+            // launch in round 5.)
+            if (tid < 64) icp_solve_to_lds(sh.tot, sh.est, P.schur_solve);
+            __syncthreads();
             nrm2 = sh.est[7];
+        } else {
+            if (tid < kIcpSolveThreads) {
+                est = icp_solve_sums(sh.tot, P.schur_solve, nrm2);
+                if (tid == 0) {
+                    sh.est[0] = est.q[0];
+                    sh.est[1] = est.q[1];
+                    sh.est[2] = est.q[2];
+                    sh.est[3] = est.q[3];
+                    sh.est[4] = est.t[0];
+                    sh.est[5] = est.t[1];
+                    sh.est[6] = est.t[2];
+                    sh.est[7] = nrm2;
+                }
+            }
+            __syncthreads();
+            if (tid >= kIcpSolveThreads) {
+                est.q[0] = sh.est[0];
+                est.q[1] = sh.est[1];
+                est.q[2] = sh.est[2];
+                est.q[3] = sh.est[3];
+                est.t[0] = sh.est[4];
+                est.t[1] = sh.est[5];
+                est.t[2] = sh.est[6];
+                nrm2 = sh.est[7];
+            }
         }
         if (blockIdx.x == 0 && tid == kIcpBookThread) {
             // T_icp = est * T_icp (Registration.cpp:161) and the statistics, by a thread whose wave is
             // not on the critical path; sh.tot stays valid until the next gather
-            SE3 T;
+            SE3 T, step = est;
+            if constexpr (WIDE) {  // (this form keeps the update in LDS only)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) step.q[i] = sh.est[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) step.t[i] = sh.est[4 + i];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) T.q[i] = sh.T_icp[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) T.t[i] = sh.T_icp[4 + i];
-            T = se3_mul(est, T);
+            T = se3_mul(step, T);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sh.T_icp[i] = T.q[i];
 #pragma unroll

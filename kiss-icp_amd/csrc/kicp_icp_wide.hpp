@@ -145,8 +145,17 @@ __device__ __forceinline__ WideGaps wide_gaps(const double s[3], const int v[3],
 }
 // which of the 27 cells can still matter: bound <= limit (sums of three of the nine squared gaps, picked at compile time).
 // The reference compares norms (kicp_search.hpp): a cell is given up only when its bound lies beyond kNormTie of the limit.
-__device__ __forceinline__ unsigned wide_keep_mask(const WideGaps &gaps, double limit) {
+__device__ __forceinline__ unsigned wide_keep_mask(const WideGaps &gaps_in, double limit) {
     unsigned keep = 0u;
+    // (the six squared gaps go through empty asm statements: the 27 sums below depend on the query only, so the compiler hoisted
+    // them out of every loop this is called in and kept 54 registers alive across the searches and the queue rounds -- a third
+    // of the kernel's spills in round 5.  Recomputed per call they are 54 additions.)
+    WideGaps gaps = gaps_in;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        asm volatile("" : "+v"(gaps.m2[a]));
+        asm volatile("" : "+v"(gaps.p2[a]));
+    }
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
         const int cx = (int)((kShift.x >> (2 * j)) & 3), cy = (int)((kShift.y >> (2 * j)) & 3), cz = (int)((kShift.z >> (2 * j)) & 3);
@@ -497,7 +506,7 @@ constexpr size_t kWideFlatScratchBytes = sizeof(unsigned short) * 2 * (kWideItem
 static_assert(kWideItems < kIcpThreads, "a thread per item leads it");
 template <bool LDS>
 __device__ __forceinline__ void wide_serve_flat(const MapView &m, const Tile &tile, WideItem *items, int n, void *scr, bool promote) {
-    const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
+    const int tid = kicp_tid(), lane64 = tid & 63, wave = tid >> 6;
     unsigned short *start = reinterpret_cast<unsigned short *>(scr);  // [n + 1]: first point of item e in the round's sequence
     unsigned short *offs = start + (kWideItems + 2);                  // [n]: where item e's voxel goes in the LDS store (0xFFFF: nowhere)
     int *wsum = reinterpret_cast<int *>(offs + (kWideItems + 2));     // [8]: points per wave of leaders
@@ -683,7 +692,7 @@ __device__ __forceinline__ double wide_group_scan(const MapView &m, const Tile &
             mybad = 2;
         }
     }
-    const int half_shift = threadIdx.x & 32;
+    const int half_shift = kicp_tid() & 32;
     bad = (unsigned)(__ballot(mybad != 0) >> half_shift) != 0u ? 2 : 0;
     if (bad) cnt = 0;
     occ = (unsigned)(__ballot(cnt > 0) >> half_shift);
@@ -855,7 +864,7 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
                                               int *range_err_out, bool prof, int prefill_eighths) {
     const int cn = q_hi - q_lo;
     IcpShared &sh = *shp;
-    const int tid = threadIdx.x;
+    const int tid = kicp_tid();
     unsigned tk = prof ? ticks32() : 0u;
     auto stamp = [&](int ph) {
         if (prof && tid == 0) {

@@ -45,6 +45,15 @@ __device__ __forceinline__ void granule_store_pair(__amdgpu_buffer_rsrc_t r, uns
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_offset, 0, 16);
 }
 
+// The thread index through an empty asm statement: the compiler cannot prove two reads equal or loop-invariant, so what is
+// derived from it (predicates, lane numbers, LDS addresses) is computed where it is used -- one v_and -- instead of being
+// hoisted out of k_icp's iteration loop and kept alive across it (kicp_icp.hip: the loop's own tid, and why).
+__device__ __forceinline__ int kicp_tid() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 __device__ __forceinline__ int count_of(const int *n_ptr, int n_imm) { return n_ptr ? *n_ptr : n_imm; }
 
 // Point index of a sorted tile key {30-bit Morton code | 24-bit index} (kicp_sort.hip).
@@ -295,7 +304,7 @@ __device__ __forceinline__ void group_imin_step(int &v) {
 __device__ __forceinline__ bool group_norm_tie(double best, double g, double sec) {
     const double lim = g * kNormTie;
     const bool mine = g < DBL_MAX && (sec <= lim || (best <= lim && best != g));
-    return (unsigned)(__ballot(mine) >> (threadIdx.x & 32)) != 0u;
+    return (unsigned)(__ballot(mine) >> (kicp_tid() & 32)) != 0u;
 }
 
 //   FILL: additionally stage the candidates, packed in (shift, index) order, into an LDS region
@@ -307,7 +316,7 @@ __device__ __forceinline__ double scan_hits(const MapView &m, const Probe &pr, d
                                             int lane, double nn[3], double *cand = nullptr, int stride = 0, bool *tie = nullptr) {
     // hit mask of this group (the wave holds two groups)
     const unsigned long long ball = __ballot(pr.blk >= 0);
-    unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
+    unsigned hits = (unsigned)(ball >> (kicp_tid() & 32));
     double best = DBL_MAX;
     double bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
@@ -370,7 +379,7 @@ __device__ __forceinline__ double scan_hits(const MapView &m, const Probe &pr, d
 // stand-alone GetClosestNeighbor.  Returns the SQUARED distance of the chosen neighbour.
 __device__ __forceinline__ double scan_hits_exact(const MapView &m, const Probe &pr, double sx, double sy, double sz, int lane, double nn[3]) {
     const unsigned long long ball = __ballot(pr.blk >= 0);
-    unsigned hits = (unsigned)(ball >> (threadIdx.x & 32));
+    unsigned hits = (unsigned)(ball >> (kicp_tid() & 32));
     double bestn = DBL_MAX, best2 = DBL_MAX;
     double bx = 0.0, by = 0.0, bz = 0.0;
     int bkey = 0x7FFFFFFF;
@@ -622,7 +631,7 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
             }
         }
     }
-    const int half_shift = threadIdx.x & 32;
+    const int half_shift = kicp_tid() & 32;
     if ((unsigned)(__ballot(fail) >> half_shift) != 0u) {
         if (lane == 0) meta->valid = -1;  // do not try again
         return false;
@@ -776,7 +785,7 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
             mybad = 2;
         }
     }
-    const int half_shift = threadIdx.x & 32;
+    const int half_shift = kicp_tid() & 32;
     bad = (unsigned)(__ballot(mybad == 2) >> half_shift) != 0u ? 2 : ((unsigned)(__ballot(mybad == 1) >> half_shift) != 0u ? 1 : 0);
     if (bad) cnt = 0;
     int tot = cnt;
@@ -896,7 +905,7 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
             mybad = true;
         }
     }
-    const int half_shift = threadIdx.x & 32;
+    const int half_shift = kicp_tid() & 32;
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {

@@ -23,6 +23,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "kiss-icp_amd", "csrc", "libkicp.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
 def _device_listings():
@@ -87,3 +88,47 @@ def test_no_loaded_word_reaches_an_address_multiply_unmasked():
         assert not hits, "%s: a freshly loaded word is multiplied into an address without its mask (the ROCm 7.2 MUL_U24 miscompile):\n%s" % (
             name, "\n".join("  %s:  %s  ->  %s" % h for h in hits))
     assert seen > 20  # (the kernels do form such addresses: the scan looked at the right thing)
+
+
+def _kernel_notes():
+    """{kernel symbol: {metadata key: value}} of every gfx950 code object of the built library (llvm-readelf --notes)"""
+    if not (os.path.exists(OBJDUMP) and os.path.exists(READELF)):
+        pytest.skip("no llvm-objdump / llvm-readelf")
+    subprocess.check_call(["make", "-C", os.path.dirname(LIB)], stdout=subprocess.DEVNULL)
+    tmp = tempfile.mkdtemp(prefix="kicp_notes_")
+    out = {}
+    try:
+        shutil.copy(LIB, os.path.join(tmp, "libkicp.so"))
+        subprocess.run([OBJDUMP, "--offloading", "libkicp.so"], cwd=tmp, capture_output=True, text=True, check=True)
+        for name in sorted(os.listdir(tmp)):
+            if "amdgcn" in name and "gfx950" in name:
+                r = subprocess.run([READELF, "--notes", name], cwd=tmp, capture_output=True, text=True, check=True)
+                cur = None
+                for line in r.stdout.splitlines():
+                    m = re.match(r"\s*(?:- )?\.(\w+):\s+(\S+)", line)
+                    if not m:
+                        continue
+                    key, val = m.group(1), m.group(2)
+                    if line.lstrip().startswith("- ."):  # first key of a kernel's record
+                        cur = {}
+                    if cur is None:
+                        continue
+                    cur[key] = val
+                    if key == "name":
+                        out[val] = cur
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def test_the_registration_kernels_do_not_spill():
+    """Round 5's thread-per-query kernel spilled 193 registers (380 bytes of scratch per lane, 335 MB of writes per launch of the
+    1M-point configuration).  Both release forms of k_icp must fit their 256 registers: no spilled vector register, no scratch."""
+    notes = _kernel_notes()
+    for sym, form in (("_ZN4kicp5k_icpILb0ELb0EEEvNS_9IcpParamsE", "group"), ("_ZN4kicp5k_icpILb0ELb1EEEvNS_9IcpParamsE", "thread per query")):
+        assert sym in notes, "k_icp (%s form) not found in the code objects: %s" % (form, sorted(k for k in notes if "k_icp" in k))
+        k = notes[sym]
+        assert int(k["vgpr_spill_count"]) == 0, "k_icp (%s form) spills %s vector registers" % (form, k["vgpr_spill_count"])
+        assert int(k["private_segment_fixed_size"]) == 0, "k_icp (%s form) uses %s bytes of scratch per lane" % (form, k["private_segment_fixed_size"])
+        assert k.get("uses_dynamic_stack", "false") == "false"
+        assert int(k["vgpr_count"]) <= 256
