@@ -463,6 +463,11 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *   "icp_wide_prune"  thread-per-point form: 0 = visit every occupied voxel of the 27; 1 = skip voxels whose box lies farther
  *                     than the best candidate / the correspondence threshold; 2 (default) = also bounded by the previous
  *                     iteration's neighbour.  Exact: skipped voxels lose every comparison of VoxelHashMap.cpp:58-63 anyway.
+ *   "icp_group_stable"  group form (workgroups of at most 64 points, which keep a scan list per point): 1 (default) = a source point
+ *                     that has stayed in its voxel and whose last neighbour is still provably closer than every other candidate of
+ *                     its list (the list scan's second smallest distance, minus how far the point has moved since) keeps that
+ *                     neighbour without a search; 0 = every point is searched in every iteration.  Exact either way: pose,
+ *                     iterations, correspondences and examined points are bitwise the same (IcpQueryMeta::Lr).
  *   "icp_wide_stable"  thread-per-point form: 1 (default) = a source point that has stayed in its voxel and whose last neighbour is
  *                     still provably closer than any other map point (a bound kept from its last search, minus how far the
  *                     point has moved) keeps that neighbour without a search, and the searches that remain run on a few lanes;

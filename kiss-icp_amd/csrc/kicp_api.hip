@@ -463,6 +463,7 @@ static int icp_fill_policy(int device_id, IcpParams &P, size_t n_hint, int cap, 
     P.wide_flat = (int)options().icp_wide_flat;
     P.wide_group_max = (int)options().icp_wide_group_max;
     P.wide_stable = (int)options().icp_wide_stable;
+    P.group_stable = (int)options().icp_group_stable;
     P.wide_promote_from = (int)options().icp_wide_promote_from;
     P.wide_load_eighths = (int)options().icp_wide_load_eighths;
     return grid;
@@ -2953,6 +2954,8 @@ int kicp_set_option(const char *name, long value) {
         options().icp_wide_load_eighths = value;
     } else if (!strcmp(name, "icp_wide_stable")) {
         options().icp_wide_stable = value != 0;
+    } else if (!strcmp(name, "icp_group_stable")) {
+        options().icp_group_stable = value != 0;
     } else if (!strcmp(name, "icp_wide_per_round")) {
         if (value < 1 || value > 27) return KICP_ERR_INVALID_ARG;
         options().icp_wide_per_round = value;

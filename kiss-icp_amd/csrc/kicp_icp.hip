@@ -75,6 +75,9 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     int bulk_failed;  // tile_fill_bulk: cells that could not be entered (table full / block id beyond 24 bits)
     unsigned bulk_ticks[8];  // (profiling build) tile_fill_bulk's phases, 10 ns ticks (5 used)
     unsigned bulk_fail_keys[kBulkFailMax];
+    int search_count;                        // group form, phase B: points of the chunk that need a search ...
+    int pad3[3];
+    unsigned char search_idx[kIcpChunk];     // ... and which (filed by phase A in any order: nothing depends on who serves which)
     double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
@@ -832,6 +835,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     }
     const int n_meta = (P.use_lds && m.max_points <= 32) ? min(n_local, WIDE ? kWideChunk : kIcpMaxMeta) : 0;
     const bool use_lists = !WIDE && n_meta > 0 && n_local <= kIcpListRunMax;
+    // (group form) queries whose neighbour provably stays skip the search: runs that keep scan lists -- a single chunk, every
+    // query with its record, its point slot its own through the launch
+    const bool use_stable = use_lists && P.group_stable != 0 && n_local <= kIcpChunk && n_meta == n_local;
     // LDS behind the fixed part: only as many point slots of a chunk as the run can fill (a run of 16 points leaves
     // 9 KiB of the 128 to the tile), then the query records, the table, and the region of points and lists
     // (WIDE: all of sh.pts stays -- the slow-path queue and, with sh.terms, phase C's rows; 20-byte query records)
@@ -878,6 +884,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         sh.tile_entries = 0;
         sh.list_entries = 0;
         sh.any_fill = 0;
+        sh.search_count = 0;
         const SE3 id = se3_identity();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -902,6 +909,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             metas[i].list_state = 0;
             metas[i].list_base = 0;
             metas[i].list_n = metas[i].list_cap = 0;
+            metas[i].lr_state = 0;
         }
     }
     if (n_meta > 0)
@@ -1577,31 +1585,55 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
                              meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
                              meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
+                IcpPoint &pt = sh.pts[tid];
+                // STABILITY (IcpQueryMeta::Lr).  The query's last list scan, made from this very voxel, left its neighbour and count
+                // in this point slot (a run with lists is a single chunk: the slot is this query's through the launch) and Lr, a
+                // lower bound of the distance to every OTHER candidate of the 27 cells.  The query has moved by |s - pin| since the
+                // last iteration: every one of those candidates stays at least Lr - (all the moves since the scan) away, and while the
+                // neighbour's new distance is strictly below that it is still the unique minimum the reference's strict '<' loops
+                // would find (VoxelHashMap.cpp:55-63), with the same points examined: no search, the distance is computed here --
+                // by the expression the search uses, so the bits are the search's.
+                bool stable = false;
+                if (use_stable && it > 0 && cached && meta->lr_state == 1 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz) {
+                    const double mx = s[0] - pin[0], my = s[1] - pin[1], mz = s[2] - pin[2];
+                    const double moved = sqrt((mx * mx + my * my) + mz * mz) * (1.0 + 0x1p-30) + DBL_MIN;  // (rounded up)
+                    const double Lr = meta->Lr - moved;
+                    meta->Lr = Lr;
+                    if (pt.d2 < DBL_MAX) {  // (DBL_MAX: the 27 cells hold no candidate at all -- and never will)
+                        const double ex = pt.nn[0] - s[0], ey = pt.nn[1] - s[1], ez = pt.nn[2] - s[2];
+                        const double dp = (ex * ex + ey * ey) + ez * ez;  // (as the search computes it)
+                        stable = sqrt(dp) * (1.0 + 0x1p-30) < Lr;
+                        if (stable) pt.d2 = dp;
+                    } else {
+                        stable = true;
+                    }
+                }
                 if (has_meta) {
                     meta->s[0] = s[0];
                     meta->s[1] = s[1];
                     meta->s[2] = s[2];
+                    if (!stable) meta->lr_state = 0;  // (renewed by the search that follows, if it is a list scan)
                 } else {
                     P.work[3 * p] = s[0];
                     P.work[3 * p + 1] = s[1];
                     P.work[3 * p + 2] = s[2];
                 }
-                IcpPoint &pt = sh.pts[tid];
                 pt.s[0] = s[0];
                 pt.s[1] = s[1];
                 pt.s[2] = s[2];
                 pt.v[0] = vx;
                 pt.v[1] = vy;
                 pt.v[2] = vz;
-                pt.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
+                pt.flag = stable ? 3 : (cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2));
                 if (pt.flag == 1) sh.any_fill = 1;
+                if (!stable) sh.search_idx[atomicAdd(&sh.search_count, 1)] = (unsigned char)tid;
                 if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
                     sh.origin[0] = vx - kTileSpanXY / 2;
                     sh.origin[1] = vy - kTileSpanXY / 2;
                     sh.origin[2] = vz - kTileSpanZ / 2;
                 }
             }
-            if (tid == 0) sh.next_point = kIcpGroupsPerBlock;  // points 0..15 go to the groups directly
+            if (tid == 0) sh.next_point = kIcpGroupsPerBlock;  // the first 16 points that need a search go to the groups directly
             __syncthreads();
             tile.ox = sh.origin[0];
             tile.oy = sh.origin[1];
@@ -1636,7 +1668,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // do not take a fixed share: each takes the next unserved point when it is done.  Which group
             // serves a point has no influence on the result (phase C adds in point order).
             const unsigned tb0 = PROF ? ticks32() : 0u;
-            for (int t = grp; t < cn;) {
+            const int n_search = sh.search_count;  // (filed before the barrier behind phase A; reset behind the one that ends this phase)
+            for (int e = grp; e < n_search;) {
+                const int t = (int)sh.search_idx[e];
                 IcpPoint &pt = sh.pts[t];
                 const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
                 const int vx = pt.v[0], vy = pt.v[1], vz = pt.v[2];
@@ -1656,9 +1690,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         tile_list_build(tile, vx, vy, vz, lane, meta);
                     if (meta->list_state == 1) {
                         E = meta->list_n;
-                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, &tie);
+                        double sec2 = DBL_MAX;
+                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, &tie, use_stable, &sec2);
                         listed = true;
                         path = 1;
+                        // (a tie in norm is settled by the exact search below: its neighbour has no margin worth keeping)
+                        if (use_stable && lane == 0 && !tie) {
+                            meta->Lr = sqrt(sec2) * (1.0 - 0x1p-30);
+                            meta->lr_state = 1;
+                        }
                     }
                 }
                 if (flag == 0 && !listed) {
@@ -1685,7 +1725,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     pt.E = E;
                 }
                 const unsigned td = PROF ? ticks32() : 0u;
-                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && t == grp) {
+                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && e == grp) {
                     // per-group record of this iteration (10 ns ticks): where the group's time went
                     unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
                                                    (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
@@ -1698,10 +1738,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
                 int nt = 0;
                 if (lane == 0) nt = atomicAdd(&sh.next_point, 1);
-                t = __shfl(nt, 0, 32);
+                e = __shfl(nt, 0, 32);
             }
             if (PROF) t_group += ticks32() - tb0;
             __syncthreads();
+            if (tid == 0) sh.search_count = 0;  // (the next chunk's phase A files behind phase C's barriers)
             // ---- C -------------------------------------------------------------------------------------
             for (int sub = 0; sub < cn; sub += kIcpTermChunk) {
                 const int sn = min(kIcpTermChunk, cn - sub);

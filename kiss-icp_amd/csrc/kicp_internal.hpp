@@ -219,7 +219,7 @@ constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the wh
 constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time
 constexpr int kIcpTermChunk = 64;  // points whose products are in LDS together (a multiple of the group count)
 constexpr int kIcpTerms = 18;      // 16 normal-equation scalars + correspondence count + examined count
-constexpr int kIcpMaxMeta = 448;   // local points of a workgroup that may use the workgroup's voxel tile (64 bytes each)
+constexpr int kIcpMaxMeta = 448;   // local points of a workgroup that may use the workgroup's voxel tile (80 bytes each)
 constexpr int kIcpTileSlots = 4096;  // slots of the workgroup's voxel table (occupied voxels only; power of two)
 constexpr int kIcpListRunMax = 64;   // workgroups that serve at most this many points keep a scan list per point
 constexpr int kIcpWeightedMin = 2048;  // source clouds of at least this many points are cut into runs of equal weight
@@ -236,8 +236,15 @@ struct IcpQueryMeta {
     int lv[3];               // voxel of the query the scan list was built for
     int list_base;           // first entry of the list in the pool
     unsigned short list_n, list_cap;
+    // STABILITY (option icp_group_stable; the thread-per-query form's WideQuery::Lr, kicp_icp_wide.hpp): a lower bound -- a
+    // distance, shaved by 2^-30 -- of the distance from the query to every candidate of its scan list EXCEPT the neighbour the
+    // last list scan found, less the way the query has moved since.  While the query stays in voxel lv and the neighbour's new
+    // distance is strictly below it, the neighbour is still what the reference's strict '<' loops would find: no search.
+    double Lr;
+    int lr_state;  // 1: Lr, and the neighbour / count kept in the workgroup's point slot, belong to voxel lv
+    int pad;
 };
-static_assert(sizeof(IcpQueryMeta) == 64, "IcpQueryMeta layout");
+static_assert(sizeof(IcpQueryMeta) == 80, "IcpQueryMeta layout");
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
@@ -268,6 +275,7 @@ struct IcpParams {
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int schur_solve;       // solve well-conditioned normal equations through their 3 x 3 Schur complement (kicp_math.hpp: schur3_solve)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
+    int group_stable;      // group form: queries whose neighbour cannot have changed skip the search (IcpQueryMeta::Lr)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
     int wide_promote_from; // thread-per-query form: first iteration whose map reads leave their voxels in the LDS store
@@ -311,6 +319,7 @@ struct Options {
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
+    long icp_group_stable = 1;   // group form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
     long icp_wide_promote_from = 1;
     long icp_wide_load_eighths = 5;

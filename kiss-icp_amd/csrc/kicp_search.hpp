@@ -957,8 +957,11 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
 
 // GetClosestNeighbor over a scan list: 32 lanes stride over it, four candidates per lane in flight per trip,
 // no divergent control flow.  Returns the squared distance (DBL_MAX: no candidate) and the neighbour.
+// second (when given): the SECOND smallest squared distance over the whole list (+inf / DBL_MAX: the list holds one candidate /
+// none) -- the winner's lane contributes the runner-up of what it has met, every other lane its best; a candidate that ties
+// with the winner counts as a runner-up.  What the stability test of the next iterations needs (IcpQueryMeta::Lr).
 __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigned short *I, int n, double sx, double sy, double sz,
-                                                 int lane, double nn[3], bool *tie = nullptr) {
+                                                 int lane, double nn[3], bool *tie = nullptr, bool want_second = false, double *second = nullptr) {
     constexpr int U = 4;
     const double *P = tile.points;
     // A lane keeps its smallest squared distance AND its second smallest (every candidate that is not kept goes into it): the
@@ -993,8 +996,19 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
             best = __builtin_fmin(best, d);
         }
     }
+    const double mybest = best;
+    const int mybi = bi;
     group_min_dist_key(best, bi, sec, tie);
     const bool found = bi != 0x7FFFFFFF;
+    if (want_second) {
+        double g2 = (found && mybi == bi) ? sec : mybest;
+        group_fmin_step<0>(g2);
+        group_fmin_step<1>(g2);
+        group_fmin_step<2>(g2);
+        group_fmin_step<3>(g2);
+        group_fmin_step<4>(g2);
+        *second = g2;
+    }
     const int p = (int)I[found ? bi : 0];
     nn[0] = found ? P[3 * p] : 0.0;
     nn[1] = found ? P[3 * p + 1] : 0.0;
