@@ -372,6 +372,8 @@ int kicp_device_alloc(int device_id, size_t bytes, void **d_ptr);
 int kicp_device_free(int device_id, void *d_ptr);
 int kicp_device_upload(int device_id, void *d_dst, const void *h_src, size_t bytes);
 int kicp_device_download(int device_id, void *h_dst, const void *d_src, size_t bytes);
+/* waits, with the library's deadline (wait_timeout_ms), for what is queued at the moment of the call on the library's own streams
+ * of the device AND on its NULL stream; work on streams the caller created itself is the caller's to wait for */
 int kicp_device_synchronize(int device_id);
 
 /* Device self-test: n systems A x = b (A row-major 6x6, symmetric) solved by the ICP kernel's own solver (the

@@ -57,9 +57,9 @@ static thread_local bool t_gave_up = false;  // this thread's most recent wait e
 // ranks of it on the 16 CPUs a GPU box's container gets run into the cgroup's quota (round 5's closing session: 2.4 cores
 // busy per stream, half of it this loop).
 template <class Query>
-static int wait_poll(Query query, const char *kind, const char *what, bool relaxed = false) {
+static int wait_poll(Query query, const char *kind, const char *what, bool relaxed = false, long limit_ms = -1) {
     const double t0 = now_ms();
-    const double limit = (double)options().wait_timeout_ms;
+    const double limit = (double)(limit_ms >= 0 ? limit_ms : options().wait_timeout_ms);
     for (;;) {
         const hipError_t e = query();
         if (e == hipSuccess) {
@@ -74,7 +74,8 @@ static int wait_poll(Query query, const char *kind, const char *what, bool relax
         const double dt = now_ms() - t0;
         if (limit > 0.0 && dt > limit) {
             t_gave_up = true;
-            set_error("%s: the device did not finish within %ld ms (wait_timeout_ms); the work is still queued", what, options().wait_timeout_ms);
+            set_error("%s: the device did not finish within %ld ms (%s); the work is still queued", what, limit_ms >= 0 ? limit_ms : options().wait_timeout_ms,
+                      limit_ms >= 0 ? "collective_timeout_ms" : "wait_timeout_ms");
             return KICP_ERR_TIMEOUT;
         }
         // a registration is a fraction of a millisecond: poll closely at first, then leave the core to others
@@ -102,6 +103,15 @@ int wait_stream(hipStream_t s, const char *what) {
         return KICP_OK;
     }
     return wait_poll([s] { return hipStreamQuery(s); }, "hipStreamQuery", what);
+}
+// ... for work that waits on PEERS (an all-gather on the exchange stream): the collective's deadline, not the device's
+int wait_stream_peers(hipStream_t s, const char *what) {
+    if (wait_blocking()) {
+        KICP_HIP(hipStreamSynchronize(s));
+        return KICP_OK;
+    }
+    const long ms = options().collective_timeout_ms > 0 ? options().collective_timeout_ms : options().wait_timeout_ms;
+    return wait_poll([s] { return hipStreamQuery(s); }, "hipStreamQuery", what, false, ms);
 }
 int wait_event(hipEvent_t e, const char *what, bool relaxed) {
     if (wait_blocking()) {
@@ -135,20 +145,45 @@ void stream_forget(hipStream_t s) {
             return;
         }
 }
-int wait_device(int device_id, const char *what) {
-    std::vector<hipStream_t> mine;
+// A POINT-IN-TIME wait, like the hipFree / hipDeviceSynchronize it stands in for: an event is recorded on every stream the
+// library has on the device, under the registry's lock, and the EVENTS are polled -- work another thread queues on its own
+// pipeline after this call started is not waited for.  (Round 5 polled hipStreamQuery per stream, i.e. "until the stream is
+// idle": a second pipeline that is kept fed on the same device never is, and the buffer growth of the first starved into a
+// spurious KICP_ERR_TIMEOUT.)  null_stream: also what was queued on the NULL stream (kicp_device_synchronize: a caller's own
+// kernels that produced a buffer handed to the *_device entries).
+int wait_device(int device_id, const char *what, bool null_stream) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device_id) KICP_HIP(hipSetDevice(device_id));
+    std::vector<hipEvent_t> evs;
+    std::vector<hipStream_t> unmarked;  // (an event could not be had for these: polled as streams)
     {
         StreamRegistry &r = stream_registry();
         std::lock_guard<std::mutex> lk(r.mu);
-        for (const auto &e : r.v)
-            if (e.first == device_id) mine.push_back(e.second);
+        for (const auto &e : r.v) {
+            if (e.first != device_id) continue;
+            if (hipStreamQuery(e.second) == hipSuccess) continue;  // nothing pending: nothing to mark
+            (void)hipGetLastError();
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, e.second) == hipSuccess) {
+                evs.push_back(ev);
+            } else {
+                (void)hipGetLastError();
+                if (ev) (void)hipEventDestroy(ev);
+                unmarked.push_back(e.second);
+            }
+        }
     }
-    // (a stream destroyed by another thread between the copy and the query: the query fails, which ends the wait --
-    // handles are not destroyed under other threads' calls by contract)
-    // (the NULL stream is not polled: the library queues nothing on it -- new buffers are zero-filled on a stream of its
-    // own, util_stream, and its blocking copies are over when they return)
-    for (hipStream_t s : mine) KICP_TRY(wait_stream(s, what));
-    return KICP_OK;
+    int st = KICP_OK;
+    for (hipEvent_t ev : evs) {
+        if (st == KICP_OK) st = wait_event(ev, what, false);
+        (void)hipEventDestroy(ev);  // (deferred by the runtime while the event is pending)
+    }
+    for (hipStream_t s : unmarked)
+        if (st == KICP_OK) st = wait_stream(s, what);
+    if (st == KICP_OK && null_stream) st = wait_stream(nullptr, what);
+    if (prev >= 0 && prev != device_id) (void)hipSetDevice(prev);
+    return st;
 }
 struct UtilStreams {
     std::mutex mu;
@@ -1148,9 +1183,11 @@ int kicp_registration_destroy(kicp_registration *r) {
         if (r->ev0) (void)hipEventDestroy(r->ev0);
         if (r->ev1) (void)hipEventDestroy(r->ev1);
     }
-    if (r->stream) {
+    if (r->stream && idle == KICP_OK) {
+        // (a stream that is leaked with its k_icp possibly in flight keeps its lane of the device's launch gate: later
+        // registrations are ordered behind it instead of being launched beside it)
         icp_forget_stream(r->device, r->stream);
-        if (idle == KICP_OK) (void)stream_destroy(r->stream);
+        (void)stream_destroy(r->stream);
     }
     delete r;
     return idle;
@@ -1576,7 +1613,7 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
     KICP_TRY(wait_stream(p->prep_stream, "pipeline buffers (front stages)"));
     // never less than a minimum: an EMPTY first scan must still find its buffers (the front-stage
     // kernels write their counts even for zero points)
-    size_t cap = n + n / 8 + 1024;
+    size_t cap = (n + n / 8 + 1024 + 1) & ~(size_t)1;  // (even: the timestamps behind cap x 24 bytes of a staging slot stay 16-byte aligned for k_stage_in's 16-byte loads)
     const size_t b3 = cap * 3 * sizeof(double);
     for (int i = 0; i < 2; ++i) {
         KICP_TRY(p->raw[i].reserve(b3));
@@ -2323,8 +2360,9 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     }
     for (hipStream_t s : {p->copy_stream, p->prep_stream, p->stream}) {
         if (!s) continue;
+        if (!gone) continue;  // (leaked with the rest: kept in the registry, and -- its k_icp may be in flight -- in its lane of the launch gate)
         if (s == p->stream) icp_forget_stream(p->device, s);
-        if (gone) (void)stream_destroy(s);  // (else leaked with the rest, and kept in the registry)
+        (void)stream_destroy(s);
     }
     delete p;
     return gone ? KICP_OK : idle;
@@ -2870,7 +2908,7 @@ int kicp_device_download(int device_id, void *h_dst, const void *d_src, size_t b
 }
 int kicp_device_synchronize(int device_id) {
     KICP_HIP(hipSetDevice(device_id));
-    return wait_device(device_id, "kicp_device_synchronize");  // (the library's own streams and the null stream, with the deadline)
+    return wait_device(device_id, "kicp_device_synchronize", true);  // (the library's own streams and the null stream, with the deadline)
 }
 // Host self-test: the staging path's float64 -> float32 narrowing (AVX2 or scalar, as the staging threads run it).
 // *exact = 1 iff every value survives the round trip -- the only case in which a scan is uploaded as float32.

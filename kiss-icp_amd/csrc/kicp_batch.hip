@@ -72,7 +72,10 @@ struct HipPipe {
     int get(void *host, size_t bytes) {
         int rc = hip(hipMemcpyAsync(h_recv, d_recv, bytes, hipMemcpyDeviceToHost, xchg), "hipMemcpyAsync(recv)");
         if (rc != KICP_OK) return rc;
-        if ((rc = wait_stream(xchg, "pose exchange")) != KICP_OK) {  // (bounded: a peer that never joins the collective must not hang this rank's host)
+        // (bounded, by the deadline of everything that waits for peers: one that never joins the collective must not hang this rank's
+        // host.  Past it the collective and the copy STAY queued on xchg, over d_send / h_recv: the driver marks the batch broken
+        // -- kicp_batch.hpp, post_all -- so that no later sync reuses them one exchange out of step with the peers.)
+        if ((rc = wait_stream_peers(xchg, "pose exchange")) != KICP_OK) {
             err = kicp_last_error();
             return rc;
         }
@@ -91,7 +94,7 @@ struct HipPipe {
             if (h_send) (void)hipHostFree(h_send);
             if (h_recv) (void)hipHostFree(h_recv);
         }
-        if (xchg) (void)stream_destroy(xchg);
+        if (xchg && gone) (void)stream_destroy(xchg);  // (not gone: leaked with its buffers -- a second full wait would follow)
         d_send = d_recv = nullptr;
         h_send = h_recv = nullptr;
         xchg = nullptr;

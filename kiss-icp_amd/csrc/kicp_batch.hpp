@@ -248,6 +248,9 @@ private:
                 rc = w.rc;
                 error_ = "stream " + std::to_string(first_rank_ + w.index) + ": " + w.err;
             }
+            // an exchange the worker itself gave up (a collective on its stream that did not end in time) is still queued over
+            // the worker's buffers: reusing them would put this rank one exchange out of step with its peers
+            if (c == Cmd::Gather && w.rc == KICP_ERR_TIMEOUT) broken_ = true;
         }
         return rc;
     }

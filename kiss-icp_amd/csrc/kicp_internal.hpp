@@ -368,8 +368,9 @@ Options &options();
 // behind such a wait, over every stream the library has created on the device; when that wait gives up the resource is
 // leaked, not freed -- a leak can be lived with, a process that never returns cannot.
 int wait_stream(hipStream_t s, const char *what);
+int wait_stream_peers(hipStream_t s, const char *what);  // the same under collective_timeout_ms: work that waits for other ranks
 int wait_event(hipEvent_t e, const char *what, bool relaxed = false);
-int wait_device(int device_id, const char *what);  // every stream libkicp has created on the device
+int wait_device(int device_id, const char *what, bool null_stream = false);  // what is queued NOW on every stream libkicp has on the device (a snapshot, like hipFree's own wait)
 hipStream_t util_stream(int device_id);            // the library's own stream for buffer initialisation (nullptr: creation failed)
 void stream_register(int device_id, hipStream_t s);
 void stream_forget(hipStream_t s);
