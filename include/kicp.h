@@ -432,6 +432,10 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     bound threads measured the same on one GPU, 2955 against 2958 scans/s, while a thread that may run anywhere
  *                     gets out of a busy neighbour's way -- boxes are shared); 0 = nothing is looked up.  Without NUMA
  *                     information (one node, a container that hides it) nothing changes.
+ *   "staging_numa_pretend"  test hook (default -1 = off): n >= 0 declares NUMA node n to be the one every GPU hangs off, so that on a
+ *                     one-GPU box -- where the runtime's pinned allocation already lies on the GPU's real node -- level 2 of
+ *                     "staging_numa" has slots to replace: mbind + hipHostRegister + bound helpers run, and kicp_host_stats reports
+ *                     the node the replaced slots landed on (tests/test_gpu_paths.py::test_host_placement_moves_the_slots).
  *   "queue_depth"     frames an asynchronous entry keeps queued on the device before it waits for the oldest (default 4,
  *                     >= 2; 0 = no limit: the host may run ahead until the 256-frame record ring is full)
  *   "collective_timeout_ms"  kicp_batch_*: how long a step that waits for PEERS may take -- the communicator's rendezvous

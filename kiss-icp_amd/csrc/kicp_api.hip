@@ -603,6 +603,7 @@ private:
 
 // the NUMA node a device hangs off (sysfs, by its PCI address); -1: unknown, or the platform has one node
 int device_numa_node(int device) {
+    if (options().staging_numa_pretend >= 0) return (int)options().staging_numa_pretend;  // (test hook: see kicp.h)
     static std::mutex mu;
     static int cache[64];
     static bool have[64] = {false};
@@ -3038,6 +3039,9 @@ int kicp_set_option(const char *name, long value) {
     } else if (!strcmp(name, "staging_numa")) {
         if (value < 0 || value > 2) return KICP_ERR_INVALID_ARG;
         options().staging_numa = value;
+    } else if (!strcmp(name, "staging_numa_pretend")) {
+        if (value < -1 || value > 1023) return KICP_ERR_INVALID_ARG;
+        options().staging_numa_pretend = value;
     } else if (!strcmp(name, "relaxed_backpressure")) {
         options().relaxed_backpressure = value != 0;
     } else if (!strcmp(name, "collective_timeout_ms")) {

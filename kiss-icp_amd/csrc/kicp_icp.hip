@@ -1562,8 +1562,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // ---- A -------------------------------------------------------------------------------------
             if (tid < cn) {
                 const int j = base + tid;
-                const int p = KICP_IDX(m.dbg, &st->err, P.order ? key_index(P.order[q0 + j]) : q0 + j, n, 4);
                 const bool has_meta = j < n_meta;
+                // (the point's index in the cloud: only where the cloud or the work array is touched -- a global load on the path
+                // of every iteration otherwise)
+                int p = 0;
+                if (it == 0 || !has_meta) p = KICP_IDX(m.dbg, &st->err, P.order ? key_index(P.order[q0 + j]) : q0 + j, n, 4);
                 IcpQueryMeta *meta = metas + (has_meta ? j : 0);
                 double pin[3];
                 if (it > 0 && has_meta) {  // running source point lives in LDS
@@ -1586,23 +1589,21 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                              meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
                              meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
                 IcpPoint &pt = sh.pts[tid];
-                // STABILITY (IcpQueryMeta::Lr).  The query's last list scan, made from this very voxel, left its neighbour and count
-                // in this point slot (a run with lists is a single chunk: the slot is this query's through the launch) and Lr, a
-                // lower bound of the distance to every OTHER candidate of the 27 cells.  The query has moved by |s - pin| since the
-                // last iteration: every one of those candidates stays at least Lr - (all the moves since the scan) away, and while the
-                // neighbour's new distance is strictly below that it is still the unique minimum the reference's strict '<' loops
-                // would find (VoxelHashMap.cpp:55-63), with the same points examined: no search, the distance is computed here --
-                // by the expression the search uses, so the bits are the search's.
+                // STABILITY (IcpQueryMeta::L2).  The query's last search, made from this very voxel, left its neighbour and count in
+                // this point slot (a run with lists is a single chunk: the slot is this query's through the launch), the position it
+                // was made from, and the second smallest squared distance over the 27 cells.  While the neighbour's new distance
+                // plus the way from there to here stays strictly below that runner-up's distance, the neighbour is still the unique
+                // minimum the reference's strict '<' loops would find (VoxelHashMap.cpp:55-63), with the same points examined: no
+                // search, and the distance is computed here -- by the expression the search uses, so the bits are the search's.
                 bool stable = false;
                 if (use_stable && it > 0 && cached && meta->lr_state == 1 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz) {
-                    const double mx = s[0] - pin[0], my = s[1] - pin[1], mz = s[2] - pin[2];
-                    const double moved = sqrt((mx * mx + my * my) + mz * mz) * (1.0 + 0x1p-30) + DBL_MIN;  // (rounded up)
-                    const double Lr = meta->Lr - moved;
-                    meta->Lr = Lr;
                     if (pt.d2 < DBL_MAX) {  // (DBL_MAX: the 27 cells hold no candidate at all -- and never will)
+                        const double mx = s[0] - meta->ss[0], my = s[1] - meta->ss[1], mz = s[2] - meta->ss[2];
+                        const double b2 = (mx * mx + my * my) + mz * mz;
                         const double ex = pt.nn[0] - s[0], ey = pt.nn[1] - s[1], ez = pt.nn[2] - s[2];
                         const double dp = (ex * ex + ey * ey) + ez * ez;  // (as the search computes it)
-                        stable = sqrt(dp) * (1.0 + 0x1p-30) < Lr;
+                        const double R = (meta->L2 - dp) - b2;
+                        stable = R > 0.0 && (4.0 * (1.0 + 0x1p-20)) * (dp * b2) < R * R;
                         if (stable) pt.d2 = dp;
                     } else {
                         stable = true;
@@ -1669,6 +1670,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // serves a point has no influence on the result (phase C adds in point order).
             const unsigned tb0 = PROF ? ticks32() : 0u;
             const int n_search = sh.search_count;  // (filed before the barrier behind phase A; reset behind the one that ends this phase)
+            if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0) {
+                // every group's record of this iteration starts as "no search" (path 5; the workgroup's searches in the examined
+                // field): a group that serves a point overwrites it below
+                unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) + (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
+                r[0] = (unsigned)(tb0 - c0);
+                r[1] = (unsigned)min(t_fill, 0xFFFFu);
+                r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)min(n_search, 0xFFFF) << 16);
+                prof_path = 5u;
+            }
             for (int e = grp; e < n_search;) {
                 const int t = (int)sh.search_idx[e];
                 IcpPoint &pt = sh.pts[t];
@@ -1686,6 +1696,9 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 bool tie = false;  // the fast search's answer may not be the reference's: a tie in NORM (kicp_search.hpp) -- settled below
                 if (flag == 0 && !listed && use_lists && meta->list_state >= 0) {
                     // the scan list belongs to the voxel the query was in when it was built
+                    // (Round 6 tried NOT rebuilding the list of a query that has entered another voxel -- with the stability shortcut it
+                    // is searched once there, as a rule -- and sending it through the lane-per-voxel search instead: that search
+                    // is 5 us where build + list scan are 3.4, on the critical path of the iteration: profiles/r06_d_ab_*.txt.)
                     if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz)
                         tile_list_build(tile, vx, vy, vz, lane, meta);
                     if (meta->list_state == 1) {
@@ -1696,19 +1709,35 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         path = 1;
                         // (a tie in norm is settled by the exact search below: its neighbour has no margin worth keeping)
                         if (use_stable && lane == 0 && !tie) {
-                            meta->Lr = sqrt(sec2) * (1.0 - 0x1p-30);
+                            meta->L2 = sec2 * (1.0 - 0x1p-20);
+                            meta->ss[0] = s[0];
+                            meta->ss[1] = s[1];
+                            meta->ss[2] = s[2];
                             meta->lr_state = 1;
                         }
                     }
                 }
                 if (flag == 0 && !listed) {
                     int bad;
-                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, &tie);
+                    double sec2 = DBL_MAX;
+                    d2 = tile_scan(m, tile, s[0], s[1], s[2], vx, vy, vz, lane, nn, E, bad, &tie, use_stable, &sec2);
                     if (bad) {  // 2: a voxel of this query did not fit into the tile -> HBM from now on; 1: one is
                                 // being fetched by another group this very moment -> HBM this once
                         if (bad == 2 && lane == 0) meta->valid = -1;
                         flag = 2;
                         path = 3;
+                    } else if (use_stable && lane == 0 && !tie) {
+                        // (a query without a scan list -- the pool was full, a voxel of it lives in the map -- walks all 27 cells
+                        // here: its runner-up bounds everything but the neighbour just as a list's does.  lv: the voxel the bound
+                        // belongs to; a query that cannot have a list does not use it otherwise, one that can has it set already.)
+                        meta->L2 = sec2 * (1.0 - 0x1p-20);
+                        meta->ss[0] = s[0];
+                        meta->ss[1] = s[1];
+                        meta->ss[2] = s[2];
+                        meta->lv[0] = vx;
+                        meta->lv[1] = vy;
+                        meta->lv[2] = vz;
+                        meta->lr_state = 1;
                     }
                 }
                 if (flag != 0) {

@@ -219,7 +219,7 @@ constexpr int kIcpLdsBytesMax = 160 * 1024;  // one workgroup per CU owns the wh
 constexpr int kIcpChunk = 128;     // local points a workgroup carries through the phases of an iteration at a time
 constexpr int kIcpTermChunk = 64;  // points whose products are in LDS together (a multiple of the group count)
 constexpr int kIcpTerms = 18;      // 16 normal-equation scalars + correspondence count + examined count
-constexpr int kIcpMaxMeta = 448;   // local points of a workgroup that may use the workgroup's voxel tile (80 bytes each)
+constexpr int kIcpMaxMeta = 448;   // local points of a workgroup that may use the workgroup's voxel tile (112 bytes each)
 constexpr int kIcpTileSlots = 4096;  // slots of the workgroup's voxel table (occupied voxels only; power of two)
 constexpr int kIcpListRunMax = 64;   // workgroups that serve at most this many points keep a scan list per point
 constexpr int kIcpWeightedMin = 2048;  // source clouds of at least this many points are cut into runs of equal weight
@@ -236,15 +236,19 @@ struct IcpQueryMeta {
     int lv[3];               // voxel of the query the scan list was built for
     int list_base;           // first entry of the list in the pool
     unsigned short list_n, list_cap;
-    // STABILITY (option icp_group_stable; the thread-per-query form's WideQuery::Lr, kicp_icp_wide.hpp): a lower bound -- a
-    // distance, shaved by 2^-30 -- of the distance from the query to every candidate of its scan list EXCEPT the neighbour the
-    // last list scan found, less the way the query has moved since.  While the query stays in voxel lv and the neighbour's new
-    // distance is strictly below it, the neighbour is still what the reference's strict '<' loops would find: no search.
-    double Lr;
-    int lr_state;  // 1: Lr, and the neighbour / count kept in the workgroup's point slot, belong to voxel lv
-    int pad;
+    // STABILITY (option icp_group_stable; the thread-per-query form's WideQuery::Lr, kicp_icp_wide.hpp).  The last full search,
+    // made from position ss in voxel lv, left L2: the SECOND smallest squared distance over all candidates of the 27 cells
+    // (shaved by 2^-20), i.e. every candidate but the neighbour found was at least sqrt(L2) from ss.  The query is now at s:
+    // those candidates are at least sqrt(L2) - |s - ss| away (triangle inequality), and while the neighbour's new distance is
+    // strictly below that -- tested on the squares, no root: with a = |nn - s|^2, b = |s - ss|^2, R = L2 - a - b the
+    // condition sqrt(a) + sqrt(b) < sqrt(L2) is R > 0 and 4 a b < R^2 -- and the query is still in voxel lv (same 27 cells, same
+    // candidates), the neighbour is still what the reference's strict '<' loops would find: no search.
+    double L2;
+    double ss[3];
+    int lr_state;  // 1: L2 / ss, and the neighbour / count kept in the workgroup's point slot, belong to voxel lv
+    int pad[3];
 };
-static_assert(sizeof(IcpQueryMeta) == 80, "IcpQueryMeta layout");
+static_assert(sizeof(IcpQueryMeta) == 112 && sizeof(IcpQueryMeta) % 16 == 0, "IcpQueryMeta layout");
 
 struct IcpParams {
     const double *frame;  // N x 3 source points in the sensor frame
@@ -341,6 +345,7 @@ struct Options {
     long staging_f32 = 1;        // narrow float64 scans to float32 for the upload when that is lossless
     long staging_zero_copy = 1;  // the front kernels read the scan straight from the pinned staging slot (no upload call)
     long stage_in = 1;           // ... unless the frame deskews: then a copy kernel brings the scan into HBM under the previous registration
+    long staging_numa_pretend = -1;  // test hook: >= 0 = the node every GPU is declared to hang off (so that "staging_numa" = 2 has something to move on a one-GPU box)
     long staging_numa = 1;       // 1: where the staging slots lie is checked and reported (kicp_numa.hpp); 2: slots on another node than the GPU's are re-made on it, helper threads and batch workers run on its CPUs; 0: nothing
     long relaxed_backpressure = 1;  // a caller that is queue_depth frames ahead of the device sleeps between polls instead of yielding in a loop
     long collective_timeout_ms = 1800000;  // kicp_batch_*: a step that waits for PEERS (communicator rendezvous, pose all-gather through a host communicator) is given up after this long; 0 = never

@@ -755,10 +755,16 @@ __device__ __forceinline__ bool tile_fill(const MapView &m, const Tile &tile, co
 // voxel (max_points_per_voxel steps), not by the size of the neighbourhood.
 // Returns the squared distance (DBL_MAX: no candidate), the neighbour, the number of points examined;
 // bad = the tile cannot answer: 1 a voxel is still being fetched by a concurrent fill, 2 one did not fit.
+// second (want_second): the second smallest squared distance over all 27 cells, as tile_scan_list returns it (the stability test's
+// bound, IcpQueryMeta::Lr) -- every cell is walked here, so the runner-up of what was met IS the runner-up of the neighbourhood.
 __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, double sx, double sy, double sz, int vx, int vy, int vz,
-                                            int lane, double nn[3], int &examined, int &bad, bool *tie = nullptr) {
+                                            int lane, double nn[3], int &examined, int &bad, bool *tie = nullptr, bool want_second = false,
+                                            double *second = nullptr) {
     constexpr int U = 4;
-    double prev = DBL_MAX;  // the smallest squared distance this lane has met and not kept (kNormTie: it may have the best's norm and come first)
+    // the smallest squared distance this lane has met and not kept: its runner-up.  (The norm-tie detection needs less -- only a
+    // candidate that came BEFORE the best can have the best's norm and lose -- but the full runner-up costs one more minimum per
+    // candidate and flags a superset of the ties: re-searched exactly, once in 1e10.)
+    double prev = DBL_MAX;
     int ref = 0, cnt = 0;
     int mybad = 0;
     bool glob = false;
@@ -811,8 +817,10 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
             for (int u = 0; u < U; ++u) {
                 const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
                 const double d = (ex * ex + ey * ey) + ez * ez;
-                const bool take = (k0 + u < c) & (d < best);
-                prev = take ? best : prev;
+                const bool in = k0 + u < c;
+                const bool take = in & (d < best);
+                const double loser = take ? best : d;  // (what is not the best after this point)
+                prev = (in & (loser < prev)) ? loser : prev;
                 best = take ? d : best;
                 bk = take ? k0 + u : bk;
             }
@@ -854,25 +862,35 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
                 const double d = (ex * ex + ey * ey) + ez * ez;
                 const int k = (kj[u] << 5) | lane;  // {shift position of the voxel, index inside it}
                 if (d < best || (d == best && k < key)) {
-                    prev = (d < best && best < prev) ? best : prev;
+                    prev = best < prev ? best : prev;
                     best = d;
                     key = k;
                     bx = xy[u].x;
                     by = xy[u].y;
                     bz = zz[u];
-                } else if (k < key && d < prev) {
-                    prev = d;  // (it comes before the best in the reference's order: if its norm is the best's, it should have won)
+                } else if (d < prev) {
+                    prev = d;
                 }
             }
         }
     }
     if (best == DBL_MAX) key = 0x7FFFFFFF;
     const int mykey = key;
+    const double mybest = best;
     group_min_dist_key(best, key, prev, tie);
     const bool found = key != 0x7FFFFFFF;
     // the lane that holds the winner hands its coordinates to the group
     const unsigned who = (unsigned)(__ballot(found && mykey == key) >> half_shift);
     const int wl = who ? (__ffs(who) - 1) : 0;
+    if (want_second) {
+        double g2 = (found && lane == wl) ? prev : mybest;
+        group_fmin_step<0>(g2);
+        group_fmin_step<1>(g2);
+        group_fmin_step<2>(g2);
+        group_fmin_step<3>(g2);
+        group_fmin_step<4>(g2);
+        *second = g2;
+    }
     nn[0] = __shfl(bx, wl, 32);
     nn[1] = __shfl(by, wl, 32);
     nn[2] = __shfl(bz, wl, 32);

@@ -29,6 +29,15 @@ for i, r in enumerate(prof):
     print('%3d %6.2f %6.2f %6.2f %6.2f | %6.2f %4d' % (i, r[0] / 100, r[1] / 100, r[2] / 100, r[3] / 100, r[4] / 100, r[5]))
 
 gp = k.icp_group_profile()
+if gp.size and not livox:
+    # group form: which groups searched at all (path 5 = none: every point of the group's workgroup kept its neighbour, or the
+    # other groups took the few that did not; its "examined" field then carries the workgroup's number of searches)
+    print(' it  groups searching  workgroups with a search  most searches in one workgroup')
+    for it in range(gp.shape[0]):
+        g = gp[it].reshape(-1, 16, gp.shape[2])
+        idle = g[:, :, 6] == 5
+        per_wg = np.where(idle.any(axis=1), np.where(idle, g[:, :, 5], 0).max(axis=1), 16)  # (16: every group searched: at least that many)
+        print('%3d %8d %18d %22d' % (it, int((~idle).sum()), int(((~idle).any(axis=1)).sum()), int(per_wg.max())))
 if gp.size:
     names = ('wait-in', 'xform', 'fill', 'scan')
     for it in (0, 1, min(6, gp.shape[0] - 1), gp.shape[0] - 1):

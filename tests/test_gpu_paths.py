@@ -938,6 +938,47 @@ def test_host_placement_levels(gpu):
     assert np.array_equal(poses[0], poses[1]) and np.array_equal(poses[1], poses[2])
 
 
+def test_host_placement_moves_the_slots(gpu):
+    """"staging_numa" = 2 on a device: the re-placement branch (mbind + hipHostRegister of node-bound pages, helper threads bound to
+    the node) never ran on the one-GPU boxes, where the runtime's pinned slots already lie on the GPU's node.  The test hook
+    "staging_numa_pretend" declares ANOTHER node to be the GPU's: the slots must then be re-made there (kicp_host_stats reports
+    the node their first page landed on), the helpers run bound, and the poses stay bit for bit those of the default placement.
+    Skipped where the platform shows one node or hides the topology; reported as skipped, not passed, where the container
+    refuses mbind."""
+    import os
+
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+
+    ds = kitti_like(seed=6, n_frames=4, beams=32, azimuth_steps=512)
+    k = _pipe(deskew=False)
+    for i in range(4):
+        k.register_frame(*ds[i])
+    ref, h0 = k.last_pose.copy(), k.host_stats()
+    del k
+    real = h0["staging_numa_node"]
+    nodes = [n for n in range(8) if os.path.isdir("/sys/devices/system/node/node%d" % n)]
+    if real < 0 or len(nodes) < 2:
+        pytest.skip("one NUMA node, or the topology is hidden: nothing to move (%s)" % h0)
+    other = [n for n in nodes if n != real][0]
+    try:
+        _cabi.set_option("staging_numa_pretend", other)
+        _cabi.set_option("staging_numa", 2)
+        k = _pipe(deskew=False)
+        for i in range(4):
+            k.register_frame(*ds[i])
+        h = k.host_stats()
+        assert np.array_equal(k.last_pose, ref)
+        assert h["device_numa_node"] == other, h
+        if h["staging_numa_node"] != other:
+            pytest.skip("the re-placement was refused here (mbind / hipHostRegister): slots stayed on node %d (%s)" % (h["staging_numa_node"], h))
+        assert h["helpers_bound"] == h["staging_helpers"], h
+        del k
+    finally:
+        _cabi.set_option("staging_numa_pretend", -1)
+        _cabi.set_option("staging_numa", 1)
+
+
 def test_slot_array_rebuilt_in_stream_order(gpu, O):
     """a moving sensor fills the map's slot array with tombstones; the pipeline drops them by rebuilding the array IN
     STREAM ORDER, frames queued before and behind it, without the host waiting for anything.  Forced here every 7 frames

@@ -147,6 +147,52 @@ def test_a_kept_neighbour_is_the_one_a_search_would_find():
     assert kept > 2000 and searched > 500, (kept, searched)
 
 
+def test_group_form_keeps_a_neighbour_only_when_a_search_would_find_it():
+    """the group form's test (IcpQueryMeta::L2, kicp_icp.hip phase A): no roots -- with a = |nn - s|^2, b = |s - ss|^2 (ss: where the
+    last search was made), L2 = the search's second smallest squared distance shaved by 2^-20, R = (L2 - a) - b, the neighbour is
+    kept iff R > 0 and 4 (1 + 2^-20) a b < R^2, i.e. sqrt(a) + sqrt(b) < sqrt(L2).  Whenever it says "keep", the reference's walk
+    must return that very point with that very distance -- near-ties down to 1e-15 included; the norms of all other points must
+    also be strictly larger than the neighbour's (the reference compares norms: no tie in norm can hide behind a kept neighbour)."""
+    rng = np.random.default_rng(11)
+    kept = searched = 0
+    for trial in range(1500):
+        vs = rng.choice([0.1, 0.5, 1.0])
+        v = np.floor(rng.uniform(-300, 300, 3))
+        s = (v + rng.uniform(0.05, 0.95, 3)) * vs
+        if not np.array_equal(voxel_coord(s, vs), v):
+            continue
+        n = int(rng.integers(2, 40))
+        pts = (v + rng.uniform(-1.0, 2.0, (n, 3))) * vs
+        if trial % 3 == 0:
+            i0 = int(np.argmin(((pts - s) ** 2).sum(axis=1)))
+            pts = np.vstack([pts, s + (pts[i0] - s) * (1.0 + rng.choice([1e-15, 1e-12, 1e-9, 1e-6, 1e-3])) * rng.choice([1.0, -1.0])])
+        order = rng.permutation(len(pts))
+
+        def search(at):
+            nn, _ = _reference_search(pts, order, at)
+            second = min(dist2(pts[i], at) for i in range(len(pts)) if i != nn)
+            return nn, second * (1.0 - 2.0 ** -20), at.copy()
+
+        nn, L2, ss = search(s)
+        for step in range(12):
+            s = s + rng.normal(0.0, 1.0, 3) * vs * 10.0 ** rng.uniform(-6, -1.3)
+            if not np.array_equal(voxel_coord(s, vs), v):
+                break
+            m = s - ss
+            b2 = (m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]
+            dp = dist2(pts[nn], s)
+            R = (L2 - dp) - b2
+            if R > 0.0 and (4.0 * (1.0 + 2.0 ** -20)) * (dp * b2) < R * R:
+                got, d = _reference_search(pts, order, s)
+                assert got == nn and d == dp, (trial, step)
+                assert all(np.sqrt(dist2(pts[i], s)) > np.sqrt(dp) for i in range(len(pts)) if i != nn), (trial, step)
+                kept += 1
+            else:
+                nn, L2, ss = search(s)
+                searched += 1
+    assert kept > 2000 and searched > 500, (kept, searched)
+
+
 def test_flat_service_settles_an_item_like_the_references_walk():
     """wide_serve_flat: unsigned minimum of the distance's bit pattern, then the smallest index among the points at the minimum,
     the others' distances into the runner-up -- against the plain walk, with exact ties"""
