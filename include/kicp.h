@@ -513,6 +513,13 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     long (0 .. 60000; consumed by the first taker) -- the dependency that is not signalled in time
  *                     (tests/test_gpu_deadlines.py)
  *   "map_apply_threads"  workgroup size of the AddPoints apply kernel: 256, 512 (default) or 1024
+ *   "sort_by_rank"    1 (default) = a source cloud of a few thousand points (judged by the previous frame's count: up to ~6.5 k) gets
+ *                     its spatial order for the registration's workgroups in ONE launch, every key placed by its rank among all;
+ *                     0 = always sorted runs + merge passes.  The same order either way (the keys are unique)
+ *   "map_fused_update"  1 (default) = local_map_.Update (KissICP.cpp:61; VoxelHashMap.cpp:83-132) is two kernels: the verdicts of
+ *                     RemovePointsFarFromLocation are taken beside AddPoints' first kernel and carried out by its second (a
+ *                     sentenced voxel receives nothing and goes, a created one is judged by its first point); 0 = a third
+ *                     kernel behind them.  The same map either way, voxel for voxel, point for point.  Also kicp_map_update_*
  *   "icp_profile"     1 = launch the ICP kernel variant that records the in-kernel phase timers read
  *                     by kicp_pipeline_icp_profile / _icp_iteration_profile (default 0)
  * ---------------------------------------------------------------------------------------- */

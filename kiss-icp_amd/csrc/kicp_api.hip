@@ -676,6 +676,9 @@ using namespace kicp;
 // ==============================================================================================
 // kicp_map
 // ==============================================================================================
+// behind the map counters and the PipeState: the first-level sign-off words of a frame's last kernel (idle = 0: each is
+// reset by the workgroup that completes it)
+static constexpr size_t kDoneSubOffset = ((sizeof(int) * C_COUNT + sizeof(PipeState) + 127) / 128) * 128;
 MapView kicp_map::view() const {
     MapView v;
     v.slots = slots.as<Slot>();
@@ -687,6 +690,8 @@ MapView kicp_map::view() const {
     v.ctr = ctr.as<int>();
     v.free_ids = free_ids.as<int>();
     v.free_cap = blocks_cap;
+    v.doomed = doomed.as<int>();
+    v.done_sub = reinterpret_cast<int *>(ctr.as<char>() + kDoneSubOffset);
     v.heads = heads.as<int>();
     v.z_off = kBlockHeader + 16 * (int)max_points;
     v.voxel_size = voxel_size;
@@ -715,6 +720,7 @@ int kicp_map::scratch_reserve(size_t n_max, InsertScratch &sc) {
     KICP_TRY(world.reserve(n_max * 3 * sizeof(double)));
     KICP_TRY(next.reserve(n_max * sizeof(int)));
     KICP_TRY(rec_slot.reserve(n_max * sizeof(int)));
+    KICP_TRY(rec_block.reserve(n_max * sizeof(int)));
     KICP_TRY(rec_list.reserve(n_max * kRecList * sizeof(int)));
     // idle state of a record: count 0, head -1 (every insert leaves its records idle again)
     if (rec_count.bytes < n_max * sizeof(int)) {
@@ -728,6 +734,7 @@ int kicp_map::scratch_reserve(size_t n_max, InsertScratch &sc) {
     sc.world = world.as<double>();
     sc.next = next.as<int>();
     sc.rec_slot = rec_slot.as<int>();
+    sc.rec_block = rec_block.as<int>();
     sc.rec_count = rec_count.as<int>();
     sc.rec_head = rec_head.as<int>();
     sc.rec_list = rec_list.as<int>();
@@ -816,6 +823,7 @@ int kicp_map::ensure_capacity(size_t incoming) {
             KICP_HIP(hipMemcpy(old_ring.data(), free_ids.p, (size_t)blocks_cap * sizeof(int), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < count; ++i) lin[i] = old_ring[(head + (unsigned)i) % (unsigned)blocks_cap];
             KICP_TRY(free_ids.reserve(want * sizeof(int)));
+            KICP_TRY(doomed.reserve(want * sizeof(int)));  // (a list per frame: nothing to keep)
             if (count) KICP_HIP(hipMemcpyAsync(free_ids.p, lin.data(), count * sizeof(int), hipMemcpyHostToDevice, stream));
             const int cur[3] = {0, (int)count, (int)count};
             KICP_HIP(hipMemcpyAsync(ctr.as<int>() + C_FHEAD, &cur[0], sizeof(int), hipMemcpyHostToDevice, stream));
@@ -837,7 +845,8 @@ static int map_alloc(kicp_map *m) {
     KICP_HIP(hipMemsetAsync(m->heads.p, 0xFF, (size_t)m->slot_cap * sizeof(int), m->stream));
     KICP_TRY(m->blocks.reserve((size_t)m->blocks_cap * m->stride + 64));
     KICP_TRY(m->free_ids.reserve((size_t)m->blocks_cap * sizeof(int)));
-    KICP_TRY(m->ctr.reserve(sizeof(int) * C_COUNT + sizeof(PipeState)));
+    KICP_TRY(m->doomed.reserve((size_t)m->blocks_cap * sizeof(int)));
+    KICP_TRY(m->ctr.reserve(kDoneSubOffset + sizeof(int) * kCtrStride * kDoneSub));
     KICP_HIP(hipMemsetAsync(m->slots.p, 0xFF, (size_t)m->slot_cap * sizeof(Slot), m->stream));
     KICP_HIP(hipMemsetAsync(m->blocks.p, 0, m->blocks.bytes, m->stream));
     KICP_HIP(hipMemsetAsync(m->ctr.p, 0, m->ctr.bytes, m->stream));
@@ -900,7 +909,7 @@ int kicp_map_destroy(kicp_map *m) {
     // (one bounded wait for everything the map owns; a device that does not answer keeps the memory)
     int idle = wait_stream(m->stream, "map teardown");
     if (idle == KICP_OK) idle = wait_device(m->device, "map teardown");
-    for (DevBuf *b : {&m->slots, &m->heads, &m->blocks, &m->free_ids, &m->ctr, &m->pts_in, &m->world, &m->next, &m->rec_slot, &m->rec_count,
+    for (DevBuf *b : {&m->slots, &m->heads, &m->blocks, &m->free_ids, &m->doomed, &m->ctr, &m->pts_in, &m->world, &m->next, &m->rec_slot, &m->rec_block, &m->rec_count,
                       &m->rec_head, &m->rec_list})
         b->drop(idle == KICP_OK);
     if (m->own_stream && m->stream) {
@@ -932,6 +941,7 @@ int kicp_map_clone(const kicp_map *csrc, kicp_map **out) {
     copy(m->heads, src->heads);
     copy(m->blocks, src->blocks);
     copy(m->free_ids, src->free_ids);
+    copy(m->doomed, src->doomed);  // (for its size: the list is per frame)
     copy(m->ctr, src->ctr);
     if (s == KICP_OK) s = wait_stream(m->stream, "map copy");
     if (s != KICP_OK) {
@@ -988,16 +998,27 @@ int kicp_map_size(const kicp_map *cm, size_t *n_voxels, size_t *n_points) {
     return KICP_OK;
 }
 
+// AddPoints on points already in HBM.  origin / origin_state (one of them, or neither): RemovePointsFarFromLocation around that
+// point rides along -- the fused update of kicp_map.hip ("map_fused_update"; an insert of no points has nothing to ride on)
 static int map_insert_device(kicp_map *m, const double *d_in, const int *n_ptr, int n_imm,
-                             size_t n_max, const PipeState *state, int use_pose) {
-    // AddPoints on points already in HBM (shared by the standalone calls and the pipeline)
+                             size_t n_max, const PipeState *state, int use_pose, const double *origin = nullptr,
+                             const PipeState *origin_state = nullptr) {
     if (n_max == 0) return KICP_OK;
     KICP_TRY(m->ensure_capacity(n_max));
     InsertScratch sc;
     KICP_TRY(m->scratch_reserve(n_max, sc));
     const MapView v = m->view();
-    launch_map_link(v, sc, d_in, n_ptr, n_imm, (int)n_max, state, use_pose, m->stream);
-    launch_map_apply(v, sc, (int)n_max, m->stream);
+    MapPrune mp;
+    memset(&mp, 0, sizeof mp);
+    const bool fused = origin || origin_state;
+    if (fused) {
+        mp.bump_ub = m->bump_ub;
+        mp.state = origin_state;
+        mp.use_state_origin = origin_state ? 1 : 0;
+        for (int k = 0; k < 3; ++k) mp.origin[k] = origin ? origin[k] : 0.0;
+    }
+    launch_map_link(v, sc, d_in, n_ptr, n_imm, (int)n_max, state, use_pose, m->stream, fused ? &mp : nullptr);
+    launch_map_apply(v, sc, (int)n_max, m->stream, fused ? &mp : nullptr);
     KICP_HIP(hipGetLastError());
     m->used_ub += (long)n_max;
     m->live_ub += (long)n_max;
@@ -1038,8 +1059,9 @@ int kicp_map_update_origin(kicp_map *m, const double *xyz, size_t n, const doubl
     if (!m || (!xyz && n) || !origin) return KICP_ERR_INVALID_ARG;
     KICP_HIP(hipSetDevice(m->device));
     KICP_TRY(map_upload(m, xyz, n));
-    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, nullptr, 0));
-    launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, 0, m->stream);
+    const bool fused = options().map_fused_update != 0 && n > 0;
+    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, nullptr, 0, fused ? origin : nullptr));
+    if (!fused) launch_map_prune(m->view(), m->bump_ub, nullptr, 0, origin, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -1055,8 +1077,9 @@ int kicp_map_update_pose(kicp_map *m, const double *xyz, size_t n, const double 
     PipeState *ms = map_mini_state(m);
     KICP_HIP(hipMemcpyAsync(&ms->new_pose, &T, sizeof T, hipMemcpyHostToDevice, m->stream));
     KICP_TRY(map_upload(m, xyz, n));
-    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, ms, 1));
-    launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, 0, m->stream);
+    const bool fused = options().map_fused_update != 0 && n > 0;
+    KICP_TRY(map_insert_device(m, m->pts_in.as<double>(), nullptr, (int)n, n, ms, 1, nullptr, fused ? ms : nullptr));
+    if (!fused) launch_map_prune(m->view(), m->bump_ub, ms, 1, nullptr, nullptr, 0, m->stream);
     KICP_HIP(hipGetLastError());
     return m->check_errors();
 }
@@ -1958,6 +1981,16 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     D2.n_out = &prep->n_src;
     D2.err = &st->err;
     D2.dbg = kDebugBounds ? bounds_rec(p->device) : nullptr;
+    // --- spatial order of the source cloud: the ICP kernel hands every workgroup a compact patch of it ----
+    // (how many points there will be is known on the device only; the previous frame's count says how to sort: a small cloud
+    // by rank in one launch, its keys written beside it by the scatter that emits it)
+    const bool sorted = n <= ((size_t)1 << 24);
+    const size_t sort_hint = p->have_last ? (size_t)p->last.st.n_src : n / 8;
+    const bool keys_ready = sorted && n && tile_sort_by_rank(n, sort_hint);
+    if (keys_ready) {
+        D2.sort_keys = p->sort_in.as<unsigned long long>();
+        D2.sort_inv_cell = tile_sort_inv_cell(c.voxel_size);
+    }
     if (p->ds_order) {  // the reference's output order: arrange the grid's clusters, then compact bucket by bucket
         launch_ds_arrange(D1, sp);
         launch_ds_scatter_rb(D1, sp);
@@ -1970,12 +2003,9 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         launch_ds_scatter(D2, sp);
     }
     KICP_HIP(hipGetLastError());
-    // --- spatial order of the source cloud: the ICP kernel hands every workgroup a compact patch of it ----
-    const bool sorted = n <= ((size_t)1 << 24);
     if (sorted && n) {
-        // (how many points there will be is known on the device only; the previous frame's count says how to merge the sorted runs)
         const int se = launch_tile_sort(p->src[par].as<double>(), &prep->n_src, 0, n, c.voxel_size, p->sort_in.as<unsigned long long>(),
-                                        p->sort_out[par].as<unsigned long long>(), p->have_last ? (size_t)p->last.st.n_src : n / 8, sp);
+                                        p->sort_out[par].as<unsigned long long>(), sort_hint, sp, keys_ready);
         if (se != 0) {
             set_error("device sort of the source cloud failed (%s)", hipGetErrorString((hipError_t)se));
             return KICP_ERR_HIP;
@@ -2049,16 +2079,24 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     InsertScratch sc;
     KICP_TRY(m->scratch_reserve(p->cap_points, sc));
     const MapView v = m->view();
-    launch_map_link(v, sc, fd, &prep->n_fd, 0, n_i, st, 1, s);
-    launch_map_apply(v, sc, n_i, s);
+    // (RemovePointsFarFromLocation rides in the two kernels of AddPoints -- "map_fused_update" --, or follows as a third)
+    FrameRecord *rec = p->ring + slot;
+    rec->n_raw = n;
+    MapPrune mp;
+    memset(&mp, 0, sizeof mp);
+    mp.bump_ub = m->bump_ub;
+    mp.state = st;
+    mp.use_state_origin = 1;
+    mp.host_rec = reinterpret_cast<unsigned *>(rec);  // the frame record, written by the frame's last kernel itself into the pinned host ring
+    mp.rec_words = kRecWords;
+    const bool fused = options().map_fused_update != 0;
+    launch_map_link(v, sc, fd, &prep->n_fd, 0, n_i, st, 1, s, fused ? &mp : nullptr);
+    launch_map_apply(v, sc, n_i, s, fused ? &mp : nullptr, fused && p->ext_events ? p->ev_done[slot] : nullptr);
     m->used_ub += (long)n;
     m->live_ub += (long)n;
     m->bump_ub += (long)n;
     if (m->bump_ub > m->blocks_cap) m->bump_ub = m->blocks_cap;
-    // --- ... and the frame record, written by the kernel itself into the pinned host ring ---------
-    FrameRecord *rec = p->ring + slot;
-    rec->n_raw = n;
-    launch_map_prune(v, m->bump_ub, st, 1, nullptr, reinterpret_cast<unsigned *>(rec), kRecWords, s, p->ext_events ? p->ev_done[slot] : nullptr);
+    if (!fused) launch_map_prune(v, m->bump_ub, st, 1, nullptr, mp.host_rec, kRecWords, s, p->ext_events ? p->ev_done[slot] : nullptr);
     KICP_HIP(hipGetLastError());
     p->in_flight++;
     p->frames_enqueued++;
@@ -2334,7 +2372,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     p->pool = nullptr;
     if (p->map) {  // (the map lives on the pipeline's stream: the wait above was its wait too)
         kicp_map *m = p->map;
-        for (DevBuf *b : {&m->slots, &m->heads, &m->blocks, &m->free_ids, &m->ctr, &m->pts_in, &m->world, &m->next, &m->rec_slot, &m->rec_count,
+        for (DevBuf *b : {&m->slots, &m->heads, &m->blocks, &m->free_ids, &m->doomed, &m->ctr, &m->pts_in, &m->world, &m->next, &m->rec_slot, &m->rec_block, &m->rec_count,
                           &m->rec_head, &m->rec_list})
             b->drop(gone);
         delete m;
@@ -2995,6 +3033,10 @@ int kicp_set_option(const char *name, long value) {
         options().icp_wide_stable = value != 0;
     } else if (!strcmp(name, "icp_group_stable")) {
         options().icp_group_stable = value != 0;
+    } else if (!strcmp(name, "sort_by_rank")) {
+        options().sort_by_rank = value != 0;
+    } else if (!strcmp(name, "map_fused_update")) {
+        options().map_fused_update = value != 0;
     } else if (!strcmp(name, "icp_wide_per_round")) {
         if (value < 1 || value > 27) return KICP_ERR_INVALID_ARG;
         options().icp_wide_per_round = value;

@@ -46,7 +46,11 @@ struct BlockHdr {
     unsigned long long key;
     int count;
     int slot;
+    int doom;  // fused map update (k_map_link / k_map_apply with a doomed list): 0 = stays, 1 = sentenced by this frame's
+               // verdict pass and not yet removed, 2 = removed (a block on the free ring); reset when the block is handed out
+    int pad[3];
 };
+static_assert(sizeof(BlockHdr) == kBlockHeader, "the block header fills the bytes in front of the first point");
 
 // Every counter sits in a 128-byte line of its own: the hot ones are bumped by one lane per workgroup of k_map_apply /
 // k_map_prune (returning atomics, ~12 ns each where the line lives), and three of them in ONE line made 625 workgroups
@@ -65,9 +69,13 @@ enum MapCtr {
     C_FTAIL = 9 * kCtrStride,     // free-block queue: end of the entries an insert may pop
     C_FPEND = 10 * kCtrStride,    // free-block queue: push cursor of RemovePointsFarFromLocation (merged into
                                   //   C_FTAIL by the next k_map_link)
-    C_DONE = 11 * kCtrStride,     // workgroups of k_map_prune that have finished (the last one writes the frame record)
-    C_COUNT = 12 * kCtrStride
+    C_DONE = 11 * kCtrStride,     // workgroups of a frame's last kernel that have finished (the last one writes the frame record)
+    C_DOOMED0 = 12 * kCtrStride,  // fused map update: voxels sentenced by the verdict pass beside k_map_link = entries of
+    C_DOOMED1 = 13 * kCtrStride,  //   MapView::doomed (two words used alternately, like C_TOUCHED0 / 1)
+    C_COUNT = 14 * kCtrStride
 };
+
+constexpr int kDoneSub = 16;  // first-level sign-off words of a frame's last kernel (kicp_map.hip: frame_record_handoff)
 
 enum ErrBits { E_RANGE = 1, E_TABLE_FULL = 2, E_POOL_FULL = 4, E_TIMEOUT = 8, E_BOUNDS = 16 };
 
@@ -120,6 +128,8 @@ struct MapView {
     int *ctr;
     int *free_ids;  // ring of recycled block ids, indexed modulo free_cap by the C_F* cursors
     int free_cap;
+    int *done_sub;  // kDoneSub sign-off words, a 128-byte line each (frame_record_handoff: the first level of a two-level count)
+    int *doomed;  // fused map update: block ids of the voxels this frame removes (C_DOOMED0 / 1 entries; room for every block)
     int *heads;  // per-slot id of the voxel record opened by the running insert (-1 when idle)
     int z_off;   // byte offset of the z array inside a block = 32 + 16 * max_points
     double voxel_size;
@@ -150,6 +160,7 @@ struct InsertScratch {
     double *world;  // incoming points in the map frame
     int *next;      // per point: next point of the same voxel (chain, newest first; fallback only)
     int *rec_slot;  // per record: hash slot of its voxel (-1: record lost its race, empty)
+    int *rec_block; // per record: the voxel's block when the record was opened (-1: a voxel this insert creates)
     int *rec_count; // per record: incoming points filed (0 when idle)
     int *rec_head;  // per record: chain head (-1 when idle)
     int *rec_list;  // per record: the first kRecList point indices, unordered
@@ -323,6 +334,8 @@ struct Options {
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
+    long sort_by_rank = 1;       // source clouds of up to ~6.5 k points (by the previous frame's count) are ordered by rank in one launch (kicp_sort.hip); 0: always runs + merge passes
+    long map_fused_update = 1;   // RemovePointsFarFromLocation inside the two kernels of AddPoints (kicp_map.hip); 0: a third kernel behind them
     long icp_group_stable = 1;   // group form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
     long icp_wide_stable = 1;    // thread-per-query form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
     long icp_wide_promote_from = 1;
@@ -415,7 +428,7 @@ struct kicp_map {
     double voxel_size = 1.0, max_distance = 100.0;
     unsigned max_points = 20;
     int stride = 512;
-    kicp::DevBuf slots, heads, blocks, free_ids, ctr;
+    kicp::DevBuf slots, heads, blocks, free_ids, doomed, ctr;
     uint32_t slot_cap = 0;
     int blocks_cap = 0;
     // host-side upper bounds of the device counters (exact after refresh_counters)
@@ -425,7 +438,7 @@ struct kicp_map {
     uint64_t n_refresh = 0, n_grow = 0, n_rehash = 0;
     double wait_ms = 0.0;  // host time blocked in refreshes / growth
     // scratch of add_points
-    kicp::DevBuf pts_in, world, next, rec_slot, rec_count, rec_head, rec_list;
+    kicp::DevBuf pts_in, world, next, rec_slot, rec_block, rec_count, rec_head, rec_list;
     unsigned insert_seq = 0;
     int scratch_reserve(size_t n_max, kicp::InsertScratch &sc);  // sizes the buffers, picks the parity
     kicp::MapView view() const;

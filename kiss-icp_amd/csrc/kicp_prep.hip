@@ -322,6 +322,7 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter(DsParams P) {
         P.out[3 * j + 2] = z;
         P.tab[s].key = kKeyEmpty;  // each claimed slot has exactly one winner: self-cleaning
         P.tab[s].minidx = 0x7FFFFFFF;
+        if (P.sort_keys) P.sort_keys[j] = tile_key_of(x, y, z, j, P.sort_inv_cell);
         if (P.next_tab) {
             const int vx = voxel_coord(x, P.next_voxel), vy = voxel_coord(y, P.next_voxel),
                       vz = voxel_coord(z, P.next_voxel);
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(kScanThreads) void k_ds_scatter_rb(DsParams P) {
         P.out[3 * j + 2] = z;
         P.tab[b].key = kKeyEmpty;
         P.tab[b].minidx = 0x7FFFFFFF;
+        if (P.sort_keys) P.sort_keys[j] = tile_key_of(x, y, z, j, P.sort_inv_cell);
         if (P.next_tab) {
             const int vx = voxel_coord(x, P.next_voxel), vy = voxel_coord(y, P.next_voxel),
                       vz = voxel_coord(z, P.next_voxel);

@@ -23,26 +23,6 @@
 
 namespace kicp {
 
-__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
-    v &= 0x3FFu;
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
-__device__ __forceinline__ unsigned long long tile_key(const double *xyz, int i, double inv_cell) {
-    // 2-voxel cells, offset so that +-512 cells around the sensor map to 0..1023 (farther points clamp: only the
-    // quality of the order is at stake)
-    const double cx = floor(xyz[3 * i] * inv_cell) + 512.0, cy = floor(xyz[3 * i + 1] * inv_cell) + 512.0,
-                 cz = floor(xyz[3 * i + 2] * inv_cell) + 512.0;
-    const unsigned ux = (unsigned)fmin(fmax(cx, 0.0), 1023.0), uy = (unsigned)fmin(fmax(cy, 0.0), 1023.0),
-                   uz = (unsigned)fmin(fmax(cz, 0.0), 1023.0);
-    const unsigned long long m = (unsigned long long)(spread10(ux) | (spread10(uy) << 1) | (spread10(uz) << 2));
-    return (m << 24) | (unsigned long long)(unsigned)i;  // morton30(cell of point i) << 24 | i: unique
-}
-
 constexpr int kSortRun = 2048;     // keys one workgroup sorts in LDS (a single CU moves 128 B of LDS per clock: a bitonic
                                    // network over 8192 keys is ~40 us of LDS traffic alone, over 2048 keys ~6)
 constexpr int kSortThreads = 1024;
@@ -117,6 +97,55 @@ __global__ __launch_bounds__(256) void k_tile_merge_runs(const unsigned long lon
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// A cloud of a few thousand points -- the source cloud of a full-size-voxel scan: 3 - 5 k -- sorted BY RANK in one launch:
+// a key's place is the number of smaller keys (the keys are unique), so every workgroup settles kRankKeys keys against
+// all n without talking to anybody: no network, no merge, no second launch.  n^2 comparisons -- 22 M for 4.7 k keys --
+// spread over the whole device are 2 - 3 us; the bitonic network above is 66 dependent stages in ONE workgroup's LDS per
+// run (21 us for 2048 keys, however few runs there are) plus the merge pass (5 us).  With deskewing the sort is on the
+// serial chain of every frame (the front stages wait for the previous pose, KissICP.cpp:38-47).
+// Every workgroup reads all keys (tiles of kRankTile in LDS) -- written beside the cloud by the stage that produced it
+// (DsParams::sort_keys: the second VoxelDownsample's scatter), else computed here, by every workgroup for itself: 10 us
+// instead of 5 on the MulRan-like scene (profiles/r06_i_timeline_mulran.txt) --; 16 threads
+// share one key's comparisons, lane s taking the candidates s, s + 16, ... (a wave reads 16 consecutive LDS words per step,
+// each broadcast to its four keys).  Correct for ANY n (tiles and key blocks are loops); chosen by the hint only.
+// ------------------------------------------------------------------------------------------
+constexpr int kRankThreads = 256;
+constexpr int kRankSplit = 16;                         // threads per key
+constexpr int kRankKeys = kRankThreads / kRankSplit;   // keys per workgroup and trip
+constexpr int kRankTile = 4096;                        // candidate keys in LDS at a time (32 KB)
+constexpr size_t kRankMaxHint = 8192;                  // beyond: the bitonic runs + merge passes
+__global__ __launch_bounds__(kRankThreads) void k_tile_rank_sort(const double *xyz, const int *n_ptr, int n_imm, double inv_cell,
+                                                                 const unsigned long long *keys, unsigned long long *out) {
+    __shared__ unsigned long long skeys[kRankTile];
+    const int n = n_ptr ? *n_ptr : n_imm;
+    const int sub = (int)threadIdx.x % kRankSplit, slot = (int)threadIdx.x / kRankSplit;
+    for (int base = (int)blockIdx.x * kRankKeys; base < n; base += (int)gridDim.x * kRankKeys) {  // workgroup-uniform
+        const int i = base + slot;
+        const unsigned long long key = i < n ? (keys ? keys[i] : tile_key(xyz, i, inv_cell)) : ~0ull;
+        int rank = 0;
+        for (int t0 = 0; t0 < n; t0 += kRankTile) {
+            const int cnt = min(kRankTile, n - t0);
+            __syncthreads();  // (the tile before has been read)
+            if (keys) {  // (left by the stage that wrote the cloud: DsParams::sort_keys)
+                for (int j = threadIdx.x; j < cnt; j += kRankThreads) skeys[j] = keys[t0 + j];
+            } else {
+                for (int j = threadIdx.x; j < cnt; j += kRankThreads) skeys[j] = tile_key(xyz, t0 + j, inv_cell);
+            }
+            __syncthreads();
+            int j = sub;
+            for (; j + 3 * kRankSplit < cnt; j += 4 * kRankSplit) {  // four reads in flight
+                const unsigned long long a = skeys[j], b = skeys[j + kRankSplit], c = skeys[j + 2 * kRankSplit], d = skeys[j + 3 * kRankSplit];
+                rank += (a < key) + (b < key) + (c < key) + (d < key);
+            }
+            for (; j < cnt; j += kRankSplit) rank += skeys[j] < key;
+        }
+#pragma unroll
+        for (int off = 1; off < kRankSplit; off <<= 1) rank += __shfl_xor(rank, off, 64);
+        if (sub == 0 && i < n) out[rank] = key;
+    }
+}
+
 size_t tile_sort_temp_bytes(size_t) { return 256; }  // (the sort needs no scratch beyond its two key buffers)
 
 int tile_sort_prepare(int) { return 0; }  // (the block sort's 16 KiB of LDS need no opt-in)
@@ -125,17 +154,27 @@ int tile_sort_prepare(int) { return 0; }  // (the block sort's 16 KiB of LDS nee
 // n_hint: about how many points there will be (the previous frame's count; 0: unknown -> n_max): it only decides HOW the
 // runs are merged -- passes of fan-in 8 first when there are many, and a last pass that merges whatever is left all
 // against all, so a wrong hint costs time, never the order.
+bool tile_sort_by_rank(size_t n_max, size_t n_hint) {
+    if (n_hint == 0 || n_hint > n_max) n_hint = n_max;
+    return options().sort_by_rank != 0 && n_hint + n_hint / 4 + 64 <= kRankMaxHint;
+}
 int launch_tile_sort(const double *xyz, const int *n_ptr, int n_imm, size_t n_max, double voxel_size, unsigned long long *keys_in,
-                     unsigned long long *keys_out, size_t n_hint, hipStream_t s) {
+                     unsigned long long *keys_out, size_t n_hint, hipStream_t s, bool keys_ready) {
     if (n_max == 0) return 0;
     if (n_max > ((size_t)1 << 24)) return (int)hipErrorInvalidValue;  // 24 index bits
     const int runs = (int)((n_max + kSortRun - 1) / kSortRun);
     if (n_hint == 0 || n_hint > n_max) n_hint = n_max;
+    if (tile_sort_by_rank(n_max, n_hint)) {  // a small cloud: one launch, by rank
+        const size_t cover = n_hint + n_hint / 4 + 64 < n_max ? n_hint + n_hint / 4 + 64 : n_max;
+        hipLaunchKernelGGL(k_tile_rank_sort, dim3((unsigned)((cover + kRankKeys - 1) / kRankKeys)), dim3(kRankThreads), 0, s, xyz, n_ptr, n_imm,
+                           tile_sort_inv_cell(voxel_size), keys_ready ? keys_in : nullptr, keys_out);
+        return (int)hipGetLastError();
+    }
     const size_t runs_hint = (n_hint + n_hint / 4 + kSortRun - 1) / kSortRun + 1;
     int passes = 1;
     for (size_t cover = 12; runs_hint > cover && passes < 6; cover *= 8) ++passes;  // (the last pass takes ~a dozen runs gladly)
     unsigned long long *a = (passes & 1) ? keys_in : keys_out, *b = (passes & 1) ? keys_out : keys_in;  // ... so that the last pass ends in keys_out
-    hipLaunchKernelGGL(k_tile_sort_blocks, dim3(runs), dim3(kSortThreads), 0, s, xyz, n_ptr, n_imm, 1.0 / (2.0 * voxel_size), a, keys_out);
+    hipLaunchKernelGGL(k_tile_sort_blocks, dim3(runs), dim3(kSortThreads), 0, s, xyz, n_ptr, n_imm, tile_sort_inv_cell(voxel_size), a, keys_out);
     if (runs > 1) {
         const int grid = (int)((n_max + 255) / 256 < 2048 ? (n_max + 255) / 256 : 2048);
         long run_len = kSortRun;

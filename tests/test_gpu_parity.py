@@ -214,6 +214,74 @@ def test_prune_decides_the_shell_like_the_reference(gpu, O, voxel, max_dist):
     assert np.array_equal(sort_rows(g.point_cloud()), sort_rows(o.point_cloud()))
 
 
+@pytest.mark.parametrize("voxel,max_dist,mp", [(1.0, 30.0, 20), (0.5, 12.0, 5), (1.0, 25.0, 40)])
+def test_fused_map_update_removes_what_the_reference_removes(gpu, O, voxel, max_dist, mp):
+    """local_map_.Update = AddPoints, then RemovePointsFarFromLocation (VoxelHashMap.cpp:83-132).  The fused update takes
+    the verdicts beside AddPoints' first kernel and carries them out in its second ("map_fused_update", kicp_map.hip): a
+    moving origin whose shell sweeps through voxels that (a) receive nothing, (b) receive points of the very frame that
+    removes them -- the reference appends and then drops the whole voxel; creating it anew would be wrong --, (c) are
+    created by that frame beyond max_distance (judged by their first point), and voxels re-created later in recycled
+    blocks.  Every frame: the oracle's map, and the three-kernel form's, voxel for voxel and point for point."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.mapping import VoxelHashMap
+
+    rng = np.random.default_rng(int(10 * voxel + max_dist + mp))
+    maps = {fused: VoxelHashMap(voxel, max_dist, mp) for fused in (1, 0)}
+
+    def update_all(points, where):  # (the option is read by the call)
+        try:
+            for fused, m in maps.items():
+                _cabi.set_option("map_fused_update", fused)
+                m.update(points, where)
+        finally:
+            _cabi.set_option("map_fused_update", 1)
+
+    o = O.VoxelHashMap(voxel, max_dist, mp)
+    died_touched = created_dead = 0
+    for k in range(14):
+        centre = np.array([0.45 * max_dist * k, 0.1 * max_dist * np.sin(k), 0.0])
+        # a disc larger than max_distance around the new origin (points beyond it create voxels that die at once), plus a
+        # dense patch on the far side of the OLD origin's disc: voxels that exist, receive points now, and are out of range now
+        n = 9000
+        r = max_dist * 1.15 * np.sqrt(rng.uniform(0.0, 1.0, n))
+        a = rng.uniform(0.0, 2.0 * np.pi, n)
+        pts = np.stack([r * np.cos(a), r * np.sin(a), rng.normal(0.0, 0.6, n)], axis=1)
+        back = np.array([-0.9 * max_dist, 0.0, 0.0]) + rng.normal(0.0, [0.12 * max_dist, 0.3 * max_dist, 0.5], (3000, 3))
+        pts = np.concatenate([pts, back])[rng.permutation(n + 3000)]
+        if k % 3 == 2:  # origin overload: world points, an origin
+            world = pts + centre
+            before = {tuple(v) for v in np.floor(o.point_cloud() / voxel).astype(np.int64)} if o.num_voxels() else set()
+            update_all(world, centre)
+            o.update(world, centre)
+        else:
+            T = make_pose(tuple(centre), (0.0, 0.0, 0.3 * k))
+            before = {tuple(v) for v in np.floor(o.point_cloud() / voxel).astype(np.int64)} if o.num_voxels() else set()
+            world = pts @ T[:3, :3].T + T[:3, 3]
+            update_all(pts, T)
+            o.update(pts, T)
+        after = {tuple(v) for v in np.floor(o.point_cloud() / voxel).astype(np.int64)}
+        touched = {tuple(v) for v in np.floor(world / voxel).astype(np.int64)}
+        died_touched += len((before & touched) - after)
+        created_dead += len((touched - before) - after)
+        want = sort_rows(o.point_cloud())
+        for fused, m in maps.items():
+            assert m.num_voxels() == o.num_voxels(), (k, fused)
+            got = sort_rows(m.point_cloud())
+            assert got.shape == want.shape, (k, fused)
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=str((k, fused)))
+        assert np.array_equal(sort_rows(maps[1].point_cloud()), sort_rows(maps[0].point_cloud())), k
+    assert died_touched > 50 and created_dead > 50, (died_touched, created_dead)  # the cases were there
+    # the tables and the free ring are sound afterwards: a plain insert, an explicit prune
+    more = random_cloud(rng, 5000, extent=0.5 * max_dist, z_extent=1.0) + centre
+    for m in maps.values():
+        m.add_points(more)
+        m.remove_far_away_points(centre)
+    o.add_points(more)
+    o.remove_far_away_points(centre)
+    for m in maps.values():
+        np.testing.assert_allclose(sort_rows(m.point_cloud()), sort_rows(o.point_cloud()), rtol=0, atol=1e-12)
+
+
 def test_map_copy_is_an_independent_map(gpu, O):
     """the reference's VoxelHashMap is a copyable value type (VoxelHashMap.hpp:38-57): kicp_map_clone / VoxelHashMap.copy()
     give a second device map with the same voxels and points, which neither follows nor disturbs the original -- also

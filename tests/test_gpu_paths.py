@@ -298,6 +298,48 @@ def test_long_drive_map_content_every_50_frames(gpu, O):
     assert checked == 4
 
 
+def test_fused_map_update_in_the_pipeline_is_bitwise_the_three_kernel_form(gpu, O):
+    """KissICP.cpp:61: `local_map_.Update(frame_downsample, new_pose)`.  The pipeline's frame ends with two kernels -- the
+    verdicts of RemovePointsFarFromLocation taken beside k_map_link, carried out by k_map_apply, which also hands the frame
+    record to the host ("map_fused_update") -- instead of three.  A drive that leaves its 40 m map several times over:
+    trajectory, statistics and map content bit for bit what link -> apply -> prune gives, frame records arriving all the
+    same (every sync reads them), and both the oracle's"""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like
+
+    n = 150
+    ds = kitti_like(seed=8, n_frames=n, beams=32, azimuth_steps=512, yaw_deg=0.8)
+    ko = O.KissICP(deskew=0, max_range=40.0, voxel_size=0.5)
+    runs = {}
+    try:
+        for fused in (1, 0):
+            _cabi.set_option("map_fused_update", fused)
+            k = _pipe(deskew=False, max_range=40.0, voxel_size=0.5)
+            poses, counts, every = [], [], []
+            for i in range(n):
+                k.register_frame_async(ds[i][0])
+                if fused:
+                    ko.register_frame_noout(ds[i][0], ds[i][1])
+                if (i + 1) % 25 == 0:
+                    k.sync()
+                    every.append(k.synced_poses())
+                    poses.append(np.array(k.last_pose))
+                    counts.append((k.local_map.num_voxels(), k.last_stats()["icp"]["iterations"]))
+            k.sync()
+            runs[fused] = (poses, counts, sort_rows(k.local_map.point_cloud()), np.concatenate(every))
+    finally:
+        _cabi.set_option("map_fused_update", 1)
+    for a, b in zip(runs[1][0], runs[0][0]):
+        assert np.array_equal(a, b)
+    assert runs[1][1] == runs[0][1]
+    assert np.array_equal(runs[1][2], runs[0][2])
+    assert np.array_equal(runs[1][3], runs[0][3])
+    dt, dr = pose_error(ko.last_pose, runs[1][0][-1])
+    assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+    assert runs[1][1][-1][0] == ko.local_map.num_voxels()
+    np.testing.assert_allclose(runs[1][2], sort_rows(ko.local_map.point_cloud()), rtol=0, atol=1e-8)
+
+
 # ---- BuildLinearSystem itself -----------------------------------------------------------------------------------
 def test_linear_system_matches_the_oracle(gpu, O):
     """the 6x6 / 6x1 normal equations of one iteration (Registration.cpp:80-121), element by element: the
@@ -667,22 +709,28 @@ def _morton_keys(xyz, voxel):
     return (m << np.uint64(24)) | np.arange(len(xyz), dtype=np.uint64)
 
 
-@pytest.mark.parametrize("n", [1, 2047, 2048, 2049, 5000, 16384, 16385, 40000, 150000, 300000])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 2047, 2048, 2049, 4095, 4096, 4097, 5000, 6500, 16384, 16385, 40000, 150000, 300000])
 def test_spatial_order_of_the_source_cloud(gpu, n):
-    """the order k_icp takes its runs from: sorted runs of 2048 keys merged by rank -- all at once when they are few,
-    eight at a time first when they are many (which of the two is decided by a HINT of the count, the previous
-    frame's; the count itself is on the device).  Whatever the hint and the host-side bound: THE ascending order of
-    the keys, which are those of a numpy restatement."""
+    """the order k_icp takes its runs from.  A cloud that a HINT of its size (the previous frame's count; the count itself
+    is on the device) puts at a few thousand points is ordered by rank in one launch ("sort_by_rank"); otherwise sorted
+    runs of 2048 keys are merged by rank -- all at once when they are few, eight at a time first when they are many.
+    Whatever the hint, the host-side bound and the option: THE ascending order of the keys, which are those of a numpy
+    restatement (a hint of a twentieth sends clouds of up to 130 k points down the one-launch path: slow, never wrong)."""
     from kiss_icp_amd import _cabi
 
     rng = np.random.default_rng(n)
     xyz = np.ascontiguousarray(rng.uniform(-60.0, 60.0, (n, 3)) * np.array([1.0, 1.0, 0.1]))
     want = np.sort(_morton_keys(xyz, 0.5))
     assert len(np.unique(want)) == n
-    for hint, bound in ((0, n), (n, n), (max(1, n // 20), n), (min(20 * n, 1 << 24), min(4 * n + 7, 1 << 24)), (n, min(8 * n, 1 << 24))):
-        got = np.zeros(n, dtype=np.uint64)
-        _cabi.check(_cabi.lib().kicp_selftest_tile_sort(0, _cabi.ptr(xyz), n, 0.5, hint, bound, _cabi.ptr(got)))
-        assert np.array_equal(got, want), (n, hint, bound)
+    try:
+        for by_rank in (1, 0):
+            _cabi.set_option("sort_by_rank", by_rank)
+            for hint, bound in ((0, n), (n, n), (max(1, n // 20), n), (min(20 * n, 1 << 24), min(4 * n + 7, 1 << 24)), (n, min(8 * n, 1 << 24))):
+                got = np.zeros(n, dtype=np.uint64)
+                _cabi.check(_cabi.lib().kicp_selftest_tile_sort(0, _cabi.ptr(xyz), n, 0.5, hint, bound, _cabi.ptr(got)))
+                assert np.array_equal(got, want), (n, hint, bound, by_rank)
+    finally:
+        _cabi.set_option("sort_by_rank", 1)
 
 
 # ---- robustness ---------------------------------------------------------------------------------------------
