@@ -452,6 +452,29 @@ def main():
         for f in host[W:W + K]:
             ko.register_frame(*f)  # returns (preprocessed frame, source) as numpy arrays
         rate_out = K / (time.perf_counter() - t)
+        # (d) the same signature in C++: kiss_icp::pipeline::KissICP::RegisterFrame (KissICP.cpp:35-68; what
+        #     ros/src/OdometryServer.cpp:162 calls) returning its two std::vector<Eigen::Vector3d>, driven through the pybind
+        #     module's _KissICP (a thin call: the scan is passed as a view, the result tuple is not converted)
+        try:
+            from kiss_icp_amd.metrics import _pybind
+
+            pm = _pybind()
+            pc, kc = load_config(**cfg_over), pm._KISSConfig()
+            for section in (pc.data, pc.mapping, pc.registration, pc.adaptive_threshold):
+                for name, v in vars(section).items():
+                    if v is not None and hasattr(kc, name):
+                        setattr(kc, name, v)
+            kcpp = pm._KissICP(kc)
+            for f in host[:W]:
+                kcpp._register_frame(f[0], f[1])
+            t = time.perf_counter()
+            for f in host[W:W + K]:
+                kcpp._register_frame(f[0], f[1])
+            rate_cpp = K / (time.perf_counter() - t)
+            out["sync_with_outputs_cpp"] = {"scans_per_s": rate_cpp, "ms_per_frame": 1e3 / rate_cpp,
+                                            "same_trajectory_as_host_input": bool((np.asarray(kcpp._pose()) == local_poses[-1]).all())}
+        except Exception as e:  # (the C++ layer is optional: make -C kiss-icp_amd/cpp)
+            out["sync_with_outputs_cpp"] = {"error": repr(e)}
         out["sync_per_frame"] = {"scans_per_s": rate_sync, "ms_per_frame": 1e3 / rate_sync,
                                  "same_trajectory_as_host_input": bool((ks.last_pose == local_poses[-1]).all())}
         out["sync_with_outputs"] = {"scans_per_s": rate_out, "ms_per_frame": 1e3 / rate_out,

@@ -206,6 +206,15 @@ int kicp_pipeline_register_frame_views(kicp_pipeline *p, const double *xyz, size
                                        const double *timestamps, size_t n_timestamps,
                                        const double **pre_view, size_t *n_pre,
                                        const double **src_view, size_t *n_src);
+/* The second half of RegisterFrame-with-its-return-value for a host whose result containers must be ALLOCATED per call
+ * (std::vector<Eigen::Vector3d> by value: KissICP.cpp:35-68, consumed at ros/src/OdometryServer.cpp:162-165): queue the scan with
+ * kicp_pipeline_register_frame_async -- the only frame in flight --, allocate while the device works (3 MB of fresh pages
+ * are ~0.3 ms of page faults: as long as the whole registration), then call this: it waits for the frame, has the
+ * preprocessed cloud in pre_out (at most pre_cap points; downloaded and spread while the registration was running) and the
+ * source cloud behind *src_view, in pinned memory of the pipeline (valid as for kicp_pipeline_register_frame_views).
+ * KICP_ERR_INVALID_ARG unless exactly one frame is in flight. */
+int kicp_pipeline_collect_outputs(kicp_pipeline *p, double *pre_out, size_t pre_cap, size_t *n_pre,
+                                  const double **src_view, size_t *n_src);
 /* The same without waiting: the scan is copied into pinned staging memory (a few helper threads,
  * option "staging_threads"), so the caller's buffers are free again when the call returns; its upload and
  * the stages in front of the registration then run on a second stream UNDER the previous frame's

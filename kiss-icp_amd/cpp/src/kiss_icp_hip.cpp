@@ -360,17 +360,20 @@ KissICP::Vector3dVectorTuple KissICP::RegisterFrame(const std::vector<Eigen::Vec
 
 KissICP::Vector3dVectorTuple KissICP::RegisterFrame(PointSpan frame, const double *timestamps, std::size_t n_timestamps) {
     PushPoseEdits();
-    // both clouds arrive in pinned memory of the pipeline -- the preprocessed frame while the registration is still
-    // running -- and the two vectors the reference's signature returns are built from there in one pass each
-    const double *pre = nullptr, *src = nullptr;
-    size_t n_pre = 0, n_src = 0;
-    check(kicp_pipeline_register_frame_views(handle_, frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps, &pre,
-                                             &n_pre, &src, &n_src),
+    // The two vectors the reference's signature returns are new memory every call, and 3 MB of fresh pages cost what the whole
+    // registration costs.  So: queue the scan, allocate the large one WHILE the device works, then collect -- the
+    // preprocessed frame reaches the vector while the registration is still running (kicp.h: kicp_pipeline_collect_outputs).
+    check(kicp_pipeline_sync(handle_), "KissICP::RegisterFrame");  // (frames a caller queued through other entries)
+    check(kicp_pipeline_register_frame_async(handle_, frame.xyz, frame.n, n_timestamps ? timestamps : nullptr, n_timestamps),
           "KissICP::RegisterFrame");
-    // (the vectors first, the getters after: the views are only promised until the next call that stages an output)
-    const auto *p3 = reinterpret_cast<const Eigen::Vector3d *>(pre);
+    Vector3dVector pre(frame.n);
+    const double *src = nullptr;
+    size_t n_pre = 0, n_src = 0;
+    check(kicp_pipeline_collect_outputs(handle_, xyz(pre), pre.size(), &n_pre, &src, &n_src), "KissICP::RegisterFrame");
+    pre.resize(n_pre);  // (shrinks in place)
+    // (the vector first, the getters after: the view is only promised until the next call that stages an output)
     const auto *s3 = reinterpret_cast<const Eigen::Vector3d *>(src);
-    Vector3dVectorTuple out{Vector3dVector(p3, p3 + n_pre), Vector3dVector(s3, s3 + n_src)};  // KissICP.cpp:67
+    Vector3dVectorTuple out{std::move(pre), Vector3dVector(s3, s3 + n_src)};  // KissICP.cpp:67
     CollectState();
     return out;
 }

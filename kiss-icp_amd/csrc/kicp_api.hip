@@ -2686,13 +2686,23 @@ int kicp_pipeline_output(kicp_pipeline *p, int which, double *out, size_t cap, s
 // (DMA into pinned memory on a third stream) and reaches the caller's buffer while the registration is still
 // running, so the call costs what the registration costs, not that plus a 3 MB download.
 // views: the clouds stay in the pipeline's pinned buffer and the caller gets pointers into it.
+// (enqueue = false: the frame is the one the caller has queued itself, a moment ago, through the asynchronous entry -- and
+// nothing else: kicp_pipeline_collect_outputs)
 static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, const double *timestamps, size_t n_ts, bool views,
                                  double *pre_out, size_t pre_cap, const double **pre_view, size_t *n_pre, double *src_out,
-                                 size_t src_cap, const double **src_view, size_t *n_src) {
+                                 size_t src_cap, const double **src_view, size_t *n_src, bool enqueue = true) {
     KICP_HIP(hipSetDevice(p->device));
     static const double kNone[3] = {0.0, 0.0, 0.0};
-    if (p->in_flight) KICP_TRY(pipe_sync(p, false));  // `pre` exists once: no frame may be queued behind this one
-    KICP_TRY(pipe_stage_and_enqueue(p, xyz ? xyz : kNone, nullptr, n, timestamps, n_ts));
+    if (enqueue) {
+        if (p->in_flight) KICP_TRY(pipe_sync(p, false));  // `pre` exists once: no frame may be queued behind this one
+        KICP_TRY(pipe_stage_and_enqueue(p, xyz ? xyz : kNone, nullptr, n, timestamps, n_ts));
+    } else {
+        if (p->in_flight != 1) {
+            set_error("kicp_pipeline_collect_outputs: exactly one frame must be in flight (%d are)", p->in_flight);
+            return KICP_ERR_INVALID_ARG;
+        }
+        n = p->last_in.n;
+    }
     const int par = (int)((p->frames_enqueued - 1) & 1u);
     if (!p->copy_stream) {
         KICP_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
@@ -2703,7 +2713,8 @@ static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, 
     const size_t want = views ? n : (n < pre_cap ? n : pre_cap);
     const size_t bytes = want * 3 * sizeof(double);
     const size_t off_prep = (bytes + 63) & ~(size_t)63, off_src = off_prep + 256;
-    KICP_TRY(pipe_out_stage(p, off_src + (views ? n * 3 * sizeof(double) : 0)));
+    // (the source cloud as a view needs room behind the counts whether or not the preprocessed frame is one)
+    KICP_TRY(pipe_out_stage(p, off_src + ((views || src_view) ? n * 3 * sizeof(double) : 0)));
     PrepState *h_prep = reinterpret_cast<PrepState *>(p->out_stage + off_prep);
     KICP_HIP(hipStreamWaitEvent(p->copy_stream, p->ev_prep_done[par], 0));
     KICP_HIP(hipMemcpyAsync(h_prep, p->prep.as<PrepState>() + par, sizeof(PrepState), hipMemcpyDeviceToHost, p->copy_stream));
@@ -2719,8 +2730,8 @@ static int pipe_register_outputs(kicp_pipeline *p, const double *xyz, size_t n, 
         set_error("preprocessed count changed under the download (%zu vs %zu)", got_pre, *n_pre);
         return KICP_ERR_HIP;
     }
-    if (!views) return kicp_pipeline_output(p, KICP_OUT_SOURCE, src_out, src_cap, n_src);
-    *pre_view = reinterpret_cast<const double *>(p->out_stage);
+    if (!src_view) return kicp_pipeline_output(p, KICP_OUT_SOURCE, src_out, src_cap, n_src);
+    if (pre_view) *pre_view = reinterpret_cast<const double *>(p->out_stage);
     *n_src = (size_t)p->last.st.n_src;
     *src_view = reinterpret_cast<const double *>(p->out_stage + off_src);
     if (*n_src) {
@@ -2741,6 +2752,11 @@ int kicp_pipeline_register_frame_views(kicp_pipeline *p, const double *xyz, size
                                        const double **pre_view, size_t *n_pre, const double **src_view, size_t *n_src) {
     if (!p || (!xyz && n) || !n_pre || !n_src || !pre_view || !src_view) return KICP_ERR_INVALID_ARG;
     return pipe_register_outputs(p, xyz, n, timestamps, n_ts, true, nullptr, 0, pre_view, n_pre, nullptr, 0, src_view, n_src);
+}
+
+int kicp_pipeline_collect_outputs(kicp_pipeline *p, double *pre_out, size_t pre_cap, size_t *n_pre, const double **src_view, size_t *n_src) {
+    if (!p || !n_pre || !n_src || !src_view || (!pre_out && pre_cap)) return KICP_ERR_INVALID_ARG;
+    return pipe_register_outputs(p, nullptr, 0, nullptr, 0, false, pre_out, pre_cap, nullptr, n_pre, nullptr, 0, src_view, n_src, false);
 }
 
 int kicp_pipeline_voxelize(kicp_pipeline *p, const double *xyz, size_t n, double *source_xyz, size_t *n_source,

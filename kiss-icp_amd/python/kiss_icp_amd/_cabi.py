@@ -104,6 +104,7 @@ SIGNATURES = {
     "kicp_pipeline_register_frame": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_register_frame_outputs": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _szp, _vp, _sz, _szp],
     "kicp_pipeline_register_frame_views": [_vp, _vp, _sz, _vp, _sz, C.POINTER(_vp), _szp, C.POINTER(_vp), _szp],
+    "kicp_pipeline_collect_outputs": [_vp, _vp, _sz, _szp, C.POINTER(_vp), _szp],
     "kicp_pipeline_register_frame_async": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_register_frame_async_f32": [_vp, _vp, _sz, _vp, _sz],
     "kicp_pipeline_register_frame_device": [_vp, _vp, _sz, _vp, _sz],

@@ -90,6 +90,40 @@ def test_async_host_input_is_bitwise_the_sync_path(gpu, O, deskew):
     assert dt < TIGHT and dr < TIGHT
 
 
+@pytest.mark.parametrize("deskew", [False, True])
+def test_collect_outputs_is_the_second_half_of_register_frame(gpu, deskew):
+    """KissICP::RegisterFrame returns {preprocessed frame, source} by value (KissICP.cpp:35-68).  For a host that must
+    allocate those per call: kicp_pipeline_register_frame_async, allocate while the device works, then
+    kicp_pipeline_collect_outputs -- bit for bit what kicp_pipeline_register_frame_outputs hands back, frame after frame;
+    and the entry refuses to guess when there is no frame, or more than one, in flight"""
+    import ctypes as C
+
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import kitti_like, mulran_like
+
+    L = _cabi.lib()
+    n_frames = 6
+    ds = (mulran_like if deskew else kitti_like)(seed=12, n_frames=n_frames, beams=32, azimuth_steps=512)
+    ref, k = _pipe(deskew=deskew), _pipe(deskew=deskew)
+    n_pre, n_src, view = C.c_size_t(0), C.c_size_t(0), C.c_void_p()
+    dummy = np.empty((4, 3))
+    assert L.kicp_pipeline_collect_outputs(k._h, _cabi.ptr(dummy), 4, C.byref(n_pre), C.byref(view), C.byref(n_src)) == 1  # KICP_ERR_INVALID_ARG
+    for i in range(n_frames):
+        p, t = ds[i]
+        want_pre, want_src = ref.register_frame(p, t)
+        k.register_frame_async(p, t)
+        pre = np.full((len(p), 3), np.nan)  # (the allocation the entry exists for)
+        _cabi.check(L.kicp_pipeline_collect_outputs(k._h, _cabi.ptr(pre), len(pre), C.byref(n_pre), C.byref(view), C.byref(n_src)))
+        src = np.ctypeslib.as_array(C.cast(view, C.POINTER(C.c_double)), shape=(n_src.value, 3)).copy()
+        assert n_pre.value == len(want_pre) and np.array_equal(pre[: n_pre.value], want_pre), i
+        assert np.array_equal(src, want_src), i
+        assert np.array_equal(k.last_pose, ref.last_pose), i
+    k.register_frame_async(*ds[0])
+    k.register_frame_async(*ds[1])
+    assert L.kicp_pipeline_collect_outputs(k._h, _cabi.ptr(dummy), 4, C.byref(n_pre), C.byref(view), C.byref(n_src)) == 1  # KICP_ERR_INVALID_ARG
+    k.sync()
+
+
 def test_stage_in_of_deskewing_frames_is_bitwise_neutral(gpu, O):
     """option stage_in: a frame that deskews has its scan and timestamps copied from the staging slot into HBM in FRONT of the
     wait for the previous pose (under the previous registration) instead of being read over PCIe on the frame's serial chain.
