@@ -522,6 +522,10 @@ int kicp_selftest_narrow(const double *src, size_t count, float *dst, int *exact
  *                     long (0 .. 60000; consumed by the first taker) -- the dependency that is not signalled in time
  *                     (tests/test_gpu_deadlines.py)
  *   "map_apply_threads"  workgroup size of the AddPoints apply kernel: 256, 512 (default) or 1024
+ *   "icp_weights_kernel"  1 (default) = the weights that cut a source cloud of short runs (at most 64 points per workgroup) into runs of
+ *                     equal weight are computed by a kernel of their own in front of the registration launch, and every workgroup
+ *                     finds its boundaries from all of them by itself; 0 = by the launch's prologue, with an exchange of the
+ *                     workgroups' sums.  The same weights, the same runs, the same pose bit for bit
  *   "sort_by_rank"    1 (default) = a source cloud of a few thousand points (judged by the previous frame's count: up to ~6.5 k) gets
  *                     its spatial order for the registration's workgroups in ONE launch, every key placed by its rank among all;
  *                     0 = always sorted runs + merge passes.  The same order either way (the keys are unique)

@@ -1202,7 +1202,7 @@ int kicp_registration_destroy(kicp_registration *r) {
     (void)hipSetDevice(r->device);
     int idle = r->stream ? wait_stream(r->stream, "registration teardown") : KICP_OK;
     if (idle == KICP_OK) idle = wait_device(r->device, "registration teardown");
-    for (DevBuf *b : {&r->frame, &r->work, &r->sort_in, &r->sort_out, &r->sort_tmp, &r->run_wts, &r->granules, &r->state}) b->drop(idle == KICP_OK);
+    for (DevBuf *b : {&r->frame, &r->work, &r->sort_in, &r->sort_out, &r->sort_tmp, &r->run_wts, &r->run_wts32, &r->granules, &r->state}) b->drop(idle == KICP_OK);
     if (idle == KICP_OK) {
         if (r->ev0) (void)hipEventDestroy(r->ev0);
         if (r->ev1) (void)hipEventDestroy(r->ev1);
@@ -1258,6 +1258,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
             KICP_TRY(r->run_wts.reserve(n * sizeof(unsigned long long)));
             KICP_HIP(hipMemsetAsync(r->run_wts.p, 0, r->run_wts.bytes, r->stream));
         }
+        KICP_TRY(r->run_wts32.reserve((size_t)kIcpListRunMax * kIcpMaxBlocks * sizeof(unsigned)));  // (k_icp_weights: short runs only)
     }
     PipeState h;
     for (int attempt = 0, cap = 0;; ++attempt) {
@@ -1267,6 +1268,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         P.frame = r->frame.as<double>();
         P.order = sorted ? r->sort_out.as<unsigned long long>() : nullptr;
         P.wts = sorted ? r->run_wts.as<unsigned long long>() : nullptr;
+        P.wts32 = sorted && options().icp_weights_kernel != 0 ? r->run_wts32.as<unsigned>() : nullptr;
         P.weight_base = (int)options().icp_weight_base;
         P.weight_quad = (int)options().icp_weight_quad;
         P.weight_long_base = (int)options().icp_weight_long_base;
@@ -1285,6 +1287,7 @@ int kicp_align_points_to_map(kicp_registration *r, const double *frame_xyz, size
         P.conv = r->conv;
         P.granules = r->granules.as<unsigned long long>();
         P.spin_limit = kSpinLimit;
+        if (P.wts32) launch_icp_weights(P, G, n, r->stream);
         KICP_HIP(hipEventRecord(r->ev0, r->stream));
         KICP_TRY(icp_launch_ordered(r->device, P, G, options().icp_profile != 0, r->stream, 1));
         KICP_HIP(hipGetLastError());
@@ -1571,6 +1574,7 @@ struct kicp_pipeline {
     int ds_order = 1;  // VoxelDownsample output order ("downsample_order" option, read at create)
     DevBuf sort_in, sort_out[2], sort_tmp;  // spatial order of the source cloud (keys; sorted keys by frame parity; rocPRIM scratch)
     DevBuf run_wts;                         // run weights of the sorted points, one tagged granule each (written by k_icp's prologue)
+    DevBuf run_wts32;                       // ... as plain 32-bit words, written by k_icp_weights in front of the launch (short runs)
     size_t sort_tmp_bytes = 0;
     size_t cap_points = 0;
     uint32_t tab_cap = 0;
@@ -1664,6 +1668,7 @@ static int pipe_reserve(kicp_pipeline *p, size_t n) {
         KICP_TRY(p->run_wts.reserve(cap * sizeof(unsigned long long)));
         KICP_HIP(hipMemsetAsync(p->run_wts.p, 0, p->run_wts.bytes, p->stream));
     }
+    KICP_TRY(p->run_wts32.reserve((size_t)kIcpListRunMax * kIcpMaxBlocks * sizeof(unsigned)));
     KICP_TRY(init_ds_table(p->tab1, tcap, p->stream));
     KICP_TRY(init_ds_table(p->tab2, tcap, p->stream));
     if (p->ds_order) {
@@ -2027,6 +2032,7 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
     I.order = sorted ? p->sort_out[par].as<unsigned long long>() : nullptr;
     if (sorted && n) {  // runs of equal weight, settled by the kernel's own prologue
         I.wts = p->run_wts.as<unsigned long long>();
+        I.wts32 = options().icp_weights_kernel != 0 ? p->run_wts32.as<unsigned>() : nullptr;
         I.weight_base = (int)options().icp_weight_base;
         I.weight_quad = (int)options().icp_weight_quad;
         I.weight_long_base = (int)options().icp_weight_long_base;
@@ -2055,6 +2061,9 @@ static int pipe_enqueue(kicp_pipeline *p, const void *d_xyz, int xyz_f32, size_t
         KICP_TRY(p->prof_groups.reserve(kIcpGroupProfileWords * sizeof(unsigned)));
         I.prof_groups = p->prof_groups.as<unsigned>();
     }
+    // the run weights of a cloud of short runs, by a kernel of their own in front of the launch ("icp_weights_kernel", kicp_icp.hip)
+    if (I.wts && I.wts32) launch_icp_weights(I, G, n_src_hint, s);
+    else I.wts32 = nullptr;
     const int slot = p->in_flight;
     // Two events per frame, each doing double duty: ev[slot][0] in front of the launch opens the timing
     // bracket and marks "the previous frame is completely done" (buffer reuse, capacity bounds);
@@ -2380,7 +2389,7 @@ int kicp_pipeline_destroy(kicp_pipeline *p) {
     }
     for (DevBuf *b : {&p->raw[0], &p->raw[1], &p->ts[0], &p->ts[1], &p->tmp, &p->pre, &p->fd[0], &p->fd[1], &p->src[0], &p->src[1],
                       &p->work, &p->slot1, &p->slot2, &p->tab1, &p->tab2, &p->rb1, &p->rb2, &p->counts, &p->granules, &p->prof_groups, &p->prep,
-                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_wts})
+                      &p->sort_in, &p->sort_out[0], &p->sort_out[1], &p->sort_tmp, &p->run_wts, &p->run_wts32})
         b->drop(gone);
     if (gone) {
         for (int i = 0; i < 2; ++i)
@@ -3049,6 +3058,8 @@ int kicp_set_option(const char *name, long value) {
         options().icp_wide_stable = value != 0;
     } else if (!strcmp(name, "icp_group_stable")) {
         options().icp_group_stable = value != 0;
+    } else if (!strcmp(name, "icp_weights_kernel")) {
+        options().icp_weights_kernel = value != 0;
     } else if (!strcmp(name, "sort_by_rank")) {
         options().sort_by_rank = value != 0;
     } else if (!strcmp(name, "map_fused_update")) {

@@ -682,6 +682,138 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same weights, computed by a kernel of their own IN FRONT of the registration (option "icp_weights_kernel").
+// Inside the launch a workgroup weighs its ~21 points sixteen at a time (two rounds of three dependent round trips to the
+// map), waits for the slowest of 224 to publish its sum, adds 224 sums on one thread and scans a neighbour's slice: 16 us of
+// every launch before the first association starts (profiles/r06_l_*: first iteration 46.6 us, 29.5 of them the iteration).
+// k_icp_weights weighs all points at once -- a 32-lane group per point, every group its own lookups, nothing to wait for --
+// and leaves plain 32-bit weights; every workgroup of k_icp then reads them all (19 KB), forms the prefix sums itself and finds
+// its two boundaries: no exchange.  The weights, the rule that cuts the runs (position q lies in front of boundary b iff
+// E[q] * G < b * W, E the exclusive prefix) and so the runs are the in-launch path's, integer for integer: same poses bit for bit
+// (tests/test_gpu_paths.py::test_run_weights_from_their_own_kernel_give_the_same_runs).  Short runs only (the group form's
+// regime and the thread-per-query form on small clouds); long runs keep the in-launch path with its cap on the run length.
+// ------------------------------------------------------------------------------------------
+struct IcpWeightArgs {
+    const double *frame;
+    const unsigned long long *order;
+    unsigned *wts32;
+    const int *n_ptr;
+    int n_imm;
+    MapView map;
+    PipeState *state;
+    int pipeline_mode;
+    int icp_grid, force_blocks, points_per_group;  // what k_icp will derive its G from
+    int weight_base, weight_quad, dense_min, dense_div;
+};
+__device__ __forceinline__ int icp_grid_of(int n, int force_blocks, int points_per_group, int grid) {
+    int G = force_blocks > 0 ? force_blocks : (n + kIcpGroupsPerBlock * points_per_group - 1) / (kIcpGroupsPerBlock * points_per_group);
+    return max(1, min(G, grid));
+}
+__global__ __launch_bounds__(256) void k_icp_weights(IcpWeightArgs A) {
+    const int n = count_of(A.n_ptr, A.n_imm);
+    const int G = icp_grid_of(n, A.force_blocks, A.points_per_group, A.icp_grid);
+    // (the cases in which k_icp does not cut weighted runs, or cuts long ones by its own prologue)
+    if (n < kIcpWeightedMin || A.force_blocks > 0 || n > kIcpListRunMax * G || A.map.ctr[C_LIVE] == 0) return;
+    if (__hip_atomic_load(&A.state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) return;
+    const SE3 guess = A.pipeline_mode ? se3_mul(A.state->last_pose, A.state->last_delta) : A.state->guess;  // (k_icp's own expression)
+    const int quad = A.weight_quad >= 0 ? A.weight_quad : 10;
+    const int lane = threadIdx.x & (kIcpGroup - 1);
+    const int groups = (int)(gridDim.x * blockDim.x) / kIcpGroup;
+    for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x) / kIcpGroup; q < n; q += groups) {
+        const int p = KICP_IDX(A.map.dbg, &A.state->err, key_index(A.order[q]), n, 3);
+        const double pin[3] = {A.frame[3 * p], A.frame[3 * p + 1], A.frame[3 * p + 2]};
+        double sp[3];
+        se3_act(guess, pin, sp);
+        int rerr = 0;
+        const Probe pr = probe27(A.map, sp[0], sp[1], sp[2], lane, rerr);
+        const int c = __shfl(pr.cnt, 0, kIcpGroup);  // the point's own voxel (shift 0 of the table)
+        const int dense = A.dense_div > 0 ? max(0, pr.E - A.dense_min) / A.dense_div : 0;
+        const int w = A.weight_base + c + (quad > 0 ? (c * c) / quad : 0) + dense;
+        if (lane == 0) A.wts32[q] = (unsigned)w;
+    }
+}
+void launch_icp_weights(const IcpParams &P, int icp_grid, size_t n_hint, hipStream_t s) {
+    IcpWeightArgs A;
+    A.frame = P.frame;
+    A.order = P.order;
+    A.wts32 = P.wts32;
+    A.n_ptr = P.n_ptr;
+    A.n_imm = P.n_imm;
+    A.map = P.map;
+    A.state = P.state;
+    A.pipeline_mode = P.pipeline_mode;
+    A.icp_grid = icp_grid;
+    A.force_blocks = P.force_blocks;
+    A.points_per_group = P.points_per_group;
+    A.weight_base = P.weight_base;
+    A.weight_quad = P.weight_quad;
+    A.dense_min = P.weight_dense_min;
+    A.dense_div = P.weight_dense_div;
+    // a group per point of the cloud there will probably be (the loop covers any other count)
+    size_t groups = n_hint + n_hint / 4 + 64;
+    if (groups > (size_t)kIcpListRunMax * kIcpMaxBlocks) groups = (size_t)kIcpListRunMax * kIcpMaxBlocks;
+    const int grid = (int)((groups * kIcpGroup + 255) / 256);
+    hipLaunchKernelGGL(k_icp_weights, dim3(grid), dim3(256), 0, s, A);
+}
+
+// k_icp's side: this workgroup's run [sh.run[0], sh.run[1]) from the weights k_icp_weights left.  scratch: LDS for n 32-bit words
+// (the tile's region: nothing lives there yet), or nullptr -- the weights are then read from memory twice.
+__device__ __forceinline__ void icp_runs_from_weights(const unsigned *wts32, IcpShared *shp, unsigned *scratch, int n, int G) {
+    IcpShared &sh = *shp;
+    const int tid = threadIdx.x;
+    const unsigned *w = wts32;
+    if (scratch) {
+        for (int i = tid; i < n; i += kIcpThreads) scratch[i] = wts32[i];  // (coalesced; every workgroup reads all of them: 19 KB)
+        __syncthreads();
+        w = scratch;
+    }
+    // thread t takes the contiguous piece [t per, (t + 1) per): its sum, then the exclusive prefix of the 512 sums
+    const int per = (n + kIcpThreads - 1) / kIcpThreads;
+    const int a = min(n, tid * per), b = min(n, a + per);
+    long long mine = 0;
+    for (int i = a; i < b; ++i) mine += (long long)w[i];
+    long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += up;
+    }
+    long long *wave_tot = reinterpret_cast<long long *>(sh.part);  // [8]
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    if (tid < 2) sh.run[tid] = 0;
+    __syncthreads();
+    long long before = 0, W = 0;
+#pragma unroll
+    for (int v = 0; v < kIcpThreads / 64; ++v) {
+        const long long t = wave_tot[v];
+        before += v < (tid >> 6) ? t : 0;
+        W += t;
+    }
+    // position q lies in front of boundary `which` iff E[q] * G < (blockIdx.x + which) * W, E the exclusive prefix (icp_weighted_run)
+    const long long t0 = (long long)blockIdx.x * W, t1 = ((long long)blockIdx.x + 1) * W;
+    long long E = before + incl - mine;
+    int c0 = 0, c1 = 0;
+    for (int i = a; i < b; ++i) {
+        c0 += (E * (long long)G < t0) ? 1 : 0;
+        c1 += (E * (long long)G < t1) ? 1 : 0;
+        E += (long long)w[i];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        c0 += __shfl_xor(c0, o, 64);
+        c1 += __shfl_xor(c1, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&sh.run[0], c0);
+        atomicAdd(&sh.run[1], c1);
+    }
+    __syncthreads();
+    if (tid == 0 && (int)blockIdx.x == G - 1) sh.run[1] = n;  // (the last run ends with the cloud)
+    __syncthreads();
+}
+
 }  // namespace kicp
 #include "kicp_icp_wide.hpp"
 namespace kicp {
@@ -800,7 +932,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const unsigned epoch_base = st->epoch_base;
     const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143 (nothing to align to: no iteration, no exchange, no runs)
     int q0, n_local;
-    if (P.wts && P.order && n >= kIcpWeightedMin && P.force_blocks <= 0 && !map_empty) {
+    if (P.wts32 && P.wts && P.order && n >= kIcpWeightedMin && P.force_blocks <= 0 && !map_empty && n <= kIcpListRunMax * G) {
+        // (k_icp_weights has weighed the points: exactly the condition under which it does)
+        const long room = (long)P.lds_bytes - (long)sizeof(IcpShared);
+        unsigned *scratch = (long)n * 4 <= room ? reinterpret_cast<unsigned *>(smem + sizeof(IcpShared)) : nullptr;
+        icp_runs_from_weights(P.wts32, &sh, scratch, n, G);
+        q0 = sh.run[0];
+        n_local = max(0, sh.run[1] - q0);
+        __syncthreads();  // sh.part and the scratch are reused
+    } else if (P.wts && P.order && n >= kIcpWeightedMin && P.force_blocks <= 0 && !map_empty) {
         IcpRunArgs R;
         R.frame = P.frame;
         R.order = P.order;

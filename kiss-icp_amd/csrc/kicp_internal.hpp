@@ -290,6 +290,8 @@ struct IcpParams {
     int lds_bytes;         // dynamic LDS of the launch (kIcpLdsBytesShared or kIcpLdsBytesMax)
     int schur_solve;       // solve well-conditioned normal equations through their 3 x 3 Schur complement (kicp_math.hpp: schur3_solve)
     int use_wide;          // host side only: launch the thread-per-query form (k_icp<.., true>)
+    unsigned *wts32;       // non-null: k_icp_weights has left the run weights here as plain 32-bit words (short runs only: at most
+                           // kIcpListRunMax * kIcpMaxBlocks of them), in front of this launch
     int group_stable;      // group form: queries whose neighbour cannot have changed skip the search (IcpQueryMeta::Lr)
     int wide_stable;       // thread-per-query form: queries whose neighbour cannot have changed skip the search (WideQuery::Lr), the rest
                            // are searched on the first lanes (0: every query is searched in place, every iteration)
@@ -334,6 +336,7 @@ struct Options {
     long icp_bulk_fill = 1;      // first iteration: all windows of a workgroup established in two bulk waves of loads
     long icp_schur_solve = 1;    // well-conditioned normal equations are solved through their 3 x 3 Schur complement (0: always the 6 x 6 pivoted LDLT)
     long icp_wide = -1;          // association form: 1 a thread per source point (kicp_icp_wide.hpp), 0 a 32-lane group, -1 by the cloud's size
+    long icp_weights_kernel = 1; // the run weights of short runs are computed by a kernel in front of k_icp (0: inside the launch, by its prologue)
     long sort_by_rank = 1;       // source clouds of up to ~6.5 k points (by the previous frame's count) are ordered by rank in one launch (kicp_sort.hip); 0: always runs + merge passes
     long map_fused_update = 1;   // RemovePointsFarFromLocation inside the two kernels of AddPoints (kicp_map.hip); 0: a third kernel behind them
     long icp_group_stable = 1;   // group form: skip the search of queries whose neighbour provably stays (0: search every query, every iteration)
@@ -453,7 +456,7 @@ struct kicp_registration {
     hipStream_t stream = nullptr;
     int max_iters = 500;
     double conv = 1e-4;
-    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_wts;
+    kicp::DevBuf frame, work, granules, state, sort_in, sort_out, sort_tmp, run_wts, run_wts32;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_sums[18] = {0};  // of the most recent kicp_align_points_to_map
 };

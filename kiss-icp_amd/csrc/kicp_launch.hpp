@@ -105,6 +105,9 @@ size_t icp_granule_words(int G);
 // start / stop: events attached to the dispatch itself (hipExtLaunchKernel: its own completion signal and timestamps --
 // no packet of their own in the queue, unlike hipEventRecord); either may be null
 void launch_icp(IcpParams P, int G, bool profile, bool wide, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// the run weights of a cloud of short runs, in front of launch_icp on the same stream (P as launch_icp will get it, wts32 set;
+// icp_grid: its grid; n_hint: about how many source points there are)
+void launch_icp_weights(const IcpParams &P, int icp_grid, size_t n_hint, hipStream_t s);
 void launch_closest_neighbor(const MapView &m, const double *q, int nq, double *nn, double *dist,
                              hipStream_t s);
 void launch_ts_minmax(const double *ts, int n_ts, PrepState *prep, hipStream_t s);

@@ -180,7 +180,7 @@ def test_every_tuning_knob_is_documented_and_every_documented_knob_exists(cabi):
              "downsample_order": 1, "icp_weight_base": 128, "icp_weight_long_base": 128, "icp_weight_dense_min": 200,
              "icp_weight_dense_div": 1, "icp_weight_quad": -1, "queue_depth": 4, "map_apply_threads": 512,
              "icp_inject_timeout": 0, "icp_inject_timeout_skip": 0, "map_rehash_every": 0, "icp_profile": 0,
-             "icp_wide": -1, "icp_wide_prune": 2, "icp_wide_stable": 1, "icp_group_stable": 1, "map_fused_update": 1, "sort_by_rank": 1, "icp_wide_prefill": 0, "icp_wide_promote_from": 1,
+             "icp_wide": -1, "icp_wide_prune": 2, "icp_wide_stable": 1, "icp_group_stable": 1, "map_fused_update": 1, "sort_by_rank": 1, "icp_weights_kernel": 1, "icp_wide_prefill": 0, "icp_wide_promote_from": 1,
              "icp_device_streams": 1, "icp_schur_solve": 1, "icp_wide_per_round": 4, "icp_wide_load_eighths": 5, "icp_weight_long_emul": 1, "icp_wide_flat": 3, "icp_wide_group_max": 128, "frame_events": 0,
              "staging_numa_pretend": -1, "wait_timeout_ms": 120000, "inject_stall_ms": 0, "collective_timeout_ms": 1800000}
     L = cabi.lib()

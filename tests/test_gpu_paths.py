@@ -619,6 +619,58 @@ def test_group_form_stability_shortcut_is_bitwise_neutral(gpu, O, kind, blocks):
 
 
 @pytest.mark.parametrize("kind", ["full_voxels", "small_voxels"])
+def test_run_weights_from_their_own_kernel_give_the_same_runs(gpu, O, kind):
+    """icp_weights_kernel: the weights that cut the sorted source cloud into runs of equal weight (one per workgroup) are
+    computed by k_icp_weights in front of the registration instead of by its prologue, and every workgroup finds its two
+    boundaries from all of them without an exchange.  Same weights, same rule, same runs -- so the pose, the iteration count,
+    the correspondences and the examined points are bit for bit those of the in-launch path: through AlignPointsToMap in the
+    group form and the thread-per-query form (which shares the short-run rule), and through the pipeline, frame by frame."""
+    from kiss_icp_amd import _cabi
+    from kiss_icp_amd.datasets import generate_scans, kitti_like_vegetated
+    from kiss_icp_amd.mapping import VoxelHashMap
+    from kiss_icp_amd.registration import Registration
+
+    rng = np.random.default_rng(76)
+    world, src, voxel, _ = _wide_scene(kind, rng)
+    if kind == "small_voxels":
+        src = src[:3500]
+    assert len(src) >= 2048  # (weighted runs at all)
+    guess = make_pose((0.45 * voxel, -0.3 * voxel, 0.05 * voxel), (0.004, -0.003, 0.015))
+    g = VoxelHashMap(voxel, 100.0, 20)
+    g.add_points(world)
+    out = {}
+    try:
+        for wide in (0, 1):
+            _cabi.set_option("icp_wide", wide)
+            for own in (1, 0):
+                _cabi.set_option("icp_weights_kernel", own)
+                r = Registration(500, 1e-5)
+                out[wide, own] = (r.align_points_to_map(src, g, guess, 3.0 * voxel, voxel), dict(r.last_stats))
+        _cabi.set_option("icp_wide", -1)
+        ds = generate_scans(kitti_like_vegetated, dict(seed=0, n_frames=8), range(8), processes=1)  # (the bench's scene: ~4 k source points)
+        for own in (1, 0):
+            _cabi.set_option("icp_weights_kernel", own)
+            k = _pipe(deskew=False)
+            for i in range(8):
+                k.register_frame_async(ds[i][0])
+            k.sync()
+            out["pipe", own] = (k.synced_poses(), k.last_stats()["icp"], k.output(1))
+    finally:
+        for name, v in (("icp_weights_kernel", 1), ("icp_wide", -1)):
+            _cabi.set_option(name, v)
+    for wide in (0, 1):
+        assert np.array_equal(out[wide, 1][0], out[wide, 0][0]), wide
+        assert np.array_equal(out[wide, 1][0], out[0, 1][0]), wide
+        for key in ("iterations", "n_corr_last", "n_corr_total", "points_examined"):
+            assert out[wide, 1][1][key] == out[wide, 0][1][key], (wide, key)
+    assert out[0, 1][1]["iterations"] >= 4
+    assert np.array_equal(out["pipe", 1][0], out["pipe", 0][0])
+    assert out["pipe", 1][1] == out["pipe", 0][1]
+    assert np.array_equal(out["pipe", 1][2], out["pipe", 0][2])
+    assert out["pipe", 1][1]["n_source"] >= 2048, out["pipe", 1][1]  # (the pipeline's clouds were cut by weight too)
+
+
+@pytest.mark.parametrize("kind", ["full_voxels", "small_voxels"])
 @pytest.mark.parametrize("blocks", [0, 1, 16])
 def test_flat_voxel_service_is_bitwise_neutral(gpu, O, kind, blocks):
     """icp_wide_flat: the queued voxels of the thread-per-query form read by a thread per POINT, the minima settled by LDS
