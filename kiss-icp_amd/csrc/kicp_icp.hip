@@ -81,6 +81,9 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     double terms[kIcpTermChunk][kIcpTerms];  // phase C: the products of kIcpTermChunk points
     IcpPoint pts[kIcpChunk];
 };
+static_assert(offsetof(IcpShared, part) % 16 == 0 && offsetof(IcpShared, range_sum) % 16 == 0 && offsetof(IcpShared, terms) % 16 == 0 &&
+                  (kIcpTerms * sizeof(double)) % 16 == 0,
+              "rows that are read and written sixteen bytes at a time (icp_row_sum, phase C)");
 static_assert(sizeof(IcpShared) % 16 == 0 && offsetof(IcpShared, pts) % 16 == 0 && sizeof(IcpPoint) % 16 == 0,
               "the query records behind the point slots must stay 16-byte aligned");
 
@@ -817,6 +820,50 @@ __device__ __forceinline__ void icp_runs_from_weights(const unsigned *wts32, Icp
 }  // namespace kicp
 #include "kicp_icp_wide.hpp"
 namespace kicp {
+
+// One scalar's fixed-order sum over the (at most 16) rows of a reduction stage.  The stage's values lie TRANSPOSED in LDS -- row k =
+// the sixteen contributions to scalar k, 128 contiguous bytes -- so that the thread of scalar k has all of them in flight at once
+// (eight 16-byte loads, one round trip) and adds them from registers: v = ((0 + a0) + a1) + ... over the first `count`, the same
+// additions in the same order as a loop over the contributors, only without a dependent LDS round trip per addend (8 - 16 of
+// them per stage and three stages per iteration: ~2 us of every Gauss-Newton step, profiles/r06_n_*).  Entries beyond `count` are
+// stale; their sums are formed and dropped.  The profiling build's tick slot is max-reduced instead.
+template <bool PROF>
+__device__ __forceinline__ double icp_row_sum(const double *row, int count, bool tick) {
+    const double2 *r2 = reinterpret_cast<const double2 *>(row);
+    double a[kIcpSumRows];
+#pragma unroll
+    for (int i = 0; i < kIcpSumRows / 2; ++i) {
+        const double2 t = r2[i];
+        a[2 * i] = t.x;
+        a[2 * i + 1] = t.y;
+    }
+    double v = 0.0;
+    // (the count is uniform and goes through an empty asm statement: left alone, the compiler forms the sixteen masks "j < count"
+    // ahead of k_icp's iteration loop and keeps them in scalar registers it does not have)
+    count = __builtin_amdgcn_readfirstlane(count);
+    asm volatile("" : "+s"(count));
+    if (count == kIcpSumRows) {
+#pragma unroll
+        for (int j = 0; j < kIcpSumRows; ++j) v = v + a[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kIcpSumRows; ++j) {
+            const double w = v + a[j];
+            v = j < count ? w : v;
+        }
+    }
+    if constexpr (PROF) {
+        if (tick) {
+            v = 0.0;
+#pragma unroll
+            for (int j = 0; j < kIcpSumRows; ++j) v = j < count ? fmax(v, a[j]) : v;
+        }
+    } else {
+        v = tick ? 0.0 : v;  // (nobody fills that row in the release build)
+    }
+    return v;
+}
+static_assert(kIcpSumRows == 16 && kIcpGroupsPerBlock == 16 && kIcpExchangeGroups <= 16 && kIcpMaxMembers <= 16, "icp_row_sum's rows hold sixteen contributions");
 
 // The solve of one Gauss-Newton step (Registration.cpp:156-157) on the sixteen sums: dx = LDLT(JTJ).solve(-JTr) -- through the
 // 3 x 3 Schur complement when that is well conditioned (kicp_math.hpp), else the reference's pivoted LDLT --, est = SE3::exp(dx);
@@ -1700,20 +1747,29 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         for (int base = 0; base < n_local; base += kIcpChunk) {
             const int cn = min(kIcpChunk, n_local - base);
             // ---- A -------------------------------------------------------------------------------------
+            // (One wave's instruction stream on every workgroup's critical path: everything it needs from LDS -- the query's record,
+            // what its last search left in the point slot -- is asked for at the top, in one round trip, and the tests are formed
+            // without short-circuits; read field by field under its conditions the phase was ~25 dependent LDS round trips,
+            // ~1 us of its 1.5: profiles/r06_n_*.  Values that are read before anything has written them -- the first
+            // iteration's -- only ever reach selects that drop them.)
             if (tid < cn) {
                 const int j = base + tid;
                 const bool has_meta = j < n_meta;
+                IcpQueryMeta *meta = metas + (has_meta ? j : 0);
+                IcpPoint &pt = sh.pts[tid];
+                IcpQueryMeta M;
+                __builtin_memcpy(&M, __builtin_assume_aligned(meta, 16), sizeof M);
+                const double last_d2 = pt.d2, last_nn0 = pt.nn[0], last_nn1 = pt.nn[1], last_nn2 = pt.nn[2];
                 // (the point's index in the cloud: only where the cloud or the work array is touched -- a global load on the path
                 // of every iteration otherwise)
                 int p = 0;
-                if (it == 0 || !has_meta) p = KICP_IDX(m.dbg, &st->err, P.order ? key_index(P.order[q0 + j]) : q0 + j, n, 4);
-                IcpQueryMeta *meta = metas + (has_meta ? j : 0);
                 double pin[3];
                 if (it > 0 && has_meta) {  // running source point lives in LDS
-                    pin[0] = meta->s[0];
-                    pin[1] = meta->s[1];
-                    pin[2] = meta->s[2];
+                    pin[0] = M.s[0];
+                    pin[1] = M.s[1];
+                    pin[2] = M.s[2];
                 } else {
+                    p = KICP_IDX(m.dbg, &st->err, P.order ? key_index(P.order[q0 + j]) : q0 + j, n, 4);
                     const double *src = (it == 0) ? P.frame : P.work;
                     pin[0] = src[3 * p];
                     pin[1] = src[3 * p + 1];
@@ -1723,32 +1779,26 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 se3_act(est, pin, s);
                 const int vx = voxel_coord_fast(s[0], m.voxel_size, inv_voxel), vy = voxel_coord_fast(s[1], m.voxel_size, inv_voxel),
                           vz = voxel_coord_fast(s[2], m.voxel_size, inv_voxel);
-                bool cached = false;
-                if (has_meta && meta->valid > 0)  // is the 27-neighbourhood of (vx, vy, vz) inside the known window?
-                    cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
-                             meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
-                             meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
-                IcpPoint &pt = sh.pts[tid];
+                // is the 27-neighbourhood of (vx, vy, vz) inside the known window?
+                const int rx = vx - M.v[0], ry = vy - M.v[1], rz = vz - M.v[2];
+                const bool cached = has_meta & (M.valid > 0) & ((int)M.lo[0] <= rx - 1) & (rx + 1 <= (int)M.hi[0]) & ((int)M.lo[1] <= ry - 1) &
+                                    (ry + 1 <= (int)M.hi[1]) & ((int)M.lo[2] <= rz - 1) & (rz + 1 <= (int)M.hi[2]);
                 // STABILITY (IcpQueryMeta::L2).  The query's last search, made from this very voxel, left its neighbour and count in
                 // this point slot (a run with lists is a single chunk: the slot is this query's through the launch), the position it
                 // was made from, and the second smallest squared distance over the 27 cells.  While the neighbour's new distance
                 // plus the way from there to here stays strictly below that runner-up's distance, the neighbour is still the unique
                 // minimum the reference's strict '<' loops would find (VoxelHashMap.cpp:55-63), with the same points examined: no
                 // search, and the distance is computed here -- by the expression the search uses, so the bits are the search's.
-                bool stable = false;
-                if (use_stable && it > 0 && cached && meta->lr_state == 1 && meta->lv[0] == vx && meta->lv[1] == vy && meta->lv[2] == vz) {
-                    if (pt.d2 < DBL_MAX) {  // (DBL_MAX: the 27 cells hold no candidate at all -- and never will)
-                        const double mx = s[0] - meta->ss[0], my = s[1] - meta->ss[1], mz = s[2] - meta->ss[2];
-                        const double b2 = (mx * mx + my * my) + mz * mz;
-                        const double ex = pt.nn[0] - s[0], ey = pt.nn[1] - s[1], ez = pt.nn[2] - s[2];
-                        const double dp = (ex * ex + ey * ey) + ez * ez;  // (as the search computes it)
-                        const double R = (meta->L2 - dp) - b2;
-                        stable = R > 0.0 && (4.0 * (1.0 + 0x1p-20)) * (dp * b2) < R * R;
-                        if (stable) pt.d2 = dp;
-                    } else {
-                        stable = true;
-                    }
-                }
+                const bool may_stay = use_stable & (it > 0) & cached & (M.lr_state == 1) & (M.lv[0] == vx) & (M.lv[1] == vy) & (M.lv[2] == vz);
+                const bool has_nn = last_d2 < DBL_MAX;  // (DBL_MAX: the 27 cells hold no candidate at all -- and never will)
+                const double mx = s[0] - M.ss[0], my = s[1] - M.ss[1], mz = s[2] - M.ss[2];
+                const double b2 = (mx * mx + my * my) + mz * mz;
+                const double ex = last_nn0 - s[0], ey = last_nn1 - s[1], ez = last_nn2 - s[2];
+                const double dp = (ex * ex + ey * ey) + ez * ez;  // (as the search computes it)
+                const double R = (M.L2 - dp) - b2;
+                const bool holds = (R > 0.0) & ((4.0 * (1.0 + 0x1p-20)) * (dp * b2) < R * R);
+                const bool stable = may_stay & (holds | !has_nn);
+                if (stable & has_nn) pt.d2 = dp;
                 if (has_meta) {
                     meta->s[0] = s[0];
                     meta->s[1] = s[1];
@@ -1765,9 +1815,18 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 pt.v[0] = vx;
                 pt.v[1] = vy;
                 pt.v[2] = vz;
-                pt.flag = stable ? 3 : (cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2));
-                if (pt.flag == 1) sh.any_fill = 1;
-                if (!stable) sh.search_idx[atomicAdd(&sh.search_count, 1)] = (unsigned char)tid;
+                const int flag = stable ? 3 : (cached ? 0 : ((has_meta & (M.valid >= 0)) ? 1 : 2));
+                pt.flag = flag;
+                if (flag == 1) sh.any_fill = 1;
+                // the points that need a search file themselves: a chunk of one wave (the rule) by its ballot, without the round trip
+                // of an atomic per point
+                if (cn <= 64) {
+                    const unsigned long long need = __ballot(!stable);
+                    if (!stable) sh.search_idx[__popcll(need & ((1ull << tid) - 1ull))] = (unsigned char)tid;
+                    if (tid == 0) sh.search_count = __popcll(need);
+                } else if (!stable) {
+                    sh.search_idx[atomicAdd(&sh.search_count, 1)] = (unsigned char)tid;
+                }
                 if (it == 0 && j == 0) {  // the tile's relative voxel coordinates are centred on the run's first point
                     sh.origin[0] = vx - kTileSpanXY / 2;
                     sh.origin[1] = vy - kTileSpanXY / 2;
@@ -1916,10 +1975,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             for (int sub = 0; sub < cn; sub += kIcpTermChunk) {
                 const int sn = min(kIcpTermChunk, cn - sub);
                 if (tid < sn) {
-                    const IcpPoint &pt = sh.pts[sub + tid];
+                    // (the point slot in one round trip, the row of products written once, from registers)
+                    IcpPoint pt;
+                    __builtin_memcpy(&pt, __builtin_assume_aligned(&sh.pts[sub + tid], 16), sizeof pt);
                     const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
                     const double d2 = pt.d2;
-                    double *T = terms[tid];
+                    double T[kIcpTerms];
 #pragma unroll
                     for (int k = 0; k < 17; ++k) T[k] = 0.0;
                     T[17] = (double)pt.E;
@@ -1947,11 +2008,26 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         T[15] = w * (s[0] * ry - s[1] * rx);
                         T[16] = 1.0;
                     }
+                    double2 *row = reinterpret_cast<double2 *>(terms[tid]);  // (144 bytes per row: 16-byte aligned)
+#pragma unroll
+                    for (int k = 0; k < kIcpTerms / 2; ++k) row[k] = make_double2(T[2 * k], T[2 * k + 1]);
                 }
                 __syncthreads();
-                if (cg < kIcpGroupsPerBlock)
-                    for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += terms[i][ck];
-                __syncthreads();
+                if (cg < kIcpGroupsPerBlock) {
+                    // term ck of the points cg, cg + 16, ... in that order: all (at most four) asked for together
+                    double a[kIcpTermChunk / kIcpGroupsPerBlock];
+#pragma unroll
+                    for (int u = 0; u < kIcpTermChunk / kIcpGroupsPerBlock; ++u) {
+                        const int i = cg + u * kIcpGroupsPerBlock;
+                        a[u] = terms[i < sn ? i : cg][ck];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kIcpTermChunk / kIcpGroupsPerBlock; ++u) {
+                        const double w = acc + a[u];
+                        acc = cg + u * kIcpGroupsPerBlock < sn ? w : acc;
+                    }
+                }
+                if (sub + kIcpTermChunk < cn) __syncthreads();  // (the rows are the next sub-chunk's; behind the last one the reduction's barrier follows)
             }
         }
         if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters) {
@@ -1962,20 +2038,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         }
         // ---- workgroup reduction (fixed order) ----------------------------------------------
         const unsigned c1 = PROF ? ticks32() : 0u;
-        if (cg < kIcpGroupsPerBlock) sh.part[cg][ck] = acc;
-        if (lane == 0) sh.part[grp][kIcpTickSlot] = (double)t_group;  // this group's search time (profiling, max-reduced)
+        // (the stages' values lie transposed -- [scalar][contributor] --: icp_row_sum)
+        double *const part_t = &sh.part[0][0], *const sums_t = &sh.range_sum[0][0];
+        if (cg < kIcpGroupsPerBlock) part_t[ck * kIcpSumRows + cg] = acc;
+        if (PROF && lane == 0) part_t[kIcpTickSlot * kIcpSumRows + grp] = (double)t_group;  // this group's search time (profiling, max-reduced)
         __syncthreads();
         const unsigned epoch = epoch_base + (unsigned)it + 1u;
         unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpSums);
         const __amdgpu_buffer_rsrc_t gran_rsrc = granule_rsrc(gran, (unsigned)(G * 2 * kIcpSums * sizeof(unsigned long long)));
         if (tid < kIcpSums) {
             const int k = tid;
-            double v = 0.0;
-#pragma unroll
-            for (int g = 0; g < kIcpGroupsPerBlock; ++g) {
-                const double pv = sh.part[g][k];
-                v = (k == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-            }
+            const double v = icp_row_sum<PROF>(part_t + k * kIcpSumRows, kIcpGroupsPerBlock, k == kIcpTickSlot);
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + k) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
         }
@@ -2013,16 +2086,12 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     const int b = (int)blockIdx.x + ng * j;
                     double v = 0.0;
                     if (!poll_pair(gran_rsrc, (unsigned)(((size_t)b * kIcpSums + k) * 16), v)) sh.fail = 1;
-                    sh.range_sum[j][k] = v;
+                    sums_t[k * kIcpSumRows + j] = v;
                 }
             }
             __syncthreads();
             if (tid < kIcpSums && !sh.fail) {
-                double v = 0.0;
-                for (int j = 0; j < members; ++j) {  // member order: fixed by G alone
-                    const double pv = sh.range_sum[j][tid];
-                    v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-                }
+                const double v = icp_row_sum<PROF>(sums_t + tid * kIcpSumRows, members, tid == kIcpTickSlot);  // member order: fixed by G alone
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
                 granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
             }
@@ -2032,16 +2101,20 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // slowed exactly those (their overflow voxels are read from L2 / HBM): measured, profiles/r03_g.  ONE lane per
         // group watches the group's first granule pair; its 19 pairs leave the leader in one store instruction, so
         // when the first has arrived the sweep below finds the rest (and polls on for any that has not).
-        if (tid < ng && !sh.fail) {
-            double dummy;
-            if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpSums) * 16), dummy)) sh.fail = 1;
+        // (kIcpPollAll: no watchers, every lane of the sweep polls its own pair from the start -- one round trip less once the sums
+        // are there, ng x 19 polling lanes per workgroup until then: a build-time switch for A/Bs, profiles/r06_o_*)
+        if (!kIcpPollAll) {
+            if (tid < ng && !sh.fail) {
+                double dummy;
+                if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpSums) * 16), dummy)) sh.fail = 1;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int e = tidv; e < ng * kIcpSums && !sh.fail; e += kIcpThreads) {
             const int k = e % kIcpSums, g = e / kIcpSums;
             double v = 0.0;
             if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpSums + k) * 16), v)) sh.fail = 1;
-            sh.range_sum[g][k] = v;
+            sums_t[k * kIcpSumRows + g] = v;
         }
         __syncthreads();
         if (sh.fail) {
@@ -2050,14 +2123,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             failed = true;
             break;
         }
-        if (tid < kIcpSums) {
-            double v = 0.0;
-            for (int g = 0; g < ng; ++g) {
-                const double pv = sh.range_sum[g][tid];
-                v = (tid == kIcpTickSlot) ? fmax(v, pv) : v + pv;
-            }
-            sh.tot[tid] = v;
-        }
+        if (tid < kIcpSums) sh.tot[tid] = icp_row_sum<PROF>(sums_t + tid * kIcpSumRows, ng, tid == kIcpTickSlot);
         __syncthreads();
         // ---- waves 0..3 (one per SIMD) of EVERY workgroup solve the same system; the result goes through LDS -----
         const unsigned c3 = PROF ? ticks32() : 0u;

@@ -523,13 +523,25 @@ static_assert(kIcpTileSlots == 4096, "hash_shift is derived from 4096 / 2048 slo
 // slot of a key or -1 (LDS loads; other waves may be inserting: relaxed workgroup-scope atomics keep the
 // compiler from caching them)
 constexpr int kTileMaxProbes = 32;  // the table is kept at most 3/4 full; a chain this long means "not here"
+// (four slots of the chain per round trip, resolved in chain order: a miss in a table that is 3/4 full walks 8 slots on
+// average, and the slowest of a group's 27 lanes is what a scan-list build waits for)
+constexpr int kTileProbeAhead = 4;
+static_assert(kTileMaxProbes % kTileProbeAhead == 0, "tile_find's rounds");
 __device__ __forceinline__ int tile_find(const Tile &t, unsigned key) {
     unsigned s = tile_hash(t, key);
-    for (int probes = 0; probes < kTileMaxProbes; ++probes) {
-        const unsigned k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == key) return (int)s;
-        if (k == kTileEmpty) return -1;
-        s = (s + 1) & (unsigned)t.slots_mask;
+    for (int probes = 0; probes < kTileMaxProbes; probes += kTileProbeAhead) {
+        unsigned k[kTileProbeAhead];
+#pragma unroll
+        for (int u = 0; u < kTileProbeAhead; ++u)
+            k[u] = __hip_atomic_load(&t.keys[(s + (unsigned)u) & (unsigned)t.slots_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int res = -2;  // undecided
+#pragma unroll
+        for (int u = 0; u < kTileProbeAhead; ++u) {
+            const int here = k[u] == key ? (int)((s + (unsigned)u) & (unsigned)t.slots_mask) : (k[u] == kTileEmpty ? -1 : -2);
+            res = res == -2 ? here : res;
+        }
+        if (res != -2) return res;
+        s = (s + (unsigned)kTileProbeAhead) & (unsigned)t.slots_mask;
     }
     return -1;
 }
