@@ -1717,8 +1717,25 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         }
                     }
                     __syncthreads();
-                    if (cg < kIcpGroupsPerBlock)
-                        for (int i = cg; i < sn; i += kIcpGroupsPerBlock) acc += rows[i][ck];
+                    if (cg < kIcpGroupsPerBlock) {
+                        // term ck of the points cg, cg + 16, ... in that order, four asked for together (eight: this form's registers
+                        // are all taken, the kernel spills)
+                        constexpr int kPer = 4;
+                        static_assert((kWideTermRows / kIcpGroupsPerBlock) % kPer == 0, "phase C's batches");
+                        for (int i0 = cg; i0 < sn; i0 += kPer * kIcpGroupsPerBlock) {
+                            double a[kPer];
+#pragma unroll
+                            for (int u = 0; u < kPer; ++u) {
+                                const int i = i0 + u * kIcpGroupsPerBlock;
+                                a[u] = rows[i < sn ? i : cg][ck];
+                            }
+#pragma unroll
+                            for (int u = 0; u < kPer; ++u) {
+                                const double w = acc + a[u];
+                                acc = i0 + u * kIcpGroupsPerBlock < sn ? w : acc;
+                            }
+                        }
+                    }
                     __syncthreads();
                 }
                 if (PROF) prof_c = ticks32() - tc0;
@@ -2097,12 +2114,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
             __syncthreads();  // range_sum is reused below
         }
-        // Few pollers: 224 workgroups x 152 lanes re-reading the group sums while the slowest workgroups still search
-        // slowed exactly those (their overflow voxels are read from L2 / HBM): measured, profiles/r03_g.  ONE lane per
-        // group watches the group's first granule pair; its 19 pairs leave the leader in one store instruction, so
-        // when the first has arrived the sweep below finds the rest (and polls on for any that has not).
-        // (kIcpPollAll: no watchers, every lane of the sweep polls its own pair from the start -- one round trip less once the sums
-        // are there, ng x 19 polling lanes per workgroup until then: a build-time switch for A/Bs, profiles/r06_o_*)
+        // Round 3's form (kIcpPollAll = false) had FEW pollers: ONE lane per group watched the group's first granule pair -- its 19
+        // pairs leave the leader in one store instruction --, then a sweep fetched the rest: 224 workgroups x 152 lanes re-reading
+        // the group sums while the slowest workgroups still searched had slowed exactly those (their overflow voxels came from
+        // L2 / HBM then: profiles/r03_g).  Since the stability shortcut the later iterations' few searches run out of LDS, and the
+        // watchers cost a memory round trip and a barrier per iteration: every lane of the sweep polls its own pair from the
+        // start -- a later iteration 9.9 -> 9.5 us (steady map), 9.0 -> 8.5 (young), +3 % on both bench commands, same box
+        // (profiles/r06_o_*).
         if (!kIcpPollAll) {
             if (tid < ng && !sh.fail) {
                 double dummy;

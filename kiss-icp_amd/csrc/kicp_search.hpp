@@ -525,6 +525,7 @@ static_assert(kIcpTileSlots == 4096, "hash_shift is derived from 4096 / 2048 slo
 constexpr int kTileMaxProbes = 32;  // the table is kept at most 3/4 full; a chain this long means "not here"
 // (four slots of the chain per round trip, resolved in chain order: a miss in a table that is 3/4 full walks 8 slots on
 // average, and the slowest of a group's 27 lanes is what a scan-list build waits for)
+constexpr bool kScanPrefetch = true;  // tile_scan_list (a build-time switch for A/Bs; neutral to +0.5 %: profiles/r06_o_*)
 constexpr int kTileProbeAhead = 4;
 static_assert(kTileMaxProbes % kTileProbeAhead == 0, "tile_find's rounds");
 __device__ __forceinline__ int tile_find(const Tile &t, unsigned key) {
@@ -1000,12 +1001,22 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
     // masked out of the comparison.
     double best = DBL_MAX, sec = DBL_MAX;
     int bi = 0x7FFFFFFF;
-    for (int i0 = lane; __ballot(i0 < n) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
-        int pos[U];
+    // (kScanPrefetch: a trip's list entries are asked for during the trip before it -- one LDS round trip per trip instead of two)
+    int pos[U];
+    if (kScanPrefetch) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + 32 * u;
+            const int i = lane + 32 * u;
             pos[u] = (int)I[i < n ? i : 0];
+        }
+    }
+    for (int i0 = lane; __ballot(i0 < n) != 0ull; i0 += 32 * U) {  // wave-uniform trip count
+        if (!kScanPrefetch) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 32 * u;
+                pos[u] = (int)I[i < n ? i : 0];
+            }
         }
         double x[U], y[U], z[U];
 #pragma unroll
@@ -1015,6 +1026,13 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
             x[u] = q[0];
             y[u] = q[1];
             z[u] = q[2];
+        }
+        if (kScanPrefetch) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 32 * U + 32 * u;
+                pos[u] = (int)I[i < n ? i : 0];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
