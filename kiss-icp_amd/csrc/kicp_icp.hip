@@ -715,12 +715,22 @@ __device__ __forceinline__ int icp_grid_of(int n, int force_blocks, int points_p
     return max(1, min(G, grid));
 }
 __global__ __launch_bounds__(256) void k_icp_weights(IcpWeightArgs A) {
+    // (what the tests below need from memory is asked for in front of them, in one round trip: k_icp's prologue, and why)
     const int n = count_of(A.n_ptr, A.n_imm);
+    const int live0 = A.map.ctr[C_LIVE];
+    const int err0 = __hip_atomic_load(&A.state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SE3 pose_a, pose_b;
+    if (A.pipeline_mode) {
+        pose_a = A.state->last_pose;
+        pose_b = A.state->last_delta;
+    } else {
+        pose_a = pose_b = A.state->guess;
+    }
     const int G = icp_grid_of(n, A.force_blocks, A.points_per_group, A.icp_grid);
     // (the cases in which k_icp does not cut weighted runs, or cuts long ones by its own prologue)
-    if (n < kIcpWeightedMin || A.force_blocks > 0 || n > kIcpListRunMax * G || A.map.ctr[C_LIVE] == 0) return;
-    if (__hip_atomic_load(&A.state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) return;
-    const SE3 guess = A.pipeline_mode ? se3_mul(A.state->last_pose, A.state->last_delta) : A.state->guess;  // (k_icp's own expression)
+    if (n < kIcpWeightedMin || A.force_blocks > 0 || n > kIcpListRunMax * G || live0 == 0) return;
+    if (err0 & E_TIMEOUT) return;
+    const SE3 guess = A.pipeline_mode ? se3_mul(pose_a, pose_b) : pose_a;  // (k_icp's own expression)
     const int quad = A.weight_quad >= 0 ? A.weight_quad : 10;
     const int lane = threadIdx.x & (kIcpGroup - 1);
     const int groups = (int)(gridDim.x * blockDim.x) / kIcpGroup;
@@ -775,8 +785,15 @@ __device__ __forceinline__ void icp_runs_from_weights(const unsigned *wts32, Icp
     // thread t takes the contiguous piece [t per, (t + 1) per): its sum, then the exclusive prefix of the 512 sums
     const int per = (n + kIcpThreads - 1) / kIcpThreads;
     const int a = min(n, tid * per), b = min(n, a + per);
+    // (a thread's piece four words per round trip, here and below: ten dependent ones per loop otherwise)
     long long mine = 0;
-    for (int i = a; i < b; ++i) mine += (long long)w[i];
+    for (int i = a; i < b; i += 4) {
+        unsigned x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = w[i + u < b ? i + u : a];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mine += i + u < b ? (long long)x[u] : 0ll;
+    }
     long long incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -798,10 +815,17 @@ __device__ __forceinline__ void icp_runs_from_weights(const unsigned *wts32, Icp
     const long long t0 = (long long)blockIdx.x * W, t1 = ((long long)blockIdx.x + 1) * W;
     long long E = before + incl - mine;
     int c0 = 0, c1 = 0;
-    for (int i = a; i < b; ++i) {
-        c0 += (E * (long long)G < t0) ? 1 : 0;
-        c1 += (E * (long long)G < t1) ? 1 : 0;
-        E += (long long)w[i];
+    for (int i = a; i < b; i += 4) {
+        unsigned x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = w[i + u < b ? i + u : a];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = i + u < b;
+            c0 += (in && E * (long long)G < t0) ? 1 : 0;
+            c1 += (in && E * (long long)G < t1) ? 1 : 0;
+            E += in ? (long long)x[u] : 0ll;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -936,23 +960,40 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const MapView &m = P.map;
     PipeState *st = P.state;
 
+    // Everything the prologue needs from memory -- the error word, the cloud's size, the map's population, the state the initial
+    // guess and the threshold come from -- is asked for HERE, before the first test: one round trip.  Read where it was used,
+    // behind one early exit after the other, it was six dependent ones (~5 us of the first iteration: profiles/r06_q_*).
+    const int err0 = __hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = count_of(P.n_ptr, P.n_imm);
+    const int live0 = m.ctr[C_LIVE];
+    const unsigned epoch_base = st->epoch_base;
+    SE3 pose_a, pose_b;  // pipeline: last_pose, last_delta; else: the caller's guess (twice)
+    double sse0 = 0.0;
+    int samples0 = 1;
+    if (P.pipeline_mode) {
+        pose_a = st->last_pose;
+        pose_b = st->last_delta;
+        sse0 = st->model_sse;
+        samples0 = st->num_samples;
+    } else {
+        pose_a = pose_b = st->guess;
+    }
     // a frame whose registration timed out (workgroups not co-resident) poisons the frames queued behind
     // it: they leave the state untouched so that the host can replay from the failed frame
-    if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) {
+    if (err0 & E_TIMEOUT) {
         // (workgroup 0 advances the tag base on EVERY path it can leave by -- also when it only started after the others
         // had given up: the replay must never meet granules that carry this launch's tags)
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->epoch_base = st->epoch_base + (unsigned)P.max_iters + 2u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
         return;
     }
     if (P.inject_timeout) {  // test hook: what a launch that never became co-resident leaves behind
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicOr(&st->err, E_TIMEOUT);
-            st->epoch_base = st->epoch_base + (unsigned)P.max_iters + 2u;
+            st->epoch_base = epoch_base + (unsigned)P.max_iters + 2u;
         }
         return;
     }
     const unsigned long long launch_cyc = clock64(), launch_tick = wall_clock64();
-    const int n = count_of(P.n_ptr, P.n_imm);
     // How many of the launched workgroups take part is decided here, from the actual N_src, so the
     // summation order (hence the result, bit for bit) never depends on host-side hints.
     int G = P.force_blocks > 0 ? P.force_blocks
@@ -967,17 +1008,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     double max_dist, ks;
     if (P.pipeline_mode) {
         // KissICP.cpp:44-47: sigma = ComputeThreshold(); initial_guess = last_pose * last_delta
-        const double sigma = sqrt(st->model_sse / (double)st->num_samples);
-        guess = se3_mul(st->last_pose, st->last_delta);
+        const double sigma = sqrt(sse0 / (double)samples0);
+        guess = se3_mul(pose_a, pose_b);
         max_dist = 3.0 * sigma;
         ks = sigma;
     } else {
-        guess = st->guess;
+        guess = pose_a;
         max_dist = P.max_dist;
         ks = P.kernel_scale;
     }
-    const unsigned epoch_base = st->epoch_base;
-    const bool map_empty = (m.ctr[C_LIVE] == 0);  // Registration.cpp:143 (nothing to align to: no iteration, no exchange, no runs)
+    const bool map_empty = (live0 == 0);  // Registration.cpp:143 (nothing to align to: no iteration, no exchange, no runs)
     int q0, n_local;
     if (P.wts32 && P.wts && P.order && n >= kIcpWeightedMin && P.force_blocks <= 0 && !map_empty && n <= kIcpListRunMax * G) {
         // (k_icp_weights has weighed the points: exactly the condition under which it does)
@@ -1910,13 +1950,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 int E = 0;
                 bool listed = false;
                 bool tie = false;  // the fast search's answer may not be the reference's: a tie in NORM (kicp_search.hpp) -- settled below
+                unsigned t_build = 0u;  // (profiling: the list build's share of the search, later iterations)
                 if (flag == 0 && !listed && use_lists && meta->list_state >= 0) {
                     // the scan list belongs to the voxel the query was in when it was built
                     // (Round 6 tried NOT rebuilding the list of a query that has entered another voxel -- with the stability shortcut it
                     // is searched once there, as a rule -- and sending it through the lane-per-voxel search instead: that search
                     // is 5 us where build + list scan are 3.4, on the critical path of the iteration: profiles/r06_d_ab_*.txt.)
-                    if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz)
+                    if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz) {
+                        const unsigned t0 = PROF ? ticks32() : 0u;
                         tile_list_build(tile, vx, vy, vz, lane, meta);
+                        if (PROF) t_build = ticks32() - t0;
+                    }
                     if (meta->list_state == 1) {
                         E = meta->list_n;
                         double sec2 = DBL_MAX;
@@ -1974,7 +2018,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     // per-group record of this iteration (10 ns ticks): where the group's time went
                     unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
                                                    (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
-                    r[0] = (unsigned)(tb0 - c0) | ((unsigned)(tb - tb0) << 16);  // phase A + barrier, wait inside B
+                    r[0] = (unsigned)(tb0 - c0) | ((it > 0 ? t_build : (unsigned)(tb - tb0)) << 16);  // phase A + barrier; wait inside B (first iteration) / list build (later ones)
                     if (it == 0 && P.bulk_fill && grp < 5) r[0] = (r[0] & 0xFFFFu) | (min(sh.bulk_ticks[grp], 0xFFFFu) << 16);  // groups 0..4: tile_fill_bulk's phases instead
                     r[1] = (unsigned)min(t_fill, 0xFFFFu) | ((unsigned)(td - tc) << 16);  // window phase of the chunk, search
                     r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)E << 16);  // points in the tile so far, examined

@@ -47,6 +47,14 @@ if gp.size:
         for j, nm in enumerate(names):
             print('   %-8s mean %6.2f  p50 %6.2f  p99 %6.2f  max %6.2f us' % (
                 nm, g[:, j].mean() / 100, np.percentile(g[:, j], 50) / 100, np.percentile(g[:, j], 99) / 100, g[:, j].max() / 100))
+        if it > 0 and (g[:, 6] == 1).any():
+            # group form, later iterations: the 'xform' field of a searching group carries its scan-list BUILD (0: the list stood)
+            sg = g[g[:, 6] == 1]
+            b = sg[:, 1] > 0
+            print('   searches by scan list: %d, of them with a list build %d (build mean %.2f max %.2f us; search incl. build mean %.2f max %.2f); without: search mean %.2f max %.2f us' % (
+                len(sg), int(b.sum()), sg[b, 1].mean() / 100 if b.any() else 0, sg[b, 1].max() / 100 if b.any() else 0,
+                sg[b, 3].mean() / 100 if b.any() else 0, sg[b, 3].max() / 100 if b.any() else 0,
+                sg[~b, 3].mean() / 100 if (~b).any() else 0, sg[~b, 3].max() / 100 if (~b).any() else 0))
         gc = g.reshape(-1, 16, g.shape[1])[:, [0, 10], :].reshape(-1, g.shape[1]) if (g[:, 6] == 4).all() else g  # (thread-per-query form: the other groups' records carry counters)
         print('   staged   mean %6.1f  max %d   examined mean %6.1f max %d' % (gc[:, 4].mean(), gc[:, 4].max(), gc[:, 5].mean(), gc[:, 5].max()))
         if (g[:, 6] == 4).all():
