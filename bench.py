@@ -157,6 +157,45 @@ def cpu_baseline(scans, warmup, steps, cfg, thread_counts=None):
     return best, detail
 
 
+def cpu_baseline_native(scans, warmup, steps, cfg, threads):
+    """the same sample on the oracle built with -march=native for THIS box's host (SURVEY.md section 8d names the flag; the
+    reference's own Release build is generic).  Compiled here, at run time, into a temporary directory -- a library built for
+    the build container's CPU may not run on this one -- and timed in a child process (the checker's library is already
+    loaded in this one).  Returns {"value", "flags"} or {"error"}: a reported figure, never a reason for the bench to fail."""
+    import pickle
+    import shutil
+    import subprocess
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="kicp_native_")
+    try:
+        lib = os.path.join(tmp, "libkiss_oracle_native.so")
+        flags = ["-O3", "-march=native", "-std=c11", "-fopenmp", "-ffp-contract=off", "-fPIC"]
+        subprocess.run(["gcc"] + flags + ["-shared", "-o", lib, os.path.join(ROOT, "oracle", "kiss_oracle.c"), "-lm"],
+                       check=True, capture_output=True, timeout=120)
+        kw = dict(cfg)
+        kw["deskew"] = int(kw.get("deskew", False))
+        with open(os.path.join(tmp, "job.pkl"), "wb") as f:
+            pickle.dump({"scans": [(a, b) for a, b in scans[:warmup + steps]], "warmup": warmup, "steps": steps, "threads": threads, "cfg": kw}, f)
+        child = (
+            "import pickle, sys, time, json\n"
+            "sys.path.insert(0, %r)\n"
+            "from oracle import oracle as O\n"
+            "j = pickle.load(open(%r, 'rb'))\n"
+            "k = O.KissICP(max_num_threads=j['threads'], **j['cfg'])\n"
+            "for i in range(j['warmup']): k.register_frame_noout(*j['scans'][i])\n"
+            "t0 = time.perf_counter()\n"
+            "for i in range(j['warmup'], j['warmup'] + j['steps']): k.register_frame_noout(*j['scans'][i])\n"
+            "print(json.dumps({'scans_per_s': j['steps'] / (time.perf_counter() - t0)}))\n" % (ROOT, os.path.join(tmp, "job.pkl")))
+        env = dict(os.environ, KISS_ORACLE_LIB=lib)
+        r = subprocess.run([sys.executable, "-c", child], check=True, capture_output=True, text=True, timeout=600, env=env)
+        return {"value": json.loads(r.stdout.strip().splitlines()[-1])["scans_per_s"], "cores": threads, "flags": " ".join(flags)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def host_communicator(n_ranks, device):
     """a kicp_batch_comm that moves the blocks through host memory with the C-ABI's own device copies: for N streams
     stacked on ONE device (a plumbing run on a 1-GPU box), where RCCL cannot be used"""
@@ -491,13 +530,16 @@ def main():
             "sample": f"the first {S} of the {K} timed frames (after the same {W} warm-up frames), host arrays",
             "what": "oracle/kiss_oracle.c -- a C restatement of the reference path, NOT the upstream binary (Eigen/Sophus/tsl/TBB "
                     "are not installed); OpenMP in the reference's three TBB sites; gcc -O3 -ffp-contract=off, no -march=native "
-                    "(the reference's Release build is generic x86-64 too)",
+                    "(the reference's Release build is generic x86-64 too); march_native: the same sample and threads on a "
+                    "-march=native build made on this box",
             "ms_per_icp_iter": detail[best]["ms_per_icp_iter"],
             "by_threads": {str(t): d["scans_per_s"] for t, d in detail.items()},
             "host_cores": os.cpu_count(),
         }
         if 1 in detail:
             out["cpu_baseline"]["single_thread_scans_per_s"] = detail[1]["scans_per_s"]
+        # the same sample, same threads, on a -march=native build of the port made on this box (both factors in the line)
+        out["cpu_baseline"]["march_native"] = cpu_baseline_native(scans, W, S, cfg_over, best)
         out["speedup_vs_cpu"] = out["value"] / detail[best]["scans_per_s"]
         out["pose_error_vs_cpu"] = {
             "translation_m": float(np.linalg.norm(D[:3, 3])),

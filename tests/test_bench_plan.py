@@ -96,3 +96,18 @@ def test_bench_measures_in_its_own_process_once():
     assert not hasattr(bench, "supervise")
     src = open(bench.__file__).read()
     assert "KICP_BENCH_CHILD" not in src and "attempts" not in src
+
+
+def test_cpu_baseline_has_a_march_native_leg_that_never_fails_the_bench():
+    """the port built with -march=native on the box that runs it, timed in a child process on the same
+    sample: a figure beside the generic build's -- or an error string, never an exception"""
+    sys.path.insert(0, os.path.join(ROOT, "kiss-icp_amd", "python"))
+    from kiss_icp_amd.datasets import generate_scans
+
+    factory, ds_kw, cfg_over, _ = bench.workload("kitti")
+    scans = generate_scans(factory, dict(ds_kw, n_frames=3), range(3))
+    r = bench.cpu_baseline_native(scans, 1, 2, cfg_over, 4)
+    assert "error" not in r, r
+    assert r["value"] > 0 and "-march=native" in r["flags"] and "-ffp-contract=off" in r["flags"] and r["cores"] == 4
+    bad = bench.cpu_baseline_native(scans, 1, 2, dict(cfg_over, no_such_option=1), 4)
+    assert "error" in bad and "value" not in bad
