@@ -381,13 +381,8 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
             for (int k = 0; k < kGroups; ++k) total += sh_need[k];
             int h = 0, avail = 0, bb = 0;
             if (total > 0) {
-                // (the queue's two cursors first, in one round trip: while this kernel runs the tail stands still and the head
-                // only advances, so a queue that reads empty IS empty -- a young map's rule -- and the returning atomic on the
-                // head, a round trip of its own in front of the one on the bump counter, is left out)
-                const unsigned tail = (unsigned)__hip_atomic_load(&m.ctr[C_FTAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned head0 = (unsigned)__hip_atomic_load(&m.ctr[C_FHEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned hh = (int)(tail - head0) > 0 ? (unsigned)atomicAdd(&m.ctr[C_FHEAD], total) : head0;
-                avail = min(max((int)(tail - hh), 0), total);
+                const unsigned hh = (unsigned)atomicAdd(&m.ctr[C_FHEAD], total);
+                avail = min(max((int)((unsigned)m.ctr[C_FTAIL] - hh), 0), total);
                 h = (int)(hh % (unsigned)m.free_cap);
                 if (total > avail) bb = atomicAdd(&m.ctr[C_BUMP], total - avail);
                 const int fresh_ok = min(max(m.blocks_cap - bb, 0), total - avail);
