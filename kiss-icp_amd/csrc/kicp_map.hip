@@ -326,6 +326,14 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
         oz = pr.state->new_pose.t[2];
     }
     const double md2 = m.max_distance * m.max_distance;
+    // (fused: this thread's first entry of the doomed list is asked for HERE -- the list is k_map_link's, complete before this
+    // kernel starts --, so that its two dependent round trips run under the records' instead of behind them)
+    const int k_first = blockIdx.x * THREADS + threadIdx.x;
+    int nd = 0, b_first = -1;
+    if (pr.fused) {
+        nd = m.ctr[C_DOOMED0 + sc.parity * kCtrStride];
+        if (k_first < m.blocks_cap) b_first = m.doomed[k_first];  // (whatever it holds beyond nd is not used)
+    }
     // workgroup-uniform trip count: the groups of a workgroup allocate their blocks together
     for (int t0 = blockIdx.x * kGroups; t0 < touched; t0 += busy * kGroups) {
         const int t = t0 + g;
@@ -474,9 +482,8 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
     }
     if (pr.fused) {
         // ---- the doomed list: voxels that no record of this frame touches, and the touched ones whose group has not got there yet
-        const int nd = m.ctr[C_DOOMED0 + sc.parity * kCtrStride];
-        for (int k = blockIdx.x * THREADS + threadIdx.x; k < nd; k += busy * THREADS) {
-            const int b = KICP_IDX(m.dbg, m.ctr + C_ERR, m.doomed[k], m.blocks_cap, 32);
+        for (int k = k_first; k < nd; k += busy * THREADS) {
+            const int b = KICP_IDX(m.dbg, m.ctr + C_ERR, k == k_first ? b_first : m.doomed[k], m.blocks_cap, 32);
             BlockHdr *hdr = block_hdr(m, b);
             if (atomicCAS(&hdr->doom, 1, 2) == 1) voxel_remove(m, hdr, b);
         }
