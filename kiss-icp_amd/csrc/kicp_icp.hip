@@ -1935,13 +1935,24 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 r[2] = (unsigned)min(sh.tile_points, 0xFFFF) | ((unsigned)min(n_search, 0xFFFF) << 16);
                 prof_path = 5u;
             }
-            for (int e = grp; e < n_search;) {
+            // (The first eight searches go to eight different WAVES -- group 2 w takes search w, group 2 w + 1 search 8 + w --: the two
+            // groups of a wave run in lock step, a scan as long as the longer list, a list build of one half with the other
+            // masked off, and a later iteration has a handful of searches per workgroup.  kIcpSpreadSearches, profiles/r06_t_*.)
+            const int e_first = kIcpSpreadSearches ? (grp >> 1) + (kIcpGroupsPerBlock / 2) * (grp & 1) : grp;
+            for (int e = e_first; e < n_search;) {
                 const int t = (int)sh.search_idx[e];
                 IcpPoint &pt = sh.pts[t];
-                const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
-                const int vx = pt.v[0], vy = pt.v[1], vz = pt.v[2];
-                int flag = pt.flag;
                 IcpQueryMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
+                // (the point slot and the query's record in ONE round trip, as register copies: what decides about the list -- its
+                // state, the voxel it belongs to, where it lies -- is not read field by field behind the conditions)
+                IcpPoint ptc;
+                __builtin_memcpy(&ptc, __builtin_assume_aligned(&pt, 16), sizeof ptc);
+                IcpQueryMeta Mc;
+                __builtin_memcpy(&Mc, __builtin_assume_aligned(meta, 16), sizeof Mc);
+                const double s[3] = {ptc.s[0], ptc.s[1], ptc.s[2]};
+                const int vx = ptc.v[0], vy = ptc.v[1], vz = ptc.v[2];
+                int flag = ptc.flag;
+                int list_state = Mc.list_state, list_base = Mc.list_base, list_n = Mc.list_n;
                 int path = flag == 0 ? 0 : 3;  // profiling: 0 tile (lane per voxel), 1 tile (scan list), 3 HBM search
                 const unsigned tb = PROF ? ticks32() : 0u;
                 const unsigned tc = tb;
@@ -1951,20 +1962,21 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 bool listed = false;
                 bool tie = false;  // the fast search's answer may not be the reference's: a tie in NORM (kicp_search.hpp) -- settled below
                 unsigned t_build = 0u;  // (profiling: the list build's share of the search, later iterations)
-                if (flag == 0 && !listed && use_lists && meta->list_state >= 0) {
+                if (flag == 0 && !listed && use_lists && list_state >= 0) {
                     // the scan list belongs to the voxel the query was in when it was built
                     // (Round 6 tried NOT rebuilding the list of a query that has entered another voxel -- with the stability shortcut it
                     // is searched once there, as a rule -- and sending it through the lane-per-voxel search instead: that search
                     // is 5 us where build + list scan are 3.4, on the critical path of the iteration: profiles/r06_d_ab_*.txt.)
-                    if (meta->list_state == 0 || meta->lv[0] != vx || meta->lv[1] != vy || meta->lv[2] != vz) {
+                    if (list_state == 0 || Mc.lv[0] != vx || Mc.lv[1] != vy || Mc.lv[2] != vz) {
                         const unsigned t0 = PROF ? ticks32() : 0u;
-                        tile_list_build(tile, vx, vy, vz, lane, meta);
+                        // (where the list lies and how long it is come back in registers: the scan does not wait for the record)
+                        list_state = tile_list_build(tile, vx, vy, vz, lane, meta, (int)Mc.list_base, (int)Mc.list_cap, list_base, list_n) ? 1 : -1;
                         if (PROF) t_build = ticks32() - t0;
                     }
-                    if (meta->list_state == 1) {
-                        E = meta->list_n;
+                    if (list_state == 1) {
+                        E = list_n;
                         double sec2 = DBL_MAX;
-                        d2 = tile_scan_list(tile, tile.lists + meta->list_base, E, s[0], s[1], s[2], lane, nn, &tie, use_stable, &sec2);
+                        d2 = tile_scan_list(tile, tile.lists + list_base, E, s[0], s[1], s[2], lane, nn, &tie, use_stable, &sec2);
                         listed = true;
                         path = 1;
                         // (a tie in norm is settled by the exact search below: its neighbour has no margin worth keeping)
@@ -2014,7 +2026,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     pt.E = E;
                 }
                 const unsigned td = PROF ? ticks32() : 0u;
-                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && e == grp) {
+                if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && e == e_first) {
                     // per-group record of this iteration (10 ns ticks): where the group's time went
                     unsigned *r = P.prof_groups + ((size_t)it * (kIcpMaxBlocks * kIcpGroupsPerBlock) +
                                                    (size_t)blockIdx.x * kIcpGroupsPerBlock + grp) * 4;
@@ -2025,6 +2037,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     r[3] = (unsigned)path;
                     prof_path = (unsigned)path;
                 }
+                if (n_search <= kIcpGroupsPerBlock) break;  // (every search had its group: nothing to come back for)
                 int nt = 0;
                 if (lane == 0) nt = atomicAdd(&sh.next_point, 1);
                 e = __shfl(nt, 0, 32);

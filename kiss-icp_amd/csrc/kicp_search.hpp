@@ -916,7 +916,10 @@ __device__ __forceinline__ double tile_scan(const MapView &m, const Tile &tile, 
 // when voxels hold 20 points -- and strict '<' plus "smaller list position wins" reproduces the reference's
 // tie rules.  Built from the table (no HBM access) whenever the query enters another voxel.  Returns false
 // when the query cannot have a list (a voxel in the extension or missing from the tile, pool exhausted).
-__device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy, int vz, int lane, IcpQueryMeta *meta) {
+// cur_base / cur_cap: the record's list_base / list_cap as the caller has read them; out_base / out_n: where the new list lies and
+// its length (what the record holds afterwards), for a scan that follows at once.
+__device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy, int vz, int lane, IcpQueryMeta *meta, int cur_base, int cur_cap,
+                                                int &out_base, int &out_n) {
     int off = 0, cnt = 0;
     bool mybad = false;
     if (lane < 27) {
@@ -945,8 +948,8 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
     }
     const int total = __shfl(incl, 31, 32);
     bool fail = (unsigned)(__ballot(mybad) >> half_shift) != 0u || total > 0xFFFF;
-    int base = meta->list_base;
-    if (!fail && total > (int)meta->list_cap) {  // a longer list than before: new room from the pool (the old one is abandoned)
+    int base = cur_base;
+    if (!fail && total > cur_cap) {  // a longer list than before: new room from the pool (the old one is abandoned)
         int nb = -1;
         const int want = total + 16;
         if (lane == 0) {
@@ -982,6 +985,8 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
         meta->list_n = (unsigned short)total;
         meta->list_state = 1;
     }
+    out_base = base;
+    out_n = total;
     group_lds_sync();
     return true;
 }
