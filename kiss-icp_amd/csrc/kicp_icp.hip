@@ -59,6 +59,8 @@ struct alignas(16) IcpShared {  // head of the dynamic LDS; the region records a
     // kept by ONE thread (kIcpBookThread of workgroup 0), off the critical path and out of registers:
     double T_icp[7];  // accumulated update, q[4] t[3]
     double guess[7];
+    double book[8];   // pipeline mode: last_pose q[4] t[3] as the prologue read it (the frame's bookkeeping at the end of the launch
+                      // takes it from here: a round trip to memory on the frame's serial chain otherwise)
     unsigned long long ncorr_last, ncorr_total, examined_total;
     double pad2;
     int fail;
@@ -967,6 +969,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
     const int n = count_of(P.n_ptr, P.n_imm);
     const int live0 = m.ctr[C_LIVE];
     const unsigned epoch_base = st->epoch_base;
+    const int n_pre0 = P.prep ? P.prep->n_pre : 0, n_fd0 = P.prep ? P.prep->n_fd : 0;  // (for the frame's record, written at the very end)
     SE3 pose_a, pose_b;  // pipeline: last_pose, last_delta; else: the caller's guess (twice)
     double sse0 = 0.0;
     int samples0 = 1;
@@ -1124,6 +1127,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             sh.guess[4 + i] = guess.t[i];
         }
         sh.ncorr_last = sh.ncorr_total = sh.examined_total = 0ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sh.book[i] = pose_a.q[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sh.book[4 + i] = pose_a.t[i];
+        sh.book[7] = 0.0;
     }
     if constexpr (WIDE) {
         for (int i = tid; i < n_meta; i += kIcpThreads) {
@@ -2316,8 +2324,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         st->icp_ncorr_total = ncorr_total;
         st->n_src = n;
         if (P.prep) {
-            st->n_pre = P.prep->n_pre;
-            st->n_fd = P.prep->n_fd;
+            st->n_pre = n_pre0;
+            st->n_fd = n_fd0;
         }
         st->icp_blocks_used = G;
 #pragma unroll
@@ -2337,11 +2345,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             const double delta_rot = 2.0 * m.max_distance * sin(theta / 2.0);
             const double delta_trans = sqrt(sqnorm3(dev.t[0], dev.t[1], dev.t[2]));
             const double model_error = delta_trans + delta_rot;
-            if (model_error > P.min_motion_th) {
-                st->model_sse += model_error * model_error;
-                st->num_samples += 1;
+            if (model_error > P.min_motion_th) {  // (the sums as the prologue read them: nobody else writes them)
+                st->model_sse = sse0 + model_error * model_error;
+                st->num_samples = samples0 + 1;
             }
-            st->last_delta = se3_mul(se3_inverse(st->last_pose), new_pose);
+            SE3 last_pose;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) last_pose.q[i] = sh.book[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) last_pose.t[i] = sh.book[4 + i];
+            st->last_delta = se3_mul(se3_inverse(last_pose), new_pose);
             st->last_pose = new_pose;
         }
     }

@@ -149,14 +149,16 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, InsertScratch sc, c
     const int link_blocks = (int)gridDim.x - scan_blocks;
     if ((int)blockIdx.x >= link_blocks) {
         // ---- fused update: the verdict pass of RemovePointsFarFromLocation (read-only but for the sentences) ----------
+        const int bump0 = m.ctr[C_BUMP];
+        const int verr0 = state ? __hip_atomic_load(&state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         if (use_state_origin) {
             ox = state->new_pose.t[0];
             oy = state->new_pose.t[1];
             oz = state->new_pose.t[2];
         }
         const double md2 = m.max_distance * m.max_distance;
-        int nb = min(m.ctr[C_BUMP], m.blocks_cap);
-        if (state && (__hip_atomic_load(&state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT)) nb = 0;  // no pose
+        int nb = min(bump0, m.blocks_cap);
+        if (verr0 & E_TIMEOUT) nb = 0;  // no pose
         int *n_doomed = &m.ctr[C_DOOMED0 + sc.parity * kCtrStride];
         for (int b = ((int)blockIdx.x - link_blocks) * (int)blockDim.x + (int)threadIdx.x; b < nb; b += scan_blocks * (int)blockDim.x) {
             BlockHdr *hdr = block_hdr(m, b);
@@ -168,7 +170,11 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, InsertScratch sc, c
         }
         return;
     }
+    // (count, error word and pose are asked for together, in front of the tests on them: one round trip, not three)
     const int n = count_of(n_ptr, n_imm);
+    const int err0 = use_pose ? __hip_atomic_load(&state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    SE3 pose = se3_identity();
+    if (use_pose) pose = state->new_pose;
     int *touched = &m.ctr[C_TOUCHED0 + sc.parity * kCtrStride];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         m.ctr[C_TOUCHED0 + (sc.parity ^ 1) * kCtrStride] = 0;  // re-arm for the next insert
@@ -179,12 +185,8 @@ __global__ __launch_bounds__(256) void k_map_link(MapView m, InsertScratch sc, c
         if ((int)(tail - head) < 0) m.ctr[C_FHEAD] = (int)tail;
         m.ctr[C_FTAIL] = m.ctr[C_FPEND];
     }
-    SE3 pose;
-    if (use_pose) {
-        // a registration that gave up (E_TIMEOUT) left no pose: the frame inserts nothing (the host replays it)
-        if (__hip_atomic_load(&state->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & E_TIMEOUT) return;
-        pose = state->new_pose;
-    }
+    // a registration that gave up (E_TIMEOUT) left no pose: the frame inserts nothing (the host replays it)
+    if (use_pose && (err0 & E_TIMEOUT)) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += link_blocks * blockDim.x) {
         double p[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
         if (use_pose) {  // VoxelHashMap.cpp:90-92
@@ -314,26 +316,26 @@ __global__ __launch_bounds__(THREADS) void k_map_apply(MapView m, InsertScratch 
     const int lane = threadIdx.x & 31;
     const int g = threadIdx.x >> 5;
     const int half_shift = threadIdx.x & 32;  // this group's half of the 64-bit wave ballot
+    // (what the kernel needs before its records -- their count, the origin, the doomed list's length and this thread's first entry
+    // of it: the list is k_map_link's, complete before this kernel starts -- is asked for together, in front of the first test)
     const int touched = m.ctr[C_TOUCHED0 + sc.parity * kCtrStride];
-    // the workgroups that have records to serve (at least one): the others leave at once -- in the fused form they would
-    // have to sign off one by one on a single word for the frame record's sake
-    const int busy = min((int)gridDim.x, max(1, (touched + kGroups - 1) / kGroups));
-    if ((int)blockIdx.x >= busy) return;
     double ox = pr.ox, oy = pr.oy, oz = pr.oz;
     if (pr.fused && pr.use_state_origin) {
         ox = pr.state->new_pose.t[0];
         oy = pr.state->new_pose.t[1];
         oz = pr.state->new_pose.t[2];
     }
-    const double md2 = m.max_distance * m.max_distance;
-    // (fused: this thread's first entry of the doomed list is asked for HERE -- the list is k_map_link's, complete before this
-    // kernel starts --, so that its two dependent round trips run under the records' instead of behind them)
     const int k_first = blockIdx.x * THREADS + threadIdx.x;
     int nd = 0, b_first = -1;
     if (pr.fused) {
         nd = m.ctr[C_DOOMED0 + sc.parity * kCtrStride];
         if (k_first < m.blocks_cap) b_first = m.doomed[k_first];  // (whatever it holds beyond nd is not used)
     }
+    // the workgroups that have records to serve (at least one): the others leave at once -- in the fused form they would
+    // have to sign off one by one on a single word for the frame record's sake
+    const int busy = min((int)gridDim.x, max(1, (touched + kGroups - 1) / kGroups));
+    if ((int)blockIdx.x >= busy) return;
+    const double md2 = m.max_distance * m.max_distance;
     // workgroup-uniform trip count: the groups of a workgroup allocate their blocks together
     for (int t0 = blockIdx.x * kGroups; t0 < touched; t0 += busy * kGroups) {
         const int t = t0 + g;

@@ -288,6 +288,18 @@ __device__ __forceinline__ double group_argmin(double best, int bkey, double bx,
 // ------------------------------------------------------------------------------------------
 constexpr double kNormTie = 0x1.0000000000004p+0;  // 1 + 2^-50
 
+// inclusive prefix sum over the 32 lanes of a group, in registers: four row_shr steps inside the rows of 16 lanes (lanes shifted
+// in from outside a row read 0), then the first row's total -- its lane 15 -- into the second row (row_bcast:15 on rows 1 and 3 of
+// the wave: both groups of a wave at once).  Five VALU operations where five __shfl_up are five trips through the LDS crossbar.
+constexpr bool kListScanDpp = true;  // (tile_list_build; false: the shuffles, for A/Bs)
+__device__ __forceinline__ int group_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xA, 0xF, true);
+    return v;
+}
 template <int STEP>
 __device__ __forceinline__ void group_fmin_step(double &v) {
     const double o = group_xchg<STEP>(v);
@@ -940,14 +952,17 @@ __device__ __forceinline__ bool tile_list_build(const Tile &tile, int vx, int vy
         }
     }
     const int half_shift = kicp_tid() & 32;
-    int incl = cnt;
+    const int incl = kListScanDpp ? group_incl_scan(cnt) : [&] {
+        int v = cnt;
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        const int up = __shfl_up(incl, o, 32);
-        if (lane >= o) incl += up;
-    }
+        for (int o = 1; o < 32; o <<= 1) {
+            const int up = __shfl_up(v, o, 32);
+            if (lane >= o) v += up;
+        }
+        return v;
+    }();
     const int total = __shfl(incl, 31, 32);
-    bool fail = (unsigned)(__ballot(mybad) >> half_shift) != 0u || total > 0xFFFF;
+    bool fail = (unsigned)(__ballot(mybad) >> half_shift) != 0u || total > 0x7FFE;  // (tile_scan_list's keys: 15 bits of list position)
     int base = cur_base;
     if (!fail && total > cur_cap) {  // a longer list than before: new room from the pool (the old one is abandoned)
         int nb = -1;
@@ -1024,9 +1039,11 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
             }
         }
         double x[U], y[U], z[U];
+        int cur[U];  // (this trip's store positions: they ride in the low half of a candidate's key, below)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + 32 * u;
+            cur[u] = pos[u];
             const double *q = i < n ? P + 3 * KICP_IDX((BoundsRec *)nullptr, (int *)nullptr, pos[u], tile.cap_points, 9) : tile.far;
             x[u] = q[0];
             y[u] = q[1];
@@ -1044,7 +1061,10 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
             const int i = i0 + 32 * u;
             const double ex = x[u] - sx, ey = y[u] - sy, ez = z[u] - sz;
             const double d = (ex * ex + ey * ey) + ez * ez;  // (+inf past the end of the list)
-            bi = d < best ? i : bi;                           // strict: a lane meets its candidates in list order and keeps the first
+            // strict: a lane meets its candidates in list order and keeps the first.  The key is {list position, store position}:
+            // ordered by the list position (the reference's visiting order decides among equal distances), and the winner's
+            // coordinates are then one LDS round trip away instead of two (list entry, then point)
+            bi = d < best ? ((i << 16) | cur[u]) : bi;
             sec = __builtin_fmin(sec, __builtin_fmax(best, d));
             best = __builtin_fmin(best, d);
         }
@@ -1062,7 +1082,7 @@ __device__ __forceinline__ double tile_scan_list(const Tile &tile, const unsigne
         group_fmin_step<4>(g2);
         *second = g2;
     }
-    const int p = (int)I[found ? bi : 0];
+    const int p = found ? (bi & 0xFFFF) : 0;
     nn[0] = found ? P[3 * p] : 0.0;
     nn[1] = found ? P[3 * p + 1] : 0.0;
     nn[2] = found ? P[3 * p + 2] : 0.0;
