@@ -1261,12 +1261,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     wq.v[0] = vx;
                     wq.v[1] = vy;
                     wq.v[2] = vz;
-                    bool cached = false;
-                    if (has_meta && meta->valid > 0)  // is the 27-neighbourhood of (vx, vy, vz) inside the known window?
-                        cached = meta->lo[0] <= vx - meta->v[0] - 1 && vx - meta->v[0] + 1 <= meta->hi[0] &&
-                                 meta->lo[1] <= vy - meta->v[1] - 1 && vy - meta->v[1] + 1 <= meta->hi[1] &&
-                                 meta->lo[2] <= vz - meta->v[2] - 1 && vz - meta->v[2] + 1 <= meta->hi[2];
-                    wq.flag = cached ? 0 : ((has_meta && meta->valid >= 0) ? 1 : 2);
+                    // is the 27-neighbourhood of (vx, vy, vz) inside the known window?  (the record -- five words -- in one round
+                    // trip and the test without short-circuits: ten dependent LDS round trips otherwise, like the group form's)
+                    WideMeta Mw;
+                    __builtin_memcpy(&Mw, __builtin_assume_aligned(meta, 4), sizeof Mw);
+                    const int wrx = vx - Mw.v[0], wry = vy - Mw.v[1], wrz = vz - Mw.v[2];
+                    const bool cached = has_meta & (Mw.valid > 0) & ((int)Mw.lo[0] <= wrx - 1) & (wrx + 1 <= (int)Mw.hi[0]) & ((int)Mw.lo[1] <= wry - 1) &
+                                        (wry + 1 <= (int)Mw.hi[1]) & ((int)Mw.lo[2] <= wrz - 1) & (wrz + 1 <= (int)Mw.hi[2]);
+                    wq.flag = cached ? 0 : ((has_meta & (Mw.valid >= 0)) ? 1 : 2);
                     if (wq.flag == 1) sh.any_fill = 1;
                     if (it == 0 && j == 0) {
                         // The tile's relative voxel coordinates: centred on the SENSOR when the map's reach fits the span (every

@@ -222,14 +222,22 @@ __device__ __forceinline__ unsigned wide_entry(const Tile &tile, int vx, int vy,
     unsigned rkey;
     if (!tile_rel(tile, qx, qy, qz, rkey)) return 0u;
     unsigned s = tile_hash(tile, rkey);
-    for (int probes = 0; probes < kTileMaxProbes; ++probes) {
-        const unsigned k = tile.keys[s];
-        if (k == rkey) {
-            if (slot_out) *slot_out = s;
-            return tile.vals[s];
+    for (int probes = 0; probes < kTileMaxProbes; probes += 4) {  // (four slots per round trip, resolved in chain order: tile_find)
+        unsigned k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = tile.keys[(s + (unsigned)u) & (unsigned)tile.slots_mask];
+        int res = -2;  // undecided; -1: not in the table; else the slot
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int here = k[u] == rkey ? (int)((s + (unsigned)u) & (unsigned)tile.slots_mask) : (k[u] == kTileEmpty ? -1 : -2);
+            res = res == -2 ? here : res;
         }
-        if (k == kTileEmpty) return 0u;
-        s = (s + 1u) & (unsigned)tile.slots_mask;
+        if (res >= 0) {
+            if (slot_out) *slot_out = (unsigned)res;
+            return tile.vals[res];
+        }
+        if (res == -1) return 0u;
+        s = (s + 4u) & (unsigned)tile.slots_mask;
     }
     return 0u;
 }
@@ -319,14 +327,23 @@ __device__ __forceinline__ void wide_search_lds(const MapView &m, const Tile &ti
         unsigned rkey;
         (void)tile_rel(tile, qx, qy, qz, rkey);
         unsigned s = (tile_hash(tile, rkey) + 2u) & (unsigned)tile.slots_mask;
-        for (int probes = 2; probes < kTileMaxProbes; ++probes) {
-            const unsigned k = tile.keys[s];
-            if (k == rkey) {
-                classify(tile.vals[s], j);
-                break;
+        // (four slots of the chain per round trip, resolved in chain order: a miss in a table 5/8 full walks four slots on average
+        // and thirty at worst, and a wave waits for its slowest lane -- 3 us on average, 36 at worst in the first iteration of the
+        // 1M-point configuration, profiles/r06_final_icp_probe_livox100.txt.  No key lies beyond kTileMaxProbes slots from
+        // its home: the two the last round looks at beyond that can only end the chain.)
+        for (int probes = 2; probes < kTileMaxProbes; probes += 4) {
+            unsigned k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = tile.keys[(s + (unsigned)u) & (unsigned)tile.slots_mask];
+            int res = -2;  // undecided; -1: not in the table; else the slot
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int here = k[u] == rkey ? (int)((s + (unsigned)u) & (unsigned)tile.slots_mask) : (k[u] == kTileEmpty ? -1 : -2);
+                res = res == -2 ? here : res;
             }
-            if (k == kTileEmpty) break;
-            s = (s + 1u) & (unsigned)tile.slots_mask;
+            if (res >= 0) classify(tile.vals[res], j);
+            if (res != -2) break;
+            s = (s + 4u) & (unsigned)tile.slots_mask;
         }
     }
     if (bad) return;
