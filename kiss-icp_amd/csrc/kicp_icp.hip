@@ -173,8 +173,13 @@ __device__ __forceinline__ bool tile_fill_bulk(MapView m, Tile tile, IcpShared *
     auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key) for every in-range cell of every pending window
         for (int idx = tid; idx < cn * 64; idx += kIcpThreads) {
             const int qt = idx >> 6;
-            if (sh.pts[qt].flag != 1) continue;
-            const IcpQueryMeta *meta = metas + qt;
+            // (the query's flag and the window part of its record in one round trip, in front of the test)
+            const int qflag = sh.pts[qt].flag;
+            struct { int v[3]; signed char lo[3], hi[3], valid, list_state; } Mq;
+            static_assert(sizeof(Mq) == 20 && offsetof(IcpQueryMeta, v) == 24 && offsetof(IcpQueryMeta, lo) == 36 && offsetof(IcpQueryMeta, hi) == 39, "window part of IcpQueryMeta");
+            __builtin_memcpy(&Mq, __builtin_assume_aligned(reinterpret_cast<const char *>(metas + qt) + offsetof(IcpQueryMeta, v), 4), sizeof Mq);
+            if (qflag != 1) continue;
+            const auto *meta = &Mq;
             const int ny = meta->hi[1] - meta->lo[1] + 1, nz = meta->hi[2] - meta->lo[2] + 1, nx = meta->hi[0] - meta->lo[0] + 1;
             const int w = idx & 63;
             if (w >= nx * ny * nz) continue;

@@ -928,7 +928,11 @@ __device__ __forceinline__ int wide_fill_bulk(const MapView &m, const Tile &tile
     auto for_each_cell = [&](auto &&fn) {  // fn(query, relative key, within one step of the query's voxel) for every in-range cell of every window taking part
         for (int idx = tid; idx < cn * 64; idx += kIcpThreads) {
             const int qt = q_lo + (idx >> 6);
-            const WideMeta *meta = metas + qt;
+            // (the query's record -- five words, the same for the 64 threads of a wave -- in one round trip, in front of the test on it:
+            // thirty-two rounds of this loop per batch of 256 queries, each a chain of dependent LDS round trips)
+            WideMeta Mq;
+            __builtin_memcpy(&Mq, __builtin_assume_aligned(metas + qt, 4), sizeof Mq);
+            const WideMeta *meta = &Mq;
             if (meta->list_state != 2) continue;
             const int ny = meta->hi[1] - meta->lo[1] + 1, nz = meta->hi[2] - meta->lo[2] + 1, nx = meta->hi[0] - meta->lo[0] + 1;
             const int w = idx & 63;
