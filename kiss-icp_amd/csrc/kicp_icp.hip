@@ -852,6 +852,44 @@ __device__ __forceinline__ void icp_runs_from_weights(const unsigned *wts32, Icp
 #include "kicp_icp_wide.hpp"
 namespace kicp {
 
+// One point's row of phase C: the sixteen products of J^T w J and J^T w r (Registration.cpp:80-121, Geman-McClure weight, strict
+// d < max_dist), the correspondence count and the examined count, written 16 bytes at a time.  One expression for whoever forms the
+// row -- phase C's thread, or (kIcpTermsInB) the group that has just searched the point / the idle wave that serves the stable
+// ones during phase B --, so the bits do not depend on who does.
+__device__ __forceinline__ void icp_terms_row(const double s[3], const double nn[3], double d2, int E, double max_dist, double ks, double *row_out) {
+    double T[kIcpTerms];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) T[k] = 0.0;
+    T[17] = (double)E;
+    if (d2 < DBL_MAX && sqrt(d2) < max_dist) {  // Registration.cpp:72 (strict)
+        const double rx = s[0] - nn[0], ry = s[1] - nn[1], rz = s[2] - nn[2];
+        const double r2 = (rx * rx + ry * ry) + rz * rz;
+        const double w = (ks * ks) / ((ks + r2) * (ks + r2));
+        T[0] = w;
+        T[1] = w * s[0];
+        T[2] = w * s[1];
+        T[3] = w * s[2];
+        // w * hat(s)^T hat(s) = w * (|s|^2 I - s s^T), upper triangle
+        T[4] = w * (s[1] * s[1] + s[2] * s[2]);
+        T[5] = w * (-(s[0] * s[1]));
+        T[6] = w * (-(s[0] * s[2]));
+        T[7] = w * (s[0] * s[0] + s[2] * s[2]);
+        T[8] = w * (-(s[1] * s[2]));
+        T[9] = w * (s[0] * s[0] + s[1] * s[1]);
+        T[10] = w * rx;
+        T[11] = w * ry;
+        T[12] = w * rz;
+        // w * (s x r)
+        T[13] = w * (s[1] * rz - s[2] * ry);
+        T[14] = w * (s[2] * rx - s[0] * rz);
+        T[15] = w * (s[0] * ry - s[1] * rx);
+        T[16] = 1.0;
+    }
+    double2 *row = reinterpret_cast<double2 *>(row_out);  // (144 bytes per row: 16-byte aligned)
+#pragma unroll
+    for (int k = 0; k < kIcpTerms / 2; ++k) row[k] = make_double2(T[2 * k], T[2 * k + 1]);
+}
+
 // One scalar's fixed-order sum over the (at most 16) rows of a reduction stage.  The stage's values lie TRANSPOSED in LDS -- row k =
 // the sixteen contributions to scalar k, 128 contiguous bytes -- so that the thread of scalar k has all of them in flight at once
 // (eight 16-byte loads, one round trip) and adds them from registers: v = ((0 + a0) + a1) + ... over the first `count`, the same
@@ -1954,6 +1992,20 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // groups of a wave run in lock step, a scan as long as the longer list, a list build of one half with the other
             // masked off, and a later iteration has a handful of searches per workgroup.  kIcpSpreadSearches, profiles/r06_t_*.)
             const int e_first = kIcpSpreadSearches ? (grp >> 1) + (kIcpGroupsPerBlock / 2) * (grp & 1) : grp;
+            // kIcpTermsInB: when the chunk is one wave of points and its searches leave the last wave idle (the rule from the second
+            // iteration on), phase C's rows are formed HERE, off the critical path: the last wave forms the rows of the stable points
+            // while the others search, a group that has searched a point forms that point's row itself -- it holds s, the
+            // neighbour, the distance and the count in registers --, and phase C is left with the additions.  Same expression
+            // (icp_terms_row), same bits.
+            const bool rows_in_b = kIcpTermsInB && kIcpSpreadSearches && use_stable && it > 0 && cn <= 64 && n_search <= kIcpGroupsPerBlock / 2 - 1;
+            if (rows_in_b && tid >= kIcpThreads - 64) {
+                const int j = tid - (kIcpThreads - 64);
+                if (j < cn) {
+                    IcpPoint pc;
+                    __builtin_memcpy(&pc, __builtin_assume_aligned(&sh.pts[j], 16), sizeof pc);
+                    if (pc.flag == 3) icp_terms_row(pc.s, pc.nn, pc.d2, pc.E, max_dist, ks, terms[j]);
+                }
+            }
             for (int e = e_first; e < n_search;) {
                 const int t = (int)sh.search_idx[e];
                 IcpPoint &pt = sh.pts[t];
@@ -2039,6 +2091,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     pt.nn[2] = nn[2];
                     pt.d2 = d2;
                     pt.E = E;
+                    if (rows_in_b) icp_terms_row(s, nn, d2, E, max_dist, ks, terms[t]);
                 }
                 const unsigned td = PROF ? ticks32() : 0u;
                 if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && e == e_first) {
@@ -2063,45 +2116,15 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // ---- C -------------------------------------------------------------------------------------
             for (int sub = 0; sub < cn; sub += kIcpTermChunk) {
                 const int sn = min(kIcpTermChunk, cn - sub);
-                if (tid < sn) {
-                    // (the point slot in one round trip, the row of products written once, from registers)
-                    IcpPoint pt;
-                    __builtin_memcpy(&pt, __builtin_assume_aligned(&sh.pts[sub + tid], 16), sizeof pt);
-                    const double s[3] = {pt.s[0], pt.s[1], pt.s[2]};
-                    const double d2 = pt.d2;
-                    double T[kIcpTerms];
-#pragma unroll
-                    for (int k = 0; k < 17; ++k) T[k] = 0.0;
-                    T[17] = (double)pt.E;
-                    if (d2 < DBL_MAX && sqrt(d2) < max_dist) {  // Registration.cpp:72 (strict)
-                        const double rx = s[0] - pt.nn[0], ry = s[1] - pt.nn[1], rz = s[2] - pt.nn[2];
-                        const double r2 = (rx * rx + ry * ry) + rz * rz;
-                        const double w = (ks * ks) / ((ks + r2) * (ks + r2));
-                        T[0] = w;
-                        T[1] = w * s[0];
-                        T[2] = w * s[1];
-                        T[3] = w * s[2];
-                        // w * hat(s)^T hat(s) = w * (|s|^2 I - s s^T), upper triangle
-                        T[4] = w * (s[1] * s[1] + s[2] * s[2]);
-                        T[5] = w * (-(s[0] * s[1]));
-                        T[6] = w * (-(s[0] * s[2]));
-                        T[7] = w * (s[0] * s[0] + s[2] * s[2]);
-                        T[8] = w * (-(s[1] * s[2]));
-                        T[9] = w * (s[0] * s[0] + s[1] * s[1]);
-                        T[10] = w * rx;
-                        T[11] = w * ry;
-                        T[12] = w * rz;
-                        // w * (s x r)
-                        T[13] = w * (s[1] * rz - s[2] * ry);
-                        T[14] = w * (s[2] * rx - s[0] * rz);
-                        T[15] = w * (s[0] * ry - s[1] * rx);
-                        T[16] = 1.0;
+                if (!rows_in_b) {
+                    if (tid < sn) {
+                        // (the point slot in one round trip, the row of products written once, from registers)
+                        IcpPoint pt;
+                        __builtin_memcpy(&pt, __builtin_assume_aligned(&sh.pts[sub + tid], 16), sizeof pt);
+                        icp_terms_row(pt.s, pt.nn, pt.d2, pt.E, max_dist, ks, terms[tid]);
                     }
-                    double2 *row = reinterpret_cast<double2 *>(terms[tid]);  // (144 bytes per row: 16-byte aligned)
-#pragma unroll
-                    for (int k = 0; k < kIcpTerms / 2; ++k) row[k] = make_double2(T[2 * k], T[2 * k + 1]);
+                    __syncthreads();
                 }
-                __syncthreads();
                 if (cg < kIcpGroupsPerBlock) {
                     // term ck of the points cg, cg + 16, ... in that order: all (at most four) asked for together
                     double a[kIcpTermChunk / kIcpGroupsPerBlock];
@@ -2179,10 +2202,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
             }
             __syncthreads();
-            if (tid < kIcpSums && !sh.fail) {
+            if (tid < kIcpSums) {
+                // (the failure flag is read beside the row, not in front of it: one LDS round trip on the path from the first hop to the second)
                 const double v = icp_row_sum<PROF>(sums_t + tid * kIcpSumRows, members, tid == kIcpTickSlot);  // member order: fixed by G alone
+                const int leader_failed = sh.fail;
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
+                if (!leader_failed)
+                    granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
             }
             __syncthreads();  // range_sum is reused below
         }
@@ -2200,20 +2226,21 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
             __syncthreads();
         }
-        for (int e = tidv; e < ng * kIcpSums && !sh.fail; e += kIcpThreads) {
+        for (int e = tidv; e < ng * kIcpSums; e += kIcpThreads) {  // (a poll that follows a failure gives up by the error word: poll_pair)
             const int k = e % kIcpSums, g = e / kIcpSums;
             double v = 0.0;
             if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpSums + k) * 16), v)) sh.fail = 1;
             sums_t[k * kIcpSumRows + g] = v;
         }
         __syncthreads();
-        if (sh.fail) {
+        const int exchange_failed = sh.fail;  // (asked for in front of the rows below, looked at behind them: one round trip, not two)
+        if (tid < kIcpSums) sh.tot[tid] = icp_row_sum<PROF>(sums_t + tid * kIcpSumRows, ng, tid == kIcpTickSlot);
+        if (exchange_failed) {
             // tell the waiting workgroups at once (they check the error word while they spin)
             if (tid == 0) atomicOr(&st->err, E_TIMEOUT);
             failed = true;
             break;
         }
-        if (tid < kIcpSums) sh.tot[tid] = icp_row_sum<PROF>(sums_t + tid * kIcpSumRows, ng, tid == kIcpTickSlot);
         __syncthreads();
         // ---- waves 0..3 (one per SIMD) of EVERY workgroup solve the same system; the result goes through LDS -----
         const unsigned c3 = PROF ? ticks32() : 0u;
