@@ -854,8 +854,8 @@ namespace kicp {
 
 // One point's row of phase C: the sixteen products of J^T w J and J^T w r (Registration.cpp:80-121, Geman-McClure weight, strict
 // d < max_dist), the correspondence count and the examined count, written 16 bytes at a time.  One expression for whoever forms the
-// row -- phase C's thread, or (kIcpTermsInB) the group that has just searched the point / the idle wave that serves the stable
-// ones during phase B --, so the bits do not depend on who does.
+// row (phase C's thread in both forms of the kernel; session y's experiment had the searching groups and an idle wave form
+// rows too), so the bits do not depend on who does.
 __device__ __forceinline__ void icp_terms_row(const double s[3], const double nn[3], double d2, int E, double max_dist, double ks, double *row_out) {
     double T[kIcpTerms];
 #pragma unroll
@@ -1992,20 +1992,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // groups of a wave run in lock step, a scan as long as the longer list, a list build of one half with the other
             // masked off, and a later iteration has a handful of searches per workgroup.  kIcpSpreadSearches, profiles/r06_t_*.)
             const int e_first = kIcpSpreadSearches ? (grp >> 1) + (kIcpGroupsPerBlock / 2) * (grp & 1) : grp;
-            // kIcpTermsInB: when the chunk is one wave of points and its searches leave the last wave idle (the rule from the second
-            // iteration on), phase C's rows are formed HERE, off the critical path: the last wave forms the rows of the stable points
-            // while the others search, a group that has searched a point forms that point's row itself -- it holds s, the
-            // neighbour, the distance and the count in registers --, and phase C is left with the additions.  Same expression
-            // (icp_terms_row), same bits.
-            const bool rows_in_b = kIcpTermsInB && kIcpSpreadSearches && use_stable && it > 0 && cn <= 64 && n_search <= kIcpGroupsPerBlock / 2 - 1;
-            if (rows_in_b && tid >= kIcpThreads - 64) {
-                const int j = tid - (kIcpThreads - 64);
-                if (j < cn) {
-                    IcpPoint pc;
-                    __builtin_memcpy(&pc, __builtin_assume_aligned(&sh.pts[j], 16), sizeof pc);
-                    if (pc.flag == 3) icp_terms_row(pc.s, pc.nn, pc.d2, pc.E, max_dist, ks, terms[j]);
-                }
-            }
             for (int e = e_first; e < n_search;) {
                 const int t = (int)sh.search_idx[e];
                 IcpPoint &pt = sh.pts[t];
@@ -2091,7 +2077,6 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     pt.nn[2] = nn[2];
                     pt.d2 = d2;
                     pt.E = E;
-                    if (rows_in_b) icp_terms_row(s, nn, d2, E, max_dist, ks, terms[t]);
                 }
                 const unsigned td = PROF ? ticks32() : 0u;
                 if (PROF && P.prof_groups && lane == 0 && it < kIcpProfIters && base == 0 && e == e_first) {
@@ -2116,15 +2101,16 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // ---- C -------------------------------------------------------------------------------------
             for (int sub = 0; sub < cn; sub += kIcpTermChunk) {
                 const int sn = min(kIcpTermChunk, cn - sub);
-                if (!rows_in_b) {
-                    if (tid < sn) {
-                        // (the point slot in one round trip, the row of products written once, from registers)
-                        IcpPoint pt;
-                        __builtin_memcpy(&pt, __builtin_assume_aligned(&sh.pts[sub + tid], 16), sizeof pt);
-                        icp_terms_row(pt.s, pt.nn, pt.d2, pt.E, max_dist, ks, terms[tid]);
-                    }
-                    __syncthreads();
+                // (Forming the rows during phase B instead -- the last wave for the stable points while the others search, a searching
+                // group for its own point, this stage and its barrier gone -- measured 0.5 - 1 % SLOWER on both bench commands:
+                // profiles/r06_y_*, the patch beside the numbers.)
+                if (tid < sn) {
+                    // (the point slot in one round trip, the row of products written once, from registers)
+                    IcpPoint pt;
+                    __builtin_memcpy(&pt, __builtin_assume_aligned(&sh.pts[sub + tid], 16), sizeof pt);
+                    icp_terms_row(pt.s, pt.nn, pt.d2, pt.E, max_dist, ks, terms[tid]);
                 }
+                __syncthreads();
                 if (cg < kIcpGroupsPerBlock) {
                     // term ck of the points cg, cg + 16, ... in that order: all (at most four) asked for together
                     double a[kIcpTermChunk / kIcpGroupsPerBlock];

@@ -224,7 +224,6 @@ constexpr int kIcpExchangeGroups = 16;  // leaders of the two-level exchange (wo
                                         // scene (profiles/r04_ak_exchange_leaders_ab.txt): 4 leaders 2602, 8: 2785, 16: 2856,
                                         // 32: 2715, 64: 2459 scans/s -- the first hop gets shorter, the second longer
 constexpr bool kIcpPollAll = true;      // the second hop without its watcher lanes (kicp_icp.hip; false: round 3's form, for A/Bs)
-constexpr bool kIcpTermsInB = true;        // group form: phase C's rows formed during phase B when the last wave is idle (kicp_icp.hip)
 constexpr bool kIcpSpreadSearches = true;  // group form, phase B: the first searches of a workgroup on different waves (kicp_icp.hip)
 constexpr int kIcpMaxMembers = 16;      // workgroups per leader at most (256 / 16)
 constexpr int kIcpSumRows = kIcpMaxMembers > kIcpExchangeGroups ? kIcpMaxMembers : kIcpExchangeGroups;
