@@ -9,7 +9,7 @@ for r in $(seq $REPS); do
     KICP_LIB=$lib timeout ${TMO:-120} python bench.py $ARGS 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); l = d.get('icp_last_launch', {})
-print('%-8s rep $r  %7.1f scans/s  k_icp/iter %.2f us  last launch: first %.1f later %.2f total %.1f  roofline %.4f' % ('$v', d['value'], d['ms_per_icp_iter'] * 1000, l.get('first_iteration_us', 0), l.get('later_iterations_us', 0), l.get('total_us', 0), d['roofline']['frac']))" >> $out
+print('%-8s rep $r  %7.1f scans/s  k_icp/iter %.2f us  last launch: first %.1f later %.2f total %.1f  roofline %.4f  local-hop groups %s' % ('$v', d['value'], d['ms_per_icp_iter'] * 1000, l.get('first_iteration_us', 0), l.get('later_iterations_us', 0), l.get('total_us', 0), d['roofline']['frac'], d['config'].get('icp_local_hop_groups', '-')))" >> $out
   done
 done
 cat $out
