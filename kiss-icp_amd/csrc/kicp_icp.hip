@@ -584,19 +584,19 @@ __device__ __forceinline__ bool icp_weighted_run(IcpRunArgs P, IcpShared *shp, S
     for (int o = 32; o >= 1; o >>= 1) my_sum += __shfl_xor(my_sum, o, 64);
     if ((tid & 63) == 0) reinterpret_cast<long long *>(sh.part)[tid >> 6] = my_sum;
     __syncthreads();
-    unsigned long long *sum_gran = P.granules + (size_t)G * (2 * kIcpSums);  // the partials' buffer of odd iterations; first used by iteration 1
-    const __amdgpu_buffer_rsrc_t sum_rsrc = granule_rsrc(sum_gran, (unsigned)(G * 2 * kIcpSums * sizeof(unsigned long long)));
+    unsigned long long *sum_gran = P.granules + (size_t)G * (2 * kIcpGranStride);  // the partials' buffer of odd iterations; first used by iteration 1
+    const __amdgpu_buffer_rsrc_t sum_rsrc = granule_rsrc(sum_gran, (unsigned)(G * 2 * kIcpGranStride * sizeof(unsigned long long)));
     if (tid == 0) {
         long long t = 0;
 #pragma unroll
         for (int w = 0; w < kIcpThreads / 64; ++w) t += reinterpret_cast<long long *>(sh.part)[w];
-        granule_store_pair(sum_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums) * 16), epoch_base, (unsigned)(unsigned long long)t,
+        granule_store_pair(sum_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpGranStride) * 16), epoch_base, (unsigned)(unsigned long long)t,
                            (unsigned)((unsigned long long)t >> 32));
     }
     bool pfail = false;
     if (tid < G) {  // thread t fetches the sum of slice t
         unsigned long long lo, hi;
-        const unsigned off = (unsigned)(((size_t)tid * kIcpSums) * 16);
+        const unsigned off = (unsigned)(((size_t)tid * kIcpGranStride) * 16);
         granule_load_pair(sum_rsrc, off, lo, hi);
         unsigned spins = 0;
         while ((unsigned)(lo >> 32) != epoch_base || (unsigned)(hi >> 32) != epoch_base) {
@@ -2142,13 +2142,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         if (PROF && lane == 0) part_t[kIcpTickSlot * kIcpSumRows + grp] = (double)t_group;  // this group's search time (profiling, max-reduced)
         __syncthreads();
         const unsigned epoch = epoch_base + (unsigned)it + 1u;
-        unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpSums);
-        const __amdgpu_buffer_rsrc_t gran_rsrc = granule_rsrc(gran, (unsigned)(G * 2 * kIcpSums * sizeof(unsigned long long)));
+        unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpGranStride);
+        const __amdgpu_buffer_rsrc_t gran_rsrc = granule_rsrc(gran, (unsigned)(G * 2 * kIcpGranStride * sizeof(unsigned long long)));
         if (tid < kIcpSums) {
             const int k = tid;
             const double v = icp_row_sum<PROF>(part_t + k * kIcpSumRows, kIcpGroupsPerBlock, k == kIcpTickSlot);
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-            granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + k) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
+            granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpGranStride + k) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
         }
         // ---- exchange: leaders sum their groups, every workgroup sums the groups and solves ----------------------
         // (One root gathering all G partials -- round 2 -- had 224 x 19 granule pairs queue up in ONE CU's memory
@@ -2156,8 +2156,8 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // partial -- round 1 -- moved 17.5 MB per iteration.)
         const unsigned c2 = PROF ? ticks32() : 0u;
         const int ng = min(kIcpExchangeGroups, G);  // groups = leaders; group g holds the workgroups g, g + ng, g + 2 ng, ...
-        unsigned long long *grp_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpSums) + (size_t)(it & 1) * kIcpExchangeGroups * (2 * kIcpSums);
-        const __amdgpu_buffer_rsrc_t grp_rsrc = granule_rsrc(grp_gran, (unsigned)(kIcpExchangeGroups * 2 * kIcpSums * sizeof(unsigned long long)));
+        unsigned long long *grp_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpGranStride) + (size_t)(it & 1) * kIcpExchangeGroups * (2 * kIcpGranStride);
+        const __amdgpu_buffer_rsrc_t grp_rsrc = granule_rsrc(grp_gran, (unsigned)(kIcpExchangeGroups * 2 * kIcpGranStride * sizeof(unsigned long long)));
         // poll one granule pair until both halves carry this iteration's tag; false: gave up (bounded spin, or another
         // workgroup has already raised the timeout)
         auto poll_pair = [&](const __amdgpu_buffer_rsrc_t &r, unsigned off, double &out) -> bool {
@@ -2183,7 +2183,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 for (int j = tidv / kIcpSums; j < members; j += kIcpParts) {
                     const int b = (int)blockIdx.x + ng * j;
                     double v = 0.0;
-                    if (!poll_pair(gran_rsrc, (unsigned)(((size_t)b * kIcpSums + k) * 16), v)) sh.fail = 1;
+                    if (!poll_pair(gran_rsrc, (unsigned)(((size_t)b * kIcpGranStride + k) * 16), v)) sh.fail = 1;
                     sums_t[k * kIcpSumRows + j] = v;
                 }
             }
@@ -2194,7 +2194,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 const int leader_failed = sh.fail;
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
                 if (!leader_failed)
-                    granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpSums + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
+                    granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpGranStride + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
             }
             __syncthreads();  // range_sum is reused below
         }
@@ -2208,14 +2208,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         if (!kIcpPollAll) {
             if (tid < ng && !sh.fail) {
                 double dummy;
-                if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpSums) * 16), dummy)) sh.fail = 1;
+                if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpGranStride) * 16), dummy)) sh.fail = 1;
             }
             __syncthreads();
         }
         for (int e = tidv; e < ng * kIcpSums; e += kIcpThreads) {  // (a poll that follows a failure gives up by the error word: poll_pair)
             const int k = e % kIcpSums, g = e / kIcpSums;
             double v = 0.0;
-            if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpSums + k) * 16), v)) sh.fail = 1;
+            if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpGranStride + k) * 16), v)) sh.fail = 1;
             sums_t[k * kIcpSumRows + g] = v;
         }
         __syncthreads();
@@ -2381,7 +2381,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 }
 
 size_t icp_granule_words(int G) {  // the workgroups' partials, then the leaders' group sums; both twice (iteration parity)
-    return (size_t)2 * G * 2 * kIcpSums + (size_t)2 * kIcpExchangeGroups * 2 * kIcpSums;
+    return (size_t)2 * G * 2 * kIcpGranStride + (size_t)2 * kIcpExchangeGroups * 2 * kIcpGranStride;
 }
 
 int icp_prepare(int device_id) {

@@ -214,6 +214,12 @@ struct PipeState {
 constexpr int kIcpSums = 19;  // 16 normal-equation scalars + correspondence count + examined count
                               // + one profiling slot (association ticks, max-reduced)
 constexpr int kIcpTickSlot = 18;
+// 16-byte slots from one workgroup's block of granule pairs to the next: 24 -- blocks of 384 bytes, three 128-byte lines that no
+// other workgroup writes.  Packed (19 slots, 304 bytes) most lines were written by TWO workgroups, as a rule on different XCDs:
+// the exchange alone, 224 workgroups, scripts/probes/xchg_bench.hip: 3.23 us per round packed, 2.97 at 24 slots (32: 3.24 --
+// four lines, the same channels again); profiles/r06_ac_*.
+constexpr int kIcpGranStride = 24;
+static_assert(kIcpGranStride >= kIcpSums && (kIcpGranStride * 16) % 128 == 0, "whole lines per workgroup");
 constexpr int kIcpThreads = 512;
 constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 probe lanes)
 constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;  // 16
@@ -282,7 +288,7 @@ struct IcpParams {
     double min_motion_th;           // AdaptiveThreshold::min_motion_threshold_ (pipeline mode)
     int max_iters;
     double conv;
-    unsigned long long *granules;  // [2][gridDim.x][kIcpSums * 2] tagged 8-byte words
+    unsigned long long *granules;  // [2][gridDim.x][kIcpGranStride * 2] tagged 8-byte words (kIcpSums pairs used of each block)
     unsigned spin_limit;
     int points_per_group;  // target points per 32-lane group and iteration (sets how many
                            // of the launched workgroups take part: ceil(n / (8 * this)))
