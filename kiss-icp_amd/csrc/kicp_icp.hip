@@ -1234,7 +1234,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // good part of the registers that did not fit.)
         const int tidv = kicp_tid();
         const int tid = tidv, lane = tidv & (kIcpGroup - 1), grp = tidv / kIcpGroup;
-        const int ck = tidv % kIcpTerms, cg = tidv / kIcpTerms;  // phase C: term and group of this thread
+        // phase C: term and group of this thread.  kIcpPublishDpp: a term's 16 groups on the 16 lanes of one DPP row (thread 16 k + g),
+        // so that the workgroup's sum of term k is four row operations away and goes to memory from the lane that holds it -- no
+        // LDS round trip, no barrier and no chain of sixteen additions between phase C and the first hop (the exchange alone:
+        // publish 0.36 -> 0.16 us, scripts/probes/xchg_bench.hip).  The groups' sums are then added as a tree, not one after the
+        // other: the same tree in every workgroup, launch and form.
+        const int ck = kIcpPublishDpp ? tidv / kIcpGroupsPerBlock : tidv % kIcpTerms, cg = kIcpPublishDpp ? tidv % kIcpGroupsPerBlock : tidv / kIcpTerms;
+        const bool c_on = kIcpPublishDpp ? ck < kIcpTerms : cg < kIcpGroupsPerBlock;
+        static_assert(kIcpGroupsPerBlock == 16 && kIcpTerms * kIcpGroupsPerBlock <= kIcpThreads, "a DPP row per term");
         double acc = 0.0;
         unsigned t_group = 0;
         unsigned prof_path = 0;
@@ -1810,7 +1817,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                         }
                     }
                     __syncthreads();
-                    if (cg < kIcpGroupsPerBlock) {
+                    if (c_on) {
                         // term ck of the points cg, cg + 16, ... in that order, four asked for together (eight: this form's registers
                         // are all taken, the kernel spills)
                         constexpr int kPer = 4;
@@ -2111,7 +2118,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                     icp_terms_row(pt.s, pt.nn, pt.d2, pt.E, max_dist, ks, terms[tid]);
                 }
                 __syncthreads();
-                if (cg < kIcpGroupsPerBlock) {
+                if (c_on) {
                     // term ck of the points cg, cg + 16, ... in that order: all (at most four) asked for together
                     double a[kIcpTermChunk / kIcpGroupsPerBlock];
 #pragma unroll
@@ -2138,13 +2145,28 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         const unsigned c1 = PROF ? ticks32() : 0u;
         // (the stages' values lie transposed -- [scalar][contributor] --: icp_row_sum)
         double *const part_t = &sh.part[0][0], *const sums_t = &sh.range_sum[0][0];
-        if (cg < kIcpGroupsPerBlock) part_t[ck * kIcpSumRows + cg] = acc;
+        if (!kIcpPublishDpp && c_on) part_t[ck * kIcpSumRows + cg] = acc;
         if (PROF && lane == 0) part_t[kIcpTickSlot * kIcpSumRows + grp] = (double)t_group;  // this group's search time (profiling, max-reduced)
-        __syncthreads();
+        if (!kIcpPublishDpp || PROF) __syncthreads();
         const unsigned epoch = epoch_base + (unsigned)it + 1u;
         unsigned long long *gran = P.granules + (size_t)(it & 1) * G * (2 * kIcpGranStride);
         const __amdgpu_buffer_rsrc_t gran_rsrc = granule_rsrc(gran, (unsigned)(G * 2 * kIcpGranStride * sizeof(unsigned long long)));
-        if (tid < kIcpSums) {
+        // (the release build leaves the profiling slot -- the last one -- out of the exchange: one pair less per block, ~0.06 us
+        // of the exchange alone, scripts/probes/xchg_bench.hip)
+        constexpr int KX = PROF ? kIcpSums : kIcpSums - 1;
+        static_assert(kIcpTickSlot == kIcpSums - 1, "the profiling slot is the last");
+        if (kIcpPublishDpp) {
+            if (c_on) {
+                const double v = row16_sum(acc);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                if (cg == 0) granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpGranStride + ck) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
+            }
+            if (PROF && tid == kIcpTickSlot) {
+                const double v = icp_row_sum<PROF>(part_t + tid * kIcpSumRows, kIcpGroupsPerBlock, true);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                granule_store_pair(gran_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpGranStride + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
+            }
+        } else if (tid < KX) {
             const int k = tid;
             const double v = icp_row_sum<PROF>(part_t + k * kIcpSumRows, kIcpGroupsPerBlock, k == kIcpTickSlot);
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -2156,8 +2178,13 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         // partial -- round 1 -- moved 17.5 MB per iteration.)
         const unsigned c2 = PROF ? ticks32() : 0u;
         const int ng = min(kIcpExchangeGroups, G);  // groups = leaders; group g holds the workgroups g, g + ng, g + 2 ng, ...
-        unsigned long long *grp_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpGranStride) + (size_t)(it & 1) * kIcpExchangeGroups * (2 * kIcpGranStride);
-        const __amdgpu_buffer_rsrc_t grp_rsrc = granule_rsrc(grp_gran, (unsigned)(kIcpExchangeGroups * 2 * kIcpGranStride * sizeof(unsigned long long)));
+        // (the group sums lie there kIcpGroupCopies times, a workgroup reads copy b mod 8 -- its XCD's, as workgroups are placed --: a
+        // line is polled by 28 workgroups instead of 224, the second hop 1.08 -> 0.92 us in the exchange alone: profiles/r06_ae_*)
+        unsigned long long *grp_gran = P.granules + (size_t)2 * kIcpMaxBlocks * (2 * kIcpGranStride) +
+                                       (size_t)(it & 1) * kIcpGroupCopies * kIcpExchangeGroups * (2 * kIcpGranStride);
+        const __amdgpu_buffer_rsrc_t grp_rsrc =
+            granule_rsrc(grp_gran, (unsigned)(kIcpGroupCopies * kIcpExchangeGroups * 2 * kIcpGranStride * sizeof(unsigned long long)));
+        const int my_copy = (int)blockIdx.x % kIcpGroupCopies;
         // poll one granule pair until both halves carry this iteration's tag; false: gave up (bounded spin, or another
         // workgroup has already raised the timeout)
         auto poll_pair = [&](const __amdgpu_buffer_rsrc_t &r, unsigned off, double &out) -> bool {
@@ -2178,9 +2205,10 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         if ((int)blockIdx.x < ng) {
             // leader: thread (k, j) fetches scalar k of the group's j-th member; 26 members per pass, all of a pass in flight
             const int members = (G - (int)blockIdx.x + ng - 1) / ng;  // <= kIcpMaxMembers
-            if (tid < kIcpParts * kIcpSums) {
-                const int k = tidv % kIcpSums;
-                for (int j = tidv / kIcpSums; j < members; j += kIcpParts) {
+            constexpr int kParts = kIcpThreads / KX;
+            if (tid < kParts * KX) {
+                const int k = tidv % KX;
+                for (int j = tidv / KX; j < members; j += kParts) {
                     const int b = (int)blockIdx.x + ng * j;
                     double v = 0.0;
                     if (!poll_pair(gran_rsrc, (unsigned)(((size_t)b * kIcpGranStride + k) * 16), v)) sh.fail = 1;
@@ -2188,13 +2216,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
                 }
             }
             __syncthreads();
-            if (tid < kIcpSums) {
+            if (tid < KX) {
                 // (the failure flag is read beside the row, not in front of it: one LDS round trip on the path from the first hop to the second)
                 const double v = icp_row_sum<PROF>(sums_t + tid * kIcpSumRows, members, tid == kIcpTickSlot);  // member order: fixed by G alone
                 const int leader_failed = sh.fail;
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                if (!leader_failed)
-                    granule_store_pair(grp_rsrc, (unsigned)(((size_t)blockIdx.x * kIcpGranStride + tid) * 16), epoch, (unsigned)bits, (unsigned)(bits >> 32));
+                if (!leader_failed) {
+#pragma unroll
+                    for (int c = 0; c < kIcpGroupCopies; ++c)
+                        granule_store_pair(grp_rsrc, (unsigned)((((size_t)c * kIcpExchangeGroups + blockIdx.x) * kIcpGranStride + tid) * 16), epoch, (unsigned)bits,
+                                           (unsigned)(bits >> 32));
+                }
             }
             __syncthreads();  // range_sum is reused below
         }
@@ -2208,14 +2240,14 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
         if (!kIcpPollAll) {
             if (tid < ng && !sh.fail) {
                 double dummy;
-                if (!poll_pair(grp_rsrc, (unsigned)(((size_t)tid * kIcpGranStride) * 16), dummy)) sh.fail = 1;
+                if (!poll_pair(grp_rsrc, (unsigned)((((size_t)my_copy * kIcpExchangeGroups + tid) * kIcpGranStride) * 16), dummy)) sh.fail = 1;
             }
             __syncthreads();
         }
-        for (int e = tidv; e < ng * kIcpSums; e += kIcpThreads) {  // (a poll that follows a failure gives up by the error word: poll_pair)
-            const int k = e % kIcpSums, g = e / kIcpSums;
+        for (int e = tidv; e < ng * KX; e += kIcpThreads) {  // (a poll that follows a failure gives up by the error word: poll_pair)
+            const int k = e % KX, g = e / KX;
             double v = 0.0;
-            if (!poll_pair(grp_rsrc, (unsigned)(((size_t)g * kIcpGranStride + k) * 16), v)) sh.fail = 1;
+            if (!poll_pair(grp_rsrc, (unsigned)((((size_t)my_copy * kIcpExchangeGroups + g) * kIcpGranStride + k) * 16), v)) sh.fail = 1;
             sums_t[k * kIcpSumRows + g] = v;
         }
         __syncthreads();
@@ -2381,7 +2413,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
 }
 
 size_t icp_granule_words(int G) {  // the workgroups' partials, then the leaders' group sums; both twice (iteration parity)
-    return (size_t)2 * G * 2 * kIcpGranStride + (size_t)2 * kIcpExchangeGroups * 2 * kIcpGranStride;
+    return (size_t)2 * G * 2 * kIcpGranStride + (size_t)2 * kIcpGroupCopies * kIcpExchangeGroups * 2 * kIcpGranStride;
 }
 
 int icp_prepare(int device_id) {

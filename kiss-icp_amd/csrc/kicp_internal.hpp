@@ -225,10 +225,11 @@ constexpr int kIcpGroup = 32;  // lanes cooperating on one source point (27 prob
 constexpr int kIcpGroupsPerBlock = kIcpThreads / kIcpGroup;  // 16
 constexpr int kIcpSolveThreads = 256;  // waves 0..3 (one per SIMD) solve the 6x6 system, the rest wait
 constexpr int kIcpBookThread = kIcpThreads - 64;  // first lane of the last wave: pose / statistics bookkeeping
-constexpr int kIcpParts = kIcpThreads / kIcpSums;  // 26 (scalar, member) pairs gathered per pass by a leader
 constexpr int kIcpExchangeGroups = 16;  // leaders of the two-level exchange (workgroups 0..15).  Measured on one box, bench
                                         // scene (profiles/r04_ak_exchange_leaders_ab.txt): 4 leaders 2602, 8: 2785, 16: 2856,
                                         // 32: 2715, 64: 2459 scans/s -- the first hop gets shorter, the second longer
+constexpr int kIcpGroupCopies = 8;      // copies of every leader's group sums (kicp_icp.hip: a workgroup polls copy b mod 8)
+constexpr bool kIcpPublishDpp = true;   // a workgroup's sums over its 16 groups by DPP row operations, stored by the lane that holds them (kicp_icp.hip)
 constexpr bool kIcpPollAll = true;      // the second hop without its watcher lanes (kicp_icp.hip; false: round 3's form, for A/Bs)
 constexpr bool kIcpSpreadSearches = true;  // group form, phase B: the first searches of a workgroup on different waves (kicp_icp.hip)
 constexpr int kIcpMaxMembers = 16;      // workgroups per leader at most (256 / 16)

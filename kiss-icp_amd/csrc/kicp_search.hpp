@@ -45,6 +45,23 @@ __device__ __forceinline__ void granule_store_pair(__amdgpu_buffer_rsrc_t r, uns
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_offset, 0, 16);
 }
 
+// The sum of the 16 lanes of a DPP row, in every lane of it: four steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) --
+// the same tree whatever the lane: a + b on one side is b + a on the other.  All 16 lanes of the row must be active.
+template <int CTRL>
+__device__ __forceinline__ double row16_dpp(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v = v + row16_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v = v + row16_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v = v + row16_dpp<0x141>(v);  // row_half_mirror
+    v = v + row16_dpp<0x140>(v);  // row_mirror
+    return v;
+}
+
 // The thread index through an empty asm statement: the compiler cannot prove two reads equal or loop-invariant, so what is
 // derived from it (predicates, lane numbers, LDS addresses) is computed where it is used -- one v_and -- instead of being
 // hoisted out of k_icp's iteration loop and kept alive across it (kicp_icp.hip: the loop's own tid, and why).

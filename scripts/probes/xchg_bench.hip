@@ -56,6 +56,22 @@ __device__ __forceinline__ double row_sum(const double *row, int count) {
     }
     return v;
 }
+// the sum of the 16 lanes of a DPP row, in every lane of it: four steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), the
+// same tree whatever the lane -- a + b on one side is b + a on the other
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v = v + dpp_f64<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v = v + dpp_f64<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v = v + dpp_f64<0x141>(v);  // row_half_mirror
+    v = v + dpp_f64<0x140>(v);  // row_mirror
+    return v;
+}
 __device__ __forceinline__ void busy(unsigned ticks) {  // 10 ns ticks
     const unsigned long long t0 = wall_clock64();
     while ((unsigned)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
@@ -102,13 +118,22 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         busy(P.work_ticks + (P.jitter_ticks ? (rng >> 8) % P.jitter_ticks : 0u));
         const unsigned s0 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         // ---- workgroup reduction
-        if (cg < kRows) part_t[ck * kRows + cg] = (cg == 0) ? (double)(b + 1) * (double)(ck + 1) + (double)it : 0.0;
-        if (tid < kRows) part_t[18 * kRows + tid] = 0.0;
-        __syncthreads();
+        if (MODE != 5) {
+            if (cg < kRows) part_t[ck * kRows + cg] = (cg == 0) ? (double)(b + 1) * (double)(ck + 1) + (double)it : 0.0;
+            if (tid < kRows) part_t[18 * kRows + tid] = 0.0;
+            __syncthreads();
+        }
         const unsigned epoch = P.epoch_base + (unsigned)it + 1u;
         unsigned long long *gran = P.gran + (size_t)(it & 1) * kMaxBlocks * (2 * ST);
         const __amdgpu_buffer_rsrc_t gran_r = rsrc_of(gran, (unsigned)(kMaxBlocks * 2 * ST * 8));
-        if (tid < kSums) store_pair(gran_r, (unsigned)((b * ST + tid) * 16), epoch, row_sum(part_t + tid * kRows, kRows));
+        const int rk = tid >> 4, rl = tid & 15;  // MODE 5: scalar and addend of this lane (a DPP row per scalar)
+        if (MODE == 5) {
+            if (rk < kSums) {
+                const double mine = (rl == 0 && rk < 18) ? (double)(b + 1) * (double)(rk + 1) + (double)it : 0.0;
+                const double v = row16_sum(mine);
+                if (rl == 0) store_pair(gran_r, (unsigned)((b * ST + rk) * 16), epoch, v);
+            }
+        } else if (tid < kSums) store_pair(gran_r, (unsigned)((b * ST + tid) * 16), epoch, row_sum(part_t + tid * kRows, kRows));
         const unsigned s1 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         auto poll = [&](const __amdgpu_buffer_rsrc_t &r, unsigned off, double &out) -> bool {
             unsigned long long lo, hi;
@@ -125,8 +150,8 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         const int ng = NG < G ? NG : G;
         unsigned long long *grp_gran = P.grp_gran + (size_t)(it & 1) * 64 * (2 * ST);
         const __amdgpu_buffer_rsrc_t grp_r = rsrc_of(grp_gran, (unsigned)(64 * 2 * ST * 8));
-        unsigned long long *mbox = P.mailbox + (size_t)(it & 1) * kMaxBlocks * NG * (2 * kSums);
-        const __amdgpu_buffer_rsrc_t mbox_r = rsrc_of(mbox, (unsigned)((size_t)kMaxBlocks * NG * 2 * kSums * 8));
+        unsigned long long *mbox = P.mailbox + (size_t)(it & 1) * kMaxBlocks * 64 * (2 * kSumsMax);
+        const __amdgpu_buffer_rsrc_t mbox_r = rsrc_of(mbox, (unsigned)((size_t)kMaxBlocks * 64 * 2 * kSumsMax * 8));
         unsigned s2 = s1, s3 = s1;
         // fetch `count` pairs {base + i * stride} until all carry the tag, add them in order (MODE 4)
         auto gather_sum = [&](const __amdgpu_buffer_rsrc_t &r, unsigned base_off, unsigned stride, int count, double &out) -> bool {
@@ -151,7 +176,22 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
             out = v;
             return true;
         };
-        if (MODE == 4) {
+        if (MODE == 5) {
+            if (b < ng && rk < kSums) {
+                const int members = (G - b + ng - 1) / ng;
+                double v = 0.0;
+                if (rl < members && !poll(gran_r, (unsigned)(((b + ng * rl) * ST + rk) * 16), v)) *fail = 1;
+                v = row16_sum(v);
+                if (rl == 0) store_pair(grp_r, (unsigned)((b * ST + rk) * 16), epoch, v);
+            }
+            if (rk < kSums) {
+                double v = 0.0;
+                if (rl < ng && !poll(grp_r, (unsigned)((rl * ST + rk) * 16), v)) *fail = 1;
+                v = row16_sum(v);
+                if (rl == 0) tot[rk] = v;
+            }
+            __syncthreads();
+        } else if (MODE == 4) {
             if (b < ng) {
                 const int members = (G - b + ng - 1) / ng;
                 if (tid < kSums) {
@@ -188,6 +228,16 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                         const int w = e / kSums, k = e % kSums;
                         store_pair(mbox_r, (unsigned)(((w * NG + b) * kSums + k) * 16), epoch, tot[k]);
                     }
+            } else if (MODE == 6 || MODE == 7) {
+                // a copy of the group's sums per XCD (MODE 6: 8 copies, MODE 7: 2): a line is polled by 28 (112) workgroups, not 224
+                constexpr int COPIES = MODE == 6 ? 8 : 2;
+                if (tid < kSums) {
+                    const double v = row_sum(sums_t + tid * kRows, members);
+                    if (!*fail) {
+#pragma unroll
+                        for (int c = 0; c < COPIES; ++c) store_pair(mbox_r, (unsigned)(((c * 64 + b) * ST + tid) * 16), epoch, v);
+                    }
+                }
             } else if (tid < kSums) {
                 const double v = row_sum(sums_t + tid * kRows, members);
                 if (!*fail) store_pair(grp_r, (unsigned)((b * ST + tid) * 16), epoch, v);
@@ -196,12 +246,21 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
             s3 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         }
         // ---- second hop
-        if (MODE == 4) {
+        if (MODE == 4 || MODE == 5) {
         } else if (MODE == 0) {
             for (int e = tid; e < ng * kSums; e += kThreads) {
                 const int k = e % kSums, g = e / kSums;
                 double v = 0.0;
                 if (!poll(grp_r, (unsigned)((g * ST + k) * 16), v)) *fail = 1;
+                sums_t[k * kRows + g] = v;
+            }
+        } else if (MODE == 6 || MODE == 7) {
+            constexpr int COPIES = MODE == 6 ? 8 : 2;
+            const int c = b % COPIES;
+            for (int e = tid; e < ng * kSums; e += kThreads) {
+                const int k = e % kSums, g = e / kSums;
+                double v = 0.0;
+                if (!poll(mbox_r, (unsigned)(((c * 64 + g) * ST + k) * 16), v)) *fail = 1;
                 sums_t[k * kRows + g] = v;
             }
         } else if (MODE == 2) {
@@ -242,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         }
         __syncthreads();
         const unsigned s4 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
-        if (MODE != 4 && tid < kSums) tot[tid] = row_sum(sums_t + tid * kRows, ng);
+        if (MODE != 4 && MODE != 5 && tid < kSums) tot[tid] = row_sum(sums_t + tid * kRows, ng);
         if (*fail) {
             if (tid == 0) atomicOr(P.err, 1);
             break;
@@ -345,16 +404,13 @@ int main(int argc, char **argv) {
     // work 2.0 us, solve 1.4 us: what surrounds the exchange in a later iteration of the bench scene
     for (int pass = 0; pass < 2; ++pass) {
         const unsigned jitter = pass == 0 ? 0u : 150u;  // 0 / up to 1.5 us of imbalance per workgroup and round
-        run<16, 0, 2, false>("product form: 19 scalars, stride 19", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 19, 24>("  19 scalars, stride 24 (384 B)", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 19, 32>("  19 scalars, stride 32 (512 B)", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 18, 24>("  18 scalars, stride 24", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 16, 16>("  16 scalars, stride 16 (256 B)", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 16, 24>("  16 scalars, stride 24", G, iters, 200, jitter, 140, A);
-        run<16, 0, 0, false, 16, 16>("  16 scalars, stride 16, sleep 0", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 8, 8>("  8 scalars, stride 8 (128 B)", G, iters, 200, jitter, 140, A);
+        run<16, 0, 2, false, 19, 24>("product form: 19 scalars, stride 24", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 19, 24>("  group sums in 8 copies (one per XCD)", G, iters, 200, jitter, 140, A);
+        run<16, 7, 2, false, 19, 24>("  group sums in 2 copies", G, iters, 200, jitter, 140, A);
+        run<16, 0, 2, false, 18, 24>("  18 scalars", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24>("  18 scalars, 8 copies", G, iters, 200, jitter, 140, A);
     }
-    run<16, 0, 2, true, 19, 24>("19 scalars, stride 24, stamps", G, iters, 200, 0, 140, A);
-    run<16, 0, 2, true, 16, 16>("16 scalars, stride 16, stamps", G, iters, 200, 0, 140, A);
+    run<16, 0, 2, true, 19, 24>("product form, stamps", G, iters, 200, 0, 140, A);
+    run<16, 6, 2, true, 19, 24>("8 copies, stamps", G, iters, 200, 0, 140, A);
     return 0;
 }
