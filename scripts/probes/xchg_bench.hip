@@ -84,6 +84,7 @@ struct Args {
     int G, iters;
     unsigned epoch_base, spin_limit;
     unsigned work_ticks, jitter_ticks, solve_ticks;
+    unsigned tail_permille, tail_ticks;  // with this probability a workgroup's round is longer by tail_ticks (a search with a list build)
     unsigned *stamps;  // [iters][6]: workgroup 0's stage ends, 10 ns ticks from the round's start
     int *err;
 };
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         const unsigned long long t_start = STAMPS ? wall_clock64() : 0ull;
         // ---- "association": a fixed wait plus this workgroup's share of the jitter
         rng = rng * 1664525u + 1013904223u;
-        busy(P.work_ticks + (P.jitter_ticks ? (rng >> 8) % P.jitter_ticks : 0u));
+        unsigned extra = P.jitter_ticks ? (rng >> 8) % P.jitter_ticks : 0u;
+        rng = rng * 1664525u + 1013904223u;
+        if (P.tail_permille && (rng >> 10) % 1000u < P.tail_permille) extra += P.tail_ticks;
+        busy(P.work_ticks + extra);
         const unsigned s0 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         // ---- workgroup reduction
         if (MODE != 5) {
@@ -401,16 +405,20 @@ int main(int argc, char **argv) {
     CK(hipMemset(A.gran, 0, gran_bytes));
     CK(hipMemset(A.grp_gran, 0, grp_bytes));
     CK(hipMemset(A.mailbox, 0, mbox_bytes));
-    // work 2.0 us, solve 1.4 us: what surrounds the exchange in a later iteration of the bench scene
-    for (int pass = 0; pass < 2; ++pass) {
-        const unsigned jitter = pass == 0 ? 0u : 150u;  // 0 / up to 1.5 us of imbalance per workgroup and round
-        run<16, 0, 2, false, 19, 24>("product form: 19 scalars, stride 24", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 19, 24>("  group sums in 8 copies (one per XCD)", G, iters, 200, jitter, 140, A);
-        run<16, 7, 2, false, 19, 24>("  group sums in 2 copies", G, iters, 200, jitter, 140, A);
-        run<16, 0, 2, false, 18, 24>("  18 scalars", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 18, 24>("  18 scalars, 8 copies", G, iters, 200, jitter, 140, A);
+    // What a tail of slow workgroups costs a round: the association as the probe of the bench scene sees it in a later iteration --
+    // A + C 1.5 us, half the workgroups without a search, the others 1.2 - 2.2 us of it, and a few per cent with a list build
+    // (+0.9 us) on top -- against the same without the builds.
+    for (int rep = 0; rep < 2; ++rep) {
+        A.tail_permille = 0;
+        run<16, 0, 2, false, 18, 24>("work 1.5 + U(0, 2.2), no tail", G, iters, 150, 220, 140, A);
+        A.tail_permille = 40; A.tail_ticks = 90;
+        run<16, 0, 2, false, 18, 24>("  + 0.9 us for 4 % of the workgroups", G, iters, 150, 220, 140, A);
+        A.tail_permille = 100; A.tail_ticks = 90;
+        run<16, 0, 2, false, 18, 24>("  + 0.9 us for 10 %", G, iters, 150, 220, 140, A);
+        A.tail_permille = 0;
+        run<16, 0, 2, false, 18, 24>("work 1.5 + U(0, 1.5), no tail", G, iters, 150, 150, 140, A);
+        run<16, 0, 2, false, 18, 24>("work 1.5 + U(0, 1.0), no tail", G, iters, 150, 100, 140, A);
+        run<16, 0, 2, false, 18, 24>("work 1.5, nothing else", G, iters, 150, 0, 140, A);
     }
-    run<16, 0, 2, true, 19, 24>("product form, stamps", G, iters, 200, 0, 140, A);
-    run<16, 6, 2, true, 19, 24>("8 copies, stamps", G, iters, 200, 0, 140, A);
     return 0;
 }
