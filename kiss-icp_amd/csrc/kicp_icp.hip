@@ -27,13 +27,14 @@ namespace kicp {
 //   C  one thread per point: keep iff d < max_dist (strict, :72), w = sigma^2 / (sigma + |r|^2)^2, the 16 unique
 //      scalars of J^T w J and J^T w r with J = [I | -hat(s)], r = s - nn (:81-98), added in point order.
 // The exchange, once per iteration (tagged 16-byte granule pairs, sc1 stores and loads: the data is its own flag):
-//   1. every workgroup publishes its 18 partial sums;
+//   1. every workgroup publishes its 18 partial sums (its 16 groups' sums of a term added by four DPP row operations, stored by the
+//      lane that holds them), a block of 384 bytes -- three lines nobody else writes;
 //   2. workgroup g < 16 (a "leader") gathers the partials of the workgroups b = g, g + 16, g + 32, ... (at most 16),
-//      sums them in that order and publishes the group's sums;
+//      sums them in that order and publishes the group's sums, in eight copies (a workgroup reads copy b mod 8);
 //   3. EVERY workgroup gathers the (at most) 16 group sums, adds them in order, and solves the same 6x6 system on its
 //      first four waves: dx = LDLT(JTJ).solve(-JTr), est = exp(dx), stop when |dx| < convergence_criterion
 //      (:156-163); workgroup 0 also keeps T_icp = est * T_icp and the statistics.
-// Two short hops (14 x 304 B into 16 CUs, then 16 x 304 B into every CU) instead of one long one (224 x 304 B into ONE
+// Two short hops (14 x 288 B into 16 CUs, then 16 x 288 B into every CU) instead of one long one (224 x 288 B into ONE
 // CU's memory queue) plus a broadcast hop for the result; the summation tree depends on G only, never on timing or
 // placement, so results are reproducible bit for bit.
 // ------------------------------------------------------------------------------------------
