@@ -97,9 +97,11 @@ struct Args {
 // KS: scalars a workgroup exchanges (the product: 19 -- 16 of the normal equations, two counts, the profiling build's slot)
 // ST: 16-byte slots between one workgroup's block of pairs and the next (the product: 19 -- blocks of 304 bytes, so that most
 //     128-byte lines are written by TWO workgroups, which as a rule sit on different XCDs)
-template <int NG, int MODE, int SLEEP, bool STAMPS = true, int KS = kSumsMax, int ST = KS>
+template <int NG, int MODE, int SLEEP, bool STAMPS = true, int KS = kSumsMax, int ST = KS, bool GM = false>
 __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
     constexpr int kSums = KS;
+    // GM: the blocks of a leader's members lie side by side (block of workgroup w at (w mod NG) * 16 + w / NG) instead of NG blocks apart
+    auto place = [](int w) { return GM ? (w % NG) * kRows + w / NG : w; };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *part_t = reinterpret_cast<double *>(smem);  // [kSums][kRows]
     double *sums_t = part_t + kSumsMax * kRows;          // [kSums][kRows]
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                 const double v = row16_sum(mine);
                 if (rl == 0) store_pair(gran_r, (unsigned)((b * ST + rk) * 16), epoch, v);
             }
-        } else if (tid < kSums) store_pair(gran_r, (unsigned)((b * ST + tid) * 16), epoch, row_sum(part_t + tid * kRows, kRows));
+        } else if (tid < kSums) store_pair(gran_r, (unsigned)((place(b) * ST + tid) * 16), epoch, row_sum(part_t + tid * kRows, kRows));
         const unsigned s1 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         auto poll = [&](const __amdgpu_buffer_rsrc_t &r, unsigned off, double &out) -> bool {
             unsigned long long lo, hi;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                 const int k = tid % kSums;
                 for (int j = tid / kSums; j < members; j += kParts) {
                     double v = 0.0;
-                    if (!poll(gran_r, (unsigned)(((b + ng * j) * ST + k) * 16), v)) *fail = 1;
+                    if (!poll(gran_r, (unsigned)((place(b + ng * j) * ST + k) * 16), v)) *fail = 1;
                     sums_t[k * kRows + j] = v;
                 }
             }
@@ -341,10 +343,10 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
 
 static unsigned g_epoch = 1000;
 
-template <int NG, int MODE, int SLEEP, bool STAMPS = true, int KS = kSumsMax, int ST = KS>
+template <int NG, int MODE, int SLEEP, bool STAMPS = true, int KS = kSumsMax, int ST = KS, bool GM = false>
 static void run(const char *name, int G, int iters, unsigned work, unsigned jitter, unsigned solve, Args A) {
     const int lds = 140 * 1024;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xchg<NG, MODE, SLEEP, STAMPS, KS, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xchg<NG, MODE, SLEEP, STAMPS, KS, ST, GM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     A.G = G;
     A.iters = iters;
     A.work_ticks = work;
@@ -362,7 +364,7 @@ static void run(const char *name, int G, int iters, unsigned work, unsigned jitt
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((k_xchg<NG, MODE, SLEEP, STAMPS, KS, ST>), dim3(G), dim3(kThreads), lds, 0, A);
+        hipLaunchKernelGGL((k_xchg<NG, MODE, SLEEP, STAMPS, KS, ST, GM>), dim3(G), dim3(kThreads), lds, 0, A);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -405,20 +407,13 @@ int main(int argc, char **argv) {
     CK(hipMemset(A.gran, 0, gran_bytes));
     CK(hipMemset(A.grp_gran, 0, grp_bytes));
     CK(hipMemset(A.mailbox, 0, mbox_bytes));
-    // What a tail of slow workgroups costs a round: the association as the probe of the bench scene sees it in a later iteration --
-    // A + C 1.5 us, half the workgroups without a search, the others 1.2 - 2.2 us of it, and a few per cent with a list build
-    // (+0.9 us) on top -- against the same without the builds.
-    for (int rep = 0; rep < 2; ++rep) {
-        A.tail_permille = 0;
-        run<16, 0, 2, false, 18, 24>("work 1.5 + U(0, 2.2), no tail", G, iters, 150, 220, 140, A);
-        A.tail_permille = 40; A.tail_ticks = 90;
-        run<16, 0, 2, false, 18, 24>("  + 0.9 us for 4 % of the workgroups", G, iters, 150, 220, 140, A);
-        A.tail_permille = 100; A.tail_ticks = 90;
-        run<16, 0, 2, false, 18, 24>("  + 0.9 us for 10 %", G, iters, 150, 220, 140, A);
-        A.tail_permille = 0;
-        run<16, 0, 2, false, 18, 24>("work 1.5 + U(0, 1.5), no tail", G, iters, 150, 150, 140, A);
-        run<16, 0, 2, false, 18, 24>("work 1.5 + U(0, 1.0), no tail", G, iters, 150, 100, 140, A);
-        run<16, 0, 2, false, 18, 24>("work 1.5, nothing else", G, iters, 150, 0, 140, A);
+    A.tail_permille = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const unsigned jitter = pass == 0 ? 0u : 150u;
+        run<16, 6, 2, false, 18, 24>("product form now (18 scalars, stride 24, 8 copies)", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24, true>("  a leader's members side by side", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24>("product form now, again", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24, true>("  side by side, again", G, iters, 200, jitter, 140, A);
     }
     return 0;
 }
