@@ -124,7 +124,8 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         busy(P.work_ticks + extra);
         const unsigned s0 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         // ---- workgroup reduction
-        if (MODE != 5) {
+        constexpr bool DPUB = MODE == 5 || MODE == 8 || MODE == 9;  // the workgroup's own reduction by DPP rows
+        if (!DPUB) {
             if (cg < kRows) part_t[ck * kRows + cg] = (cg == 0) ? (double)(b + 1) * (double)(ck + 1) + (double)it : 0.0;
             if (tid < kRows) part_t[18 * kRows + tid] = 0.0;
             __syncthreads();
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         unsigned long long *gran = P.gran + (size_t)(it & 1) * kMaxBlocks * (2 * ST);
         const __amdgpu_buffer_rsrc_t gran_r = rsrc_of(gran, (unsigned)(kMaxBlocks * 2 * ST * 8));
         const int rk = tid >> 4, rl = tid & 15;  // MODE 5: scalar and addend of this lane (a DPP row per scalar)
-        if (MODE == 5) {
+        if (DPUB) {
             if (rk < kSums) {
                 const double mine = (rl == 0 && rk < 18) ? (double)(b + 1) * (double)(rk + 1) + (double)it : 0.0;
                 const double v = row16_sum(mine);
@@ -182,7 +183,27 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
             out = v;
             return true;
         };
-        if (MODE == 5) {
+        if (MODE == 8) {
+            // a wave takes four scalars of all addends (lane 16 kk + j): the reduction stays inside the wave -- four DPP row operations,
+            // no LDS staging, no workgroup barrier between the hops; a wave's poll asks for one 64-byte piece of every block
+            const int wv = tid >> 6, kk = (tid >> 4) & 3, jj = tid & 15;
+            const int k8 = wv * 4 + kk;
+            const int c = b % 8;
+            if (b < ng && k8 < kSums) {
+                const int members = (G - b + ng - 1) / ng;
+                double v = 0.0;
+                if (jj < members && !poll(gran_r, (unsigned)((place(b + ng * jj) * ST + k8) * 16), v)) *fail = 1;
+                v = row16_sum(v);
+                if (jj < 8) store_pair(mbox_r, (unsigned)(((jj * 64 + b) * ST + k8) * 16), epoch, v);  // (lane c of the row stores copy c)
+            }
+            if (k8 < kSums) {
+                double v = 0.0;
+                if (jj < ng && !poll(mbox_r, (unsigned)(((c * 64 + jj) * ST + k8) * 16), v)) *fail = 1;
+                v = row16_sum(v);
+                if (jj == 0) tot[k8] = v;
+            }
+            __syncthreads();
+        } else if (MODE == 5) {
             if (b < ng && rk < kSums) {
                 const int members = (G - b + ng - 1) / ng;
                 double v = 0.0;
@@ -234,9 +255,9 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                         const int w = e / kSums, k = e % kSums;
                         store_pair(mbox_r, (unsigned)(((w * NG + b) * kSums + k) * 16), epoch, tot[k]);
                     }
-            } else if (MODE == 6 || MODE == 7) {
+            } else if (MODE == 6 || MODE == 7 || MODE == 9) {
                 // a copy of the group's sums per XCD (MODE 6: 8 copies, MODE 7: 2): a line is polled by 28 (112) workgroups, not 224
-                constexpr int COPIES = MODE == 6 ? 8 : 2;
+                constexpr int COPIES = MODE == 7 ? 2 : 8;
                 if (tid < kSums) {
                     const double v = row_sum(sums_t + tid * kRows, members);
                     if (!*fail) {
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
             s3 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         }
         // ---- second hop
-        if (MODE == 4 || MODE == 5) {
+        if (MODE == 4 || MODE == 5 || MODE == 8) {
         } else if (MODE == 0) {
             for (int e = tid; e < ng * kSums; e += kThreads) {
                 const int k = e % kSums, g = e / kSums;
@@ -260,8 +281,8 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                 if (!poll(grp_r, (unsigned)((g * ST + k) * 16), v)) *fail = 1;
                 sums_t[k * kRows + g] = v;
             }
-        } else if (MODE == 6 || MODE == 7) {
-            constexpr int COPIES = MODE == 6 ? 8 : 2;
+        } else if (MODE == 6 || MODE == 7 || MODE == 9) {
+            constexpr int COPIES = MODE == 7 ? 2 : 8;
             const int c = b % COPIES;
             for (int e = tid; e < ng * kSums; e += kThreads) {
                 const int k = e % kSums, g = e / kSums;
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         }
         __syncthreads();
         const unsigned s4 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
-        if (MODE != 4 && MODE != 5 && tid < kSums) tot[tid] = row_sum(sums_t + tid * kRows, ng);
+        if (MODE != 4 && MODE != 5 && MODE != 8 && tid < kSums) tot[tid] = row_sum(sums_t + tid * kRows, ng);
         if (*fail) {
             if (tid == 0) atomicOr(P.err, 1);
             break;
@@ -410,10 +431,12 @@ int main(int argc, char **argv) {
     A.tail_permille = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const unsigned jitter = pass == 0 ? 0u : 150u;
-        run<16, 6, 2, false, 18, 24>("product form now (18 scalars, stride 24, 8 copies)", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 18, 24, true>("  a leader's members side by side", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 18, 24>("product form now, again", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 18, 24, true>("  side by side, again", G, iters, 200, jitter, 140, A);
+        run<16, 9, 2, false, 18, 24>("product form now (18 scalars, stride 24, 8 copies, DPP publish)", G, iters, 200, jitter, 140, A);
+        run<16, 8, 2, false, 18, 24>("  hops inside waves (4 scalars per wave, DPP rows)", G, iters, 200, jitter, 140, A);
+        run<16, 9, 2, false, 18, 24>("product form now, again", G, iters, 200, jitter, 140, A);
+        run<16, 8, 2, false, 18, 24>("  hops inside waves, again", G, iters, 200, jitter, 140, A);
     }
+    run<16, 9, 2, true, 18, 24>("product form now, stamps", G, iters, 200, 0, 140, A);
+    run<16, 8, 2, true, 18, 24>("hops inside waves, stamps", G, iters, 200, 0, 140, A);
     return 0;
 }
