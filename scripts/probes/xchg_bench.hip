@@ -15,7 +15,10 @@
 #include <vector>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kThreads = 512, kSumsMax = 19, kRows = 16, kMaxBlocks = 256;
+#ifndef XCHG_ROWS
+#define XCHG_ROWS 16
+#endif
+constexpr int kThreads = 512, kSumsMax = 19, kRows = XCHG_ROWS, kMaxBlocks = 256;  // (-DXCHG_ROWS=32: room for 8 leaders of 28 members / 32 leaders)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
@@ -431,12 +434,14 @@ int main(int argc, char **argv) {
     A.tail_permille = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const unsigned jitter = pass == 0 ? 0u : 150u;
-        run<16, 9, 2, false, 18, 24>("product form now (18 scalars, stride 24, 8 copies, DPP publish)", G, iters, 200, jitter, 140, A);
-        run<16, 8, 2, false, 18, 24>("  hops inside waves (4 scalars per wave, DPP rows)", G, iters, 200, jitter, 140, A);
-        run<16, 9, 2, false, 18, 24>("product form now, again", G, iters, 200, jitter, 140, A);
-        run<16, 8, 2, false, 18, 24>("  hops inside waves, again", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24>("16 leaders x 14 (LDS publish, 8 copies)", G, iters, 200, jitter, 140, A);
+#if XCHG_ROWS >= 32
+        run<8, 6, 2, false, 18, 24>("8 leaders x 28", G, iters, 200, jitter, 140, A);
+        run<32, 6, 2, false, 18, 24>("32 leaders x 7", G, iters, 200, jitter, 140, A);
+        run<28, 6, 2, false, 18, 24>("28 leaders x 8", G, iters, 200, jitter, 140, A);
+        run<12, 6, 2, false, 18, 24>("12 leaders x 19", G, iters, 200, jitter, 140, A);
+        run<20, 6, 2, false, 18, 24>("20 leaders x 12", G, iters, 200, jitter, 140, A);
+#endif
     }
-    run<16, 9, 2, true, 18, 24>("product form now, stamps", G, iters, 200, 0, 140, A);
-    run<16, 8, 2, true, 18, 24>("hops inside waves, stamps", G, iters, 200, 0, 140, A);
     return 0;
 }
