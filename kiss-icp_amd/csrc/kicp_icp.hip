@@ -915,6 +915,9 @@ __device__ __forceinline__ double icp_row_sum(const double *row, int count, bool
     if (count == kIcpSumRows) {
 #pragma unroll
         for (int j = 0; j < kIcpSumRows; ++j) v = v + a[j];
+    } else if (count == kIcpSumRows - 2) {  // (a leader's 14 members at 224 workgroups: the additions without their selects)
+#pragma unroll
+        for (int j = 0; j < kIcpSumRows - 2; ++j) v = v + a[j];
     } else {
 #pragma unroll
         for (int j = 0; j < kIcpSumRows; ++j) {
@@ -2000,8 +2003,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             // groups of a wave run in lock step, a scan as long as the longer list, a list build of one half with the other
             // masked off, and a later iteration has a handful of searches per workgroup.  kIcpSpreadSearches, profiles/r06_t_*.)
             const int e_first = kIcpSpreadSearches ? (grp >> 1) + (kIcpGroupsPerBlock / 2) * (grp & 1) : grp;
+            // (a group's first search is asked for beside the count, not behind the test on it: one LDS round trip less in front of
+            // every workgroup's first search)
+            const int t_first = (int)sh.search_idx[e_first];
             for (int e = e_first; e < n_search;) {
-                const int t = (int)sh.search_idx[e];
+                const int t = e == e_first ? t_first : (int)sh.search_idx[e];
                 IcpPoint &pt = sh.pts[t];
                 IcpQueryMeta *meta = metas + ((base + t < n_meta) ? base + t : 0);
                 // (the point slot and the query's record in ONE round trip, as register copies: what decides about the list -- its
