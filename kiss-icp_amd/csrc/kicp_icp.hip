@@ -862,7 +862,13 @@ __device__ __forceinline__ void icp_terms_row(const double s[3], const double nn
 #pragma unroll
     for (int k = 0; k < 17; ++k) T[k] = 0.0;
     T[17] = (double)E;
-    if (d2 < DBL_MAX && sqrt(d2) < max_dist) {  // Registration.cpp:72 (strict)
+    // Registration.cpp:72: sqrt(d2) < max_dist, strict.  The root is taken only where it can decide: a squared distance 2^-40 below
+    // max_dist^2 or above it is on its side of the threshold whatever the two roundings do (a root and its chain of ~25 dependent
+    // instructions less on phase C's path, same verdicts).
+    const double m2 = max_dist * max_dist;
+    bool corr = d2 < m2 * (1.0 - 0x1p-40);
+    if (__builtin_expect(!corr && d2 < m2 * (1.0 + 0x1p-40), 0)) corr = sqrt(d2) < max_dist;
+    if (d2 < DBL_MAX && corr) {
         const double rx = s[0] - nn[0], ry = s[1] - nn[1], rz = s[2] - nn[2];
         const double r2 = (rx * rx + ry * ry) + rz * rz;
         const double w = (ks * ks) / ((ks + r2) * (ks + r2));
@@ -1956,9 +1962,11 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             }
             if (tid == 0) sh.next_point = kIcpGroupsPerBlock;  // the first 16 points that need a search go to the groups directly
             __syncthreads();
-            tile.ox = sh.origin[0];
-            tile.oy = sh.origin[1];
-            tile.oz = sh.origin[2];
+            if (it == 0) {  // (set by the first iteration's phase A and never again: the group form has the registers to keep it)
+                tile.ox = sh.origin[0];
+                tile.oy = sh.origin[1];
+                tile.oz = sh.origin[2];
+            }
             // ---- B0: queries that are outside their known window (all of them in the first iteration, a few
             // now and then later) establish a new one.  Kept apart from the searches: a voxel one group is
             // still fetching may be the neighbour another group is about to look for.
@@ -2345,7 +2353,17 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             r[5] = gather_passes;
         }
         gather_passes = 0;
-        if (sqrt(nrm2) < P.conv) {
+        // ||dx|| < convergence_criterion (Registration.cpp:163), the root taken only where it can decide (see icp_terms_row)
+        // (the group form: the thread-per-query form has no register to spare for the two bounds)
+        bool done;
+        if constexpr (WIDE) {
+            done = sqrt(nrm2) < P.conv;
+        } else {
+            const double conv2 = P.conv * P.conv;
+            done = nrm2 < conv2 * (1.0 - 0x1p-40);
+            if (__builtin_expect(!done && nrm2 < conv2 * (1.0 + 0x1p-40), 0)) done = sqrt(nrm2) < P.conv;
+        }
+        if (done) {
             converged = 1;
             break;
         }
