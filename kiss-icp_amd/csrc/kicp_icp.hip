@@ -2218,7 +2218,7 @@ __global__ __launch_bounds__(kIcpThreads) void k_icp(IcpParams P) {
             return true;
         };
         if ((int)blockIdx.x < ng) {
-            // leader: thread (k, j) fetches scalar k of the group's j-th member; 26 members per pass, all of a pass in flight
+            // leader: thread (k, j) fetches scalar k of the group's j-th member; kParts (28) members per pass, all of a pass in flight
             const int members = (G - (int)blockIdx.x + ng - 1) / ng;  // <= kIcpMaxMembers
             constexpr int kParts = kIcpThreads / KX;
             if (tid < kParts * KX) {
