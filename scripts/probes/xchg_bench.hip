@@ -258,9 +258,9 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                         const int w = e / kSums, k = e % kSums;
                         store_pair(mbox_r, (unsigned)(((w * NG + b) * kSums + k) * 16), epoch, tot[k]);
                     }
-            } else if (MODE == 6 || MODE == 7 || MODE == 9) {
+            } else if (MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10 || MODE == 11) {
                 // a copy of the group's sums per XCD (MODE 6: 8 copies, MODE 7: 2): a line is polled by 28 (112) workgroups, not 224
-                constexpr int COPIES = MODE == 7 ? 2 : 8;
+                constexpr int COPIES = MODE == 7 ? 2 : (MODE == 10 ? 4 : (MODE == 11 ? 16 : 8));
                 if (tid < kSums) {
                     const double v = row_sum(sums_t + tid * kRows, members);
                     if (!*fail) {
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                 if (!poll(grp_r, (unsigned)((g * ST + k) * 16), v)) *fail = 1;
                 sums_t[k * kRows + g] = v;
             }
-        } else if (MODE == 6 || MODE == 7 || MODE == 9) {
-            constexpr int COPIES = MODE == 7 ? 2 : 8;
+        } else if (MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10 || MODE == 11) {
+            constexpr int COPIES = MODE == 7 ? 2 : (MODE == 10 ? 4 : (MODE == 11 ? 16 : 8));
             const int c = b % COPIES;
             for (int e = tid; e < ng * kSums; e += kThreads) {
                 const int k = e % kSums, g = e / kSums;
@@ -434,14 +434,11 @@ int main(int argc, char **argv) {
     A.tail_permille = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const unsigned jitter = pass == 0 ? 0u : 150u;
-        run<16, 6, 2, false, 18, 24>("16 leaders x 14 (LDS publish, 8 copies)", G, iters, 200, jitter, 140, A);
-#if XCHG_ROWS >= 32
-        run<8, 6, 2, false, 18, 24>("8 leaders x 28", G, iters, 200, jitter, 140, A);
-        run<32, 6, 2, false, 18, 24>("32 leaders x 7", G, iters, 200, jitter, 140, A);
-        run<28, 6, 2, false, 18, 24>("28 leaders x 8", G, iters, 200, jitter, 140, A);
-        run<12, 6, 2, false, 18, 24>("12 leaders x 19", G, iters, 200, jitter, 140, A);
-        run<20, 6, 2, false, 18, 24>("20 leaders x 12", G, iters, 200, jitter, 140, A);
-#endif
+        run<16, 0, 2, false, 18, 24>("one copy of the group sums", G, iters, 200, jitter, 140, A);
+        run<16, 7, 2, false, 18, 24>("2 copies", G, iters, 200, jitter, 140, A);
+        run<16, 10, 2, false, 18, 24>("4 copies", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24>("8 copies", G, iters, 200, jitter, 140, A);
+        run<16, 11, 2, false, 18, 24>("16 copies", G, iters, 200, jitter, 140, A);
     }
     return 0;
 }
