@@ -432,13 +432,13 @@ int main(int argc, char **argv) {
     CK(hipMemset(A.grp_gran, 0, grp_bytes));
     CK(hipMemset(A.mailbox, 0, mbox_bytes));
     A.tail_permille = 0;
+    // the product's form of today (18 scalars on 384-byte blocks, eight copies, DPP publish) and the same with the LDS publish
     for (int pass = 0; pass < 2; ++pass) {
         const unsigned jitter = pass == 0 ? 0u : 150u;
-        run<16, 0, 2, false, 18, 24>("one copy of the group sums", G, iters, 200, jitter, 140, A);
-        run<16, 7, 2, false, 18, 24>("2 copies", G, iters, 200, jitter, 140, A);
-        run<16, 10, 2, false, 18, 24>("4 copies", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 18, 24>("8 copies", G, iters, 200, jitter, 140, A);
-        run<16, 11, 2, false, 18, 24>("16 copies", G, iters, 200, jitter, 140, A);
+        run<16, 9, 2, false, 18, 24>("product form now", G, iters, 200, jitter, 140, A);
+        run<16, 6, 2, false, 18, 24>("  with the LDS publish", G, iters, 200, jitter, 140, A);
     }
+    run<16, 9, 2, true, 18, 24>("product form now, stamps", G, iters, 200, 0, 140, A);
+    run<16, 9, 2, false, 18, 24>("product form now, nothing around it", G, iters, 0, 0, 0, A);
     return 0;
 }
