@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
         busy(P.work_ticks + extra);
         const unsigned s0 = STAMPS ? (unsigned)(wall_clock64() - t_start) : 0u;
         // ---- workgroup reduction
-        constexpr bool DPUB = MODE == 5 || MODE == 8 || MODE == 9;  // the workgroup's own reduction by DPP rows
+        constexpr bool DPUB = MODE == 5 || MODE == 8 || MODE == 9 || MODE == 12;  // the workgroup's own reduction by DPP rows
         if (!DPUB) {
             if (cg < kRows) part_t[ck * kRows + cg] = (cg == 0) ? (double)(b + 1) * (double)(ck + 1) + (double)it : 0.0;
             if (tid < kRows) part_t[18 * kRows + tid] = 0.0;
@@ -186,7 +186,19 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
             out = v;
             return true;
         };
-        if (MODE == 8) {
+        if (MODE == 12) {
+            // the leader's gather inside waves (a wave takes four scalars of all members: four DPP row operations, no LDS staging, no
+            // barrier in front of the group sums); the second hop staged as in the product
+            const int wv = tid >> 6, kk = (tid >> 4) & 3, jj = tid & 15;
+            const int k8 = wv * 4 + kk;
+            if (b < ng && k8 < kSums) {
+                const int members = (G - b + ng - 1) / ng;
+                double v = 0.0;
+                if (jj < members && !poll(gran_r, (unsigned)((place(b + ng * jj) * ST + k8) * 16), v)) *fail = 1;
+                v = row16_sum(v);
+                if (jj < 8) store_pair(mbox_r, (unsigned)(((jj * 64 + b) * ST + k8) * 16), epoch, v);
+            }
+        } else if (MODE == 8) {
             // a wave takes four scalars of all addends (lane 16 kk + j): the reduction stays inside the wave -- four DPP row operations,
             // no LDS staging, no workgroup barrier between the hops; a wave's poll asks for one 64-byte piece of every block
             const int wv = tid >> 6, kk = (tid >> 4) & 3, jj = tid & 15;
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void k_xchg(Args P) {
                 if (!poll(grp_r, (unsigned)((g * ST + k) * 16), v)) *fail = 1;
                 sums_t[k * kRows + g] = v;
             }
-        } else if (MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10 || MODE == 11) {
+        } else if (MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10 || MODE == 11 || MODE == 12) {
             constexpr int COPIES = MODE == 7 ? 2 : (MODE == 10 ? 4 : (MODE == 11 ? 16 : 8));
             const int c = b % COPIES;
             for (int e = tid; e < ng * kSums; e += kThreads) {
@@ -432,13 +444,13 @@ int main(int argc, char **argv) {
     CK(hipMemset(A.grp_gran, 0, grp_bytes));
     CK(hipMemset(A.mailbox, 0, mbox_bytes));
     A.tail_permille = 0;
-    // the product's form of today (18 scalars on 384-byte blocks, eight copies, DPP publish) and the same with the LDS publish
     for (int pass = 0; pass < 2; ++pass) {
         const unsigned jitter = pass == 0 ? 0u : 150u;
         run<16, 9, 2, false, 18, 24>("product form now", G, iters, 200, jitter, 140, A);
-        run<16, 6, 2, false, 18, 24>("  with the LDS publish", G, iters, 200, jitter, 140, A);
+        run<16, 12, 2, false, 18, 24>("  the leader's gather inside waves", G, iters, 200, jitter, 140, A);
+        run<16, 9, 2, false, 18, 24>("product form now, again", G, iters, 200, jitter, 140, A);
+        run<16, 12, 2, false, 18, 24>("  inside waves, again", G, iters, 200, jitter, 140, A);
     }
-    run<16, 9, 2, true, 18, 24>("product form now, stamps", G, iters, 200, 0, 140, A);
-    run<16, 9, 2, false, 18, 24>("product form now, nothing around it", G, iters, 0, 0, 0, A);
+    run<16, 12, 2, true, 18, 24>("the leader's gather inside waves, stamps", G, iters, 200, 0, 140, A);
     return 0;
 }
